@@ -1,0 +1,292 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz|json by running the UNMODIFIED reference on CPU.
+
+Run in the build container only (needs /root/reference):
+
+    python scripts/gen_golden.py            # all cases
+    python scripts/gen_golden.py mel stream_micro
+
+The reference is imported with the three harness-side stubs of scripts/ref_stubs.py; weights
+are the seeded synthetic checkpoints of whisperlivekit_amd.synth loaded into the reference's own
+``Whisper`` module; audio is whisperlivekit_amd.synth's generators after the int16 round trip
+AudioProcessor applies.  What is recorded per case is described next to each writer below.
+The committed fixtures are what tests/test_oracle_golden.py (CPU) and tests/test_gpu_parity.py
+(GPU, through the C ABI) compare against.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_stubs  # noqa: E402
+
+ref_stubs.install(synthetic_vocab=True)
+
+from whisperlivekit.simul_whisper.backend import SimulStreamingOnlineProcessor  # noqa: E402
+from whisperlivekit.simul_whisper.config import AlignAttConfig  # noqa: E402
+from whisperlivekit.timed_objects import ChangeSpeaker  # noqa: E402
+from whisperlivekit.whisper.audio import log_mel_spectrogram, pad_or_trim  # noqa: E402
+from whisperlivekit.whisper.model import ModelDimensions, Whisper  # noqa: E402
+
+from whisperlivekit_amd import synth  # noqa: E402
+from whisperlivekit_amd.dims import ALIGNMENT_HEADS, MODEL_DIMS  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+PROBE_IDS = np.arange(7, 51864, 101)  # fixed vocabulary probes kept from every logits row
+
+torch.set_num_threads(8)
+
+
+def build_reference_model(name: str, seed: int = 0):
+    dims = MODEL_DIMS[name]
+    model = Whisper(ModelDimensions(*dims.as_tuple()))
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(dims, seed).items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    mask = torch.zeros(dims.n_text_layer, dims.n_text_head, dtype=torch.bool)
+    for l, h in ALIGNMENT_HEADS[name]:
+        mask[l, h] = True
+    model.register_buffer("alignment_heads", mask.to_sparse(), persistent=False)
+    return model.eval()
+
+
+def engine_cfg(name: str, **over) -> AlignAttConfig:
+    kw = dict(tokenizer_is_multilingual=not name.endswith(".en"), segment_length=0.5,
+              frame_threshold=25, language="en", audio_max_len=30.0, audio_min_len=0.0,
+              cif_ckpt_path=None, decoder_type="beam", beam_size=1, task="transcribe",
+              never_fire=False, init_prompt=None, max_context_tokens=None, static_init_prompt=None)
+    kw.update(over)
+    return AlignAttConfig(**kw)
+
+
+def make_processor(model, cfg):
+    asr = types.SimpleNamespace(cfg=cfg, shared_model=model, use_full_mlx=False, mlx_encoder=None,
+                                fw_encoder=None, tokenizer=None)
+    return SimulStreamingOnlineProcessor(asr)
+
+
+# ---------------------------------------------------------------------------------------
+def gen_mel():
+    """log-mel of the streaming path (padding=480000, first 3000 frames) for edge-case lengths.
+    Kept: the leading ``keep`` frames (content + 8), the value every later frame has, content_mel_len."""
+    out = {}
+    meta = {}
+    for n_mels in (80, 128):
+        for tag, n, kind, seed in (("0p5s", 8000, "speech", 0), ("2s", 32000, "speech", 1),
+                                   ("1sample", 1, "noise", 2), ("odd", 12345, "noise", 3),
+                                   ("29p99s", 479840, "speech", 4), ("30s", 480000, "speech", 5),
+                                   ("31s", 496000, "noise", 6), ("silence", 16000, "zeros", 0)):
+            if n_mels == 128 and tag not in ("2s", "30s"):
+                continue
+            if kind == "speech":
+                a = synth.to_pcm16_roundtrip(synth.speech_like(n / 16000, seed))[:n]
+            elif kind == "noise":
+                a = synth.to_pcm16_roundtrip(synth.white_noise(max(n, 16) / 16000, seed))[:n]
+            else:
+                a = np.zeros(n, np.float32)
+            mel_padded = log_mel_spectrogram(torch.from_numpy(a), n_mels=n_mels, padding=480000,
+                                             device="cpu").unsqueeze(0)
+            mel = pad_or_trim(mel_padded, 3000)
+            cml = int((mel_padded.shape[2] - mel.shape[2]) / 2)
+            keep = min(3000, n // 160 + 8)
+            key = f"m{n_mels}_{tag}"
+            full = mel[0, :, :keep].numpy()
+            if keep > 400:   # long clips: keep three 96-frame windows + per-frame means
+                wins = [0, (keep // 2) - 48, keep - 96]
+                out[key] = np.concatenate([full[:, w:w + 96] for w in wins], axis=1)
+                out[key + "_colmean"] = full.mean(axis=0)
+            else:
+                wins = None
+                out[key] = full
+            tail = mel[0, :, keep:]
+            meta[key] = dict(n=n, kind=kind, seed=seed, n_mels=n_mels, content_mel_len=cml, keep=keep,
+                             windows=wins,
+                             tail_value=float(tail[0, 0]) if tail.numel() else None,
+                             tail_const=bool((tail == tail[0, 0]).all()) if tail.numel() else True)
+    np.savez_compressed(os.path.join(OUT, "mel.npz"), **out)
+    json.dump(meta, open(os.path.join(OUT, "mel.json"), "w"), indent=1)
+    print("mel:", {k: v.shape for k, v in out.items()})
+
+
+# ---------------------------------------------------------------------------------------
+def gen_model_numerics():
+    """Encoder output, decoder logits and cross-attention QK from the reference modules for
+    micro.en / tiny.en / base.en on a 3.2 s clip: prefill of 7 tokens, then 2 single-token steps."""
+    for name in ("micro.en", "tiny.en", "base.en"):
+        model = build_reference_model(name, seed=0)
+        dims = MODEL_DIMS[name]
+        a = synth.to_pcm16_roundtrip(synth.speech_like(3.2, 11))
+        mel_padded = log_mel_spectrogram(torch.from_numpy(a), n_mels=dims.n_mels, padding=480000,
+                                         device="cpu").unsqueeze(0)
+        mel = pad_or_trim(mel_padded, 3000)
+        with torch.no_grad():
+            enc = model.encoder(mel)
+            kv = {}
+            toks = torch.tensor([[50360, 400, 2001, 50257, 50362, 1234, 777]])
+            out = {"enc_rows": enc[0, ::50].numpy(), "enc_abs_mean": np.float32(enc.abs().mean()),
+                   "tokens": toks.numpy()}
+            feeds = [toks, torch.tensor([[31000]]), torch.tensor([[46]])]
+            for si, feed in enumerate(feeds):
+                logits, cross = model.decoder(feed, enc, kv_cache=kv, return_cross_attn=True)
+                last = logits[0, -1]
+                top = last.topk(16)
+                out[f"s{si}_top_ids"] = top.indices.numpy()
+                out[f"s{si}_top_vals"] = top.values.numpy()
+                out[f"s{si}_probe"] = last[torch.from_numpy(PROBE_IDS)].numpy()
+                out[f"s{si}_lse"] = np.float32(torch.logsumexp(last, -1))
+                if si == 0:
+                    out["s0_row3_probe"] = logits[0, 3][torch.from_numpy(PROBE_IDS)].numpy()
+                for (l, h) in ALIGNMENT_HEADS[name]:
+                    out[f"s{si}_qk_l{l}h{h}"] = cross[l][0, h, :, ::3].numpy()   # [rows, 500]
+        np.savez_compressed(os.path.join(OUT, f"numerics_{name}.npz"), **out)
+        print("numerics", name, "ok")
+
+
+# ---------------------------------------------------------------------------------------
+def _record_session(proc):
+    """Wrap the reference AlignAtt hooks of one processor to log what each call computed."""
+    m = proc.model
+    log = {"calls": []}
+    cur = {}
+
+    orig_encode = m._encode
+    def _encode(segs):
+        enc, cml = orig_encode(segs)
+        cur.clear()
+        cur.update(n_samples=int(segs.shape[0]), content_mel_len=int(cml),
+                   enc_abs_mean=float(enc.abs().mean()), enc_probe=enc[0, ::300, ::37].flatten().tolist(),
+                   steps=[])
+        log["calls"].append(cur.copy())
+        log["calls"][-1]["steps"] = cur["steps"]
+        return enc, cml
+    m._encode = _encode
+
+    orig_logits = m._get_logits_and_cross_attn
+    def _logits(tokens, enc):
+        logits, cross = orig_logits(tokens, enc)
+        last = logits[0, -1]
+        top = last.topk(4)
+        st = dict(fed=int(tokens.shape[1]), fed_tokens=tokens[0].tolist() if tokens.shape[1] > 1 else None,
+                  raw_top_ids=top.indices.tolist(), raw_top_vals=top.values.tolist(),
+                  raw_lse=float(torch.logsumexp(last, -1)))
+        cur["steps"].append(st)
+        return logits, cross
+    m._get_logits_and_cross_attn = _logits
+
+    orig_ns = m._check_no_speech
+    def _ns(logits):
+        p = logits[:, m.state.sot_index, :].float().softmax(dim=-1)[:, m.tokenizer.no_speech].tolist()
+        cur["steps"][-1]["no_speech_prob"] = p[0]
+        return orig_ns(logits)
+    m._check_no_speech = _ns
+
+    orig_upd = m._update_tokens
+    def _upd(tokens, logits, slp):
+        lp = torch.log_softmax(logits.float(), -1)
+        top = lp[0].topk(3)
+        new, completed = orig_upd(tokens, logits, slp)
+        cur["steps"][-1].update(token=int(new[0, -1]), completed=bool(completed),
+                                tokens_all=[r.tolist()[-1] for r in new],
+                                lp_top_ids=top.indices.tolist(), lp_top_vals=top.values.tolist(),
+                                sum_logprobs=slp.tolist())
+        return new, completed
+    m._update_tokens = _upd
+
+    orig_fr = m._get_attended_frames
+    def _fr(attn):
+        frames, first = orig_fr(attn)
+        row = attn[0, -1]
+        t2 = row.topk(min(2, row.numel()))
+        cur["steps"][-1].update(frame=int(first), frames=list(frames), attn_rows=int(attn.shape[1]),
+                                attn_top_vals=t2.values.tolist(), attn_top_ids=t2.indices.tolist())
+        return frames, first
+    m._get_attended_frames = _fr
+    return log
+
+
+def _toks(tokens):
+    return [[float(t.start), float(t.end), t.text, int(t.speaker)] for t in tokens]
+
+
+def run_stream(name, audio, cfg_over=None, chunk=8000, script=None, seed=0, chunks=None):
+    """Feed ``audio`` through the reference online processor in ``chunk``-sample pieces.
+    ``script`` maps a chunk index to an event performed BEFORE that chunk is inserted:
+    ("silence", seconds) -> start_silence()+end_silence(), ("speaker", id) -> new_speaker()."""
+    model = build_reference_model(name, seed)
+    cfg = engine_cfg(name, **(cfg_over or {}))
+    proc = make_processor(model, cfg)
+    if cfg_over and "nonspeech_prob" in cfg_over:
+        proc.model.cfg.nonspeech_prob = cfg_over["nonspeech_prob"]
+    log = _record_session(proc)
+    events = []
+    script = script or {}
+    bounds = chunks or [(i, min(i + chunk, len(audio))) for i in range(0, len(audio), chunk)]
+    t_end = 0.0
+    for ci, (lo, hi) in enumerate(bounds):
+        if ci in script:
+            kind, arg = script[ci]
+            n_before = len(log["calls"])
+            if kind == "silence":
+                toks, upto = proc.start_silence()
+                proc.end_silence(arg, t_end)
+                t_end += arg
+                events.append(dict(kind="silence", at_chunk=ci, arg=arg, tokens=_toks(toks), upto=upto,
+                                   call=n_before if len(log["calls"]) > n_before else None))
+            elif kind == "speaker":
+                toks, upto = proc.new_speaker(ChangeSpeaker(speaker=arg, start=t_end))
+                events.append(dict(kind="speaker", at_chunk=ci, arg=arg, tokens=_toks(toks), upto=upto,
+                                   call=n_before if len(log["calls"]) > n_before else None))
+        t_end += (hi - lo) / 16000
+        proc.insert_audio_chunk(audio[lo:hi].copy(), t_end)
+        n_before = len(log["calls"])
+        toks, upto = proc.process_iter()
+        events.append(dict(kind="chunk", at_chunk=ci, lo=lo, hi=hi, tokens=_toks(toks), upto=upto,
+                           call=n_before if len(log["calls"]) > n_before else None,
+                           hypothesis=[t[0].tolist() for t in proc.model.state.tokens[1:]][-1]
+                           if len(proc.model.state.tokens) > 1 else [],
+                           context=proc.model.state.context.text,
+                           last_attend_frame=int(proc.model.state.last_attend_frame),
+                           cumulative_time_offset=float(proc.model.state.cumulative_time_offset)))
+    return dict(model=name, seed=seed, cfg=cfg_over or {}, chunk=chunk, n_samples=len(audio),
+                calls=log["calls"], events=events)
+
+
+def gen_streams():
+    cases = {}
+    a12 = synth.to_pcm16_roundtrip(synth.speech_like(12.0, 0))
+    cases["micro_12s"] = run_stream("micro.en", a12)
+    a34 = synth.to_pcm16_roundtrip(synth.speech_like(34.0, 1))
+    cases["micro_34s_evict"] = run_stream("micro.en", a34, chunk=16000)
+    cases["micro_beam2"] = run_stream("micro.en", a12[:96000], cfg_over=dict(beam_size=2))
+    cases["micro_neverfire"] = run_stream("micro.en", a12[:96000], cfg_over=dict(never_fire=True))
+    cases["micro_nospeech"] = run_stream("micro.en", a12[:48000], cfg_over=dict(nonspeech_prob=1e-7))
+    cases["micro_events"] = run_stream("micro.en", a12, script={6: ("silence", 1.0), 12: ("silence", 6.0),
+                                                               18: ("speaker", 2)})
+    n8 = synth.to_pcm16_roundtrip(synth.white_noise(6.0, 3))
+    cases["micro_noise_ragged"] = run_stream(
+        "micro.en", n8, chunks=[(0, 700), (700, 861), (861, 5000), (5000, 5000 + 8000), (13000, 40000),
+                                (40000, 96000)])
+    a6 = synth.to_pcm16_roundtrip(synth.speech_like(6.0, 2))
+    cases["tiny_6s"] = run_stream("tiny.en", a6)
+    cases["base_4s"] = run_stream("base.en", a6[:64000])
+    for k, v in cases.items():
+        json.dump(v, open(os.path.join(OUT, f"stream_{k}.json"), "w"))
+        n_steps = sum(len(c["steps"]) for c in v["calls"])
+        n_tok = sum(len(e["tokens"]) for e in v["events"])
+        print(f"stream {k}: {len(v['calls'])} calls, {n_steps} decode steps, {n_tok} words")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = set(sys.argv[1:])
+    if not which or "mel" in which:
+        gen_mel()
+    if not which or "numerics" in which:
+        gen_model_numerics()
+    if not which or "streams" in which:
+        gen_streams()

@@ -1,0 +1,116 @@
+"""Pins the CPU oracle against outputs of the reference itself (tests/golden, produced by
+scripts/gen_golden.py).  CPU only.  Mel/logits tolerance is the north-star 1e-3 with a much
+tighter expectation written beside it; ids, frames, tokens and timestamps must be identical."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from oracle import whisper_oracle as wo
+from whisperlivekit_amd.dims import ALIGNMENT_HEADS, MODEL_DIMS
+from whisperlivekit_amd.melbank import mel_filterbank
+
+MEL_META = H.golden_json("mel.json")
+
+
+@pytest.mark.parametrize("key", sorted(MEL_META))
+def test_oracle_mel_matches_reference(key):
+    meta = MEL_META[key]
+    gold = H.golden_npz("mel.npz")
+    audio = torch.from_numpy(H.mel_case_audio(meta))
+    mel, cml = wo.encoder_input_from_audio(audio, torch.from_numpy(mel_filterbank(meta["n_mels"])))
+    assert cml == meta["content_mel_len"]
+    mel = mel[0].numpy()
+    for lo, hi, ref in H.expand_mel_golden(gold[key], meta):
+        assert np.abs(mel[:, lo:hi] - ref).max() <= 1e-6      # same torch ops: expect 0
+    if meta["tail_value"] is not None:
+        assert np.all(mel[:, meta["keep"]:] == np.float32(meta["tail_value"]))
+    if key + "_colmean" in gold:
+        assert np.abs(mel[:, :meta["keep"]].mean(axis=0) - gold[key + "_colmean"]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["micro.en", "tiny.en", "base.en"])
+def test_oracle_encoder_decoder_match_reference(name):
+    gold = H.golden_npz(f"numerics_{name}.npz")
+    dims = MODEL_DIMS[name]
+    sd = H.oracle_sd(name)
+    from whisperlivekit_amd import synth
+    audio = torch.from_numpy(synth.to_pcm16_roundtrip(synth.speech_like(3.2, 11)))
+    with torch.no_grad():
+        mel, _ = wo.encoder_input_from_audio(audio, torch.from_numpy(mel_filterbank(dims.n_mels)))
+        enc = wo.encoder_forward(sd, dims, mel)
+        assert np.abs(enc[0, ::50].numpy() - gold["enc_rows"]).max() <= 1e-5
+        cache = wo.DecoderCache(dims.n_text_layer)
+        feeds = [torch.from_numpy(gold["tokens"]), torch.tensor([[31000]]), torch.tensor([[46]])]
+        for si, feed in enumerate(feeds):
+            logits, cross = wo.decoder_forward(sd, dims, feed, enc, cache)
+            last = logits[0, -1]
+            assert last.topk(16).indices.tolist() == gold[f"s{si}_top_ids"].tolist()
+            assert np.abs(last[torch.from_numpy(H.PROBE_IDS)].numpy() - gold[f"s{si}_probe"]).max() <= 1e-5
+            assert abs(float(torch.logsumexp(last, -1)) - float(gold[f"s{si}_lse"])) <= 1e-5
+            for (l, h) in ALIGNMENT_HEADS[name]:
+                assert np.abs(cross[l][0, h, :, ::3].numpy() - gold[f"s{si}_qk_l{l}h{h}"]).max() <= 1e-5
+
+
+STREAMS = ["micro_12s", "micro_34s_evict", "micro_beam2", "micro_neverfire", "micro_nospeech",
+           "micro_events", "micro_noise_ragged", "tiny_6s", "base_4s"]
+
+
+def replay_stream(case, make_processor):
+    """Drive a processor exactly as scripts/gen_golden.py:run_stream drove the reference; returns
+    the list of (event, tokens, upto)."""
+    g = H.golden_json(f"stream_{case}.json")
+    audio = H.stream_audio(case)
+    proc = make_processor(g["model"], g["cfg"])
+    t_end = 0.0
+    got = []
+    for ev in g["events"]:
+        if ev["kind"] == "silence":
+            toks, upto = proc.start_silence()
+            proc.end_silence(ev["arg"], t_end)
+            t_end += ev["arg"]
+        elif ev["kind"] == "speaker":
+            toks, upto = proc.new_speaker(ev["arg"], t_end)
+        else:
+            t_end += (ev["hi"] - ev["lo"]) / 16000
+            proc.insert_audio_chunk(audio[ev["lo"]:ev["hi"]].copy(), t_end)
+            toks, upto = proc.process_iter()
+        got.append((ev, toks, upto))
+    return g, proc, got
+
+
+def check_stream_against_golden(g, trace, got, tol=1e-4):
+    """trace: list of per-infer dicts with content_mel_len / prefill_tokens / steps / hypothesis."""
+    assert len(trace) == len(g["calls"])
+    for rec, ref in zip(trace, g["calls"]):
+        assert rec["content_mel_len"] == ref["content_mel_len"]
+        assert len(rec["steps"]) == len(ref["steps"])
+        if ref["steps"] and ref["steps"][0]["fed_tokens"] is not None:
+            assert rec["prefill_tokens"] == ref["steps"][0]["fed_tokens"]
+        for st, rs in zip(rec["steps"], ref["steps"]):
+            assert st["fed"] == rs["fed"]
+            if "no_speech_prob" in rs and rs["no_speech_prob"] is not None:
+                assert abs(st["no_speech_prob"] - rs["no_speech_prob"]) <= 1e-6
+            if rs.get("token") is not None:
+                assert st["token"] == rs["token"]
+                assert st["completed"] == rs["completed"]
+                assert st["frame"] == rs["frame"]
+                assert abs(st["sum_logprob"] - rs["sum_logprobs"][0]) <= tol
+    for ev, toks, upto in got:
+        want = ev["tokens"]
+        assert [(round(t.start, 2), round(t.end, 2), t.text, t.speaker) for t in toks] == \
+               [(round(s, 2), round(e, 2), x, sp) for s, e, x, sp in want]
+        assert abs(upto - ev["upto"]) < 1e-9
+
+
+@pytest.mark.parametrize("case", STREAMS)
+def test_oracle_stream_matches_reference(case):
+    def mk(model, cfg):
+        return wo.OracleOnlineProcessor(H.make_oracle_session(model, cfg))
+    g, proc, got = replay_stream(case, mk)
+    check_stream_against_golden(g, proc.model.trace, got)
+    for ev, _, _ in got:
+        if ev["kind"] == "chunk":
+            last = ev
+    assert proc.model.context_text == last["context"]
+    assert proc.model.last_attend_frame == last["last_attend_frame"]
