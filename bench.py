@@ -1,0 +1,254 @@
+#!/usr/bin/env python
+"""Benchmark of the simul_whisper hot path on MI355X (BASELINE.json: real-time factor + p50
+committed-token latency, Whisper-base EN, 0.5 s chunks).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One STEP = one 30 s synthetic 16 kHz stream pushed through the per-session online processor in 60
+chunks of 0.5 s (insert_audio_chunk + process_iter per chunk, compute-unaware = back to back), i.e.
+60 passes of  log-mel -> encoder -> cross-K/V -> prefill -> AlignAtt decode loop.  Each rank runs
+its own stream(s) against its own weight replica (weights reach ranks > 0 by ONE RCCL broadcast);
+there is no steady-state collective.  Rank 0 prints one JSON line.
+
+value = audio seconds transcribed per wall second over the whole job (= 1 / RTF for one stream);
+`rtf` and the p50/p95 committed-token latency (compute-aware replay of the measured call times) are
+extra keys of the same line, as are `roofline` (dominant kernel, HIP-event timed, algorithmic
+FLOPs) and `cpu_baseline` (the torch-CPU oracle = port of the reference, on a bounded sample).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CHUNK = 8000            # 0.5 s
+STREAM_SECONDS = 30.0
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA peak
+PEAK_HBM_GBPS = 8000.0
+
+# launch tag -> kernel function (what rocprofv3 --stats reports)
+KERNEL_OF_TAG = {
+    "enc_conv1": "gemm_nt_f32_kernel", "enc_conv2": "gemm_nt_f32_kernel", "enc_qkv": "gemm_nt_f32_kernel",
+    "enc_out": "gemm_nt_f32_kernel", "enc_fc1": "gemm_nt_f32_kernel", "enc_fc2": "gemm_nt_f32_kernel",
+    "dec_cross_kv": "gemm_nt_f32_kernel", "enc_attention": "encoder_attention_kernel",
+    "dec_cross_attention": "decoder_cross_attention_kernel",
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="base.en")
+    ap.add_argument("--streams-per-gpu", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=STREAM_SECONDS)
+    ap.add_argument("--cpu-chunks", type=int, default=12, help="chunks of the stream the CPU baseline replays")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--audio", default="speech", choices=["speech", "noise"])
+    return ap.parse_args()
+
+
+def make_audio(kind, seconds, seed):
+    from whisperlivekit_amd import synth
+    gen = synth.speech_like if kind == "speech" else synth.white_noise
+    return synth.to_pcm16_roundtrip(gen(seconds, seed))
+
+
+def run_stream(proc, audio):
+    """-> per-call records [(call wall s, insert wall s, [token end times])]."""
+    calls = []
+    t_end = 0.0
+    for lo in range(0, len(audio), CHUNK):
+        chunk = audio[lo:lo + CHUNK]
+        t_end += len(chunk) / 16000
+        t0 = time.perf_counter()
+        proc.insert_audio_chunk(chunk, t_end)
+        t1 = time.perf_counter()
+        tokens, _ = proc.process_iter()
+        t2 = time.perf_counter()
+        calls.append((t2 - t1, t1 - t0, [float(t.end) for t in tokens], t_end))
+    return calls
+
+
+def committed_latencies(calls):
+    """Compute-aware replay: chunk k is available at its stream time; a call starts when both the
+    chunk has arrived and the previous call has finished; latency = finish - token.end."""
+    lat = []
+    free_at = 0.0
+    for wall, ins, ends, t_arrive in calls:
+        start = max(t_arrive, free_at)
+        free_at = start + ins + wall
+        lat += [free_at - e for e in ends]
+    return lat
+
+
+def main():
+    args = parse_args()
+    from whisperlivekit_amd import _lib, sharding, synth
+    from whisperlivekit_amd.backend import HipSimulStreamingASR, HipSimulStreamingOnlineProcessor
+    from whisperlivekit_amd.dims import ALIGNMENT_HEADS, MODEL_DIMS
+    from whisperlivekit_amd.engine import HipWhisperModel, pack_state_dict
+
+    rank, world, local = sharding.dist_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if _lib.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
+    import torch
+    dims = MODEL_DIMS[args.model]
+    heads = ALIGNMENT_HEADS[args.model]
+    if world > 1:
+        import torch.distributed as dist
+        sharding.init_process_group("nccl")
+        packed = pack_state_dict(dims, synth.synth_state_dict(dims, 0)) if rank == 0 else None
+        model = sharding.replicated_model(dims, packed, heads, device=local)
+    else:
+        dist = None
+        model = HipWhisperModel.from_state_dict(dims, synth.synth_state_dict(dims, 0), heads, device=local)
+    asr = HipSimulStreamingASR(args.model, hip_model=model)
+
+    n_local = args.streams_per_gpu
+    audios = [make_audio(args.audio, args.seconds, rank * n_local + i) for i in range(n_local)]
+    total_steps = args.warmup + args.steps
+    procs = [[HipSimulStreamingOnlineProcessor(asr) for _ in range(n_local)] for _ in range(total_steps)]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step(step_procs):
+        if n_local == 1:
+            return [run_stream(step_procs[0], audios[0])]
+        import concurrent.futures as cf
+        with cf.ThreadPoolExecutor(n_local) as ex:      # sessions are independent: one host thread each
+            return list(ex.map(lambda pa: run_stream(*pa), zip(step_procs, audios)))
+
+    for w in range(args.warmup):
+        one_step(procs[w])
+    barrier()
+    t0 = time.perf_counter()
+    records = []
+    for k in range(args.steps):
+        records.append(one_step(procs[args.warmup + k]))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- derived metrics on rank 0's own streams -------------------------------------------------
+    all_calls = [c for step in records for stream in step for c in stream]
+    asr_time = sum(c[0] for c in all_calls)
+    audio_s = args.seconds * n_local * args.steps
+    lat = [l for step in records for stream in step for l in committed_latencies(stream)]
+    errors = sum(1 for step in procs for p in step if getattr(p, "last_error", None) is not None)
+
+    # ---- roofline: one extra profiled replay of the same step (HIP events on the session stream) ---
+    prof_proc = HipSimulStreamingOnlineProcessor(asr)
+    prof_proc.model.session.prof_begin()
+    run_stream(prof_proc, audios[0])
+    prof = prof_proc.model.session.prof_end(cap=64)
+    by_kernel = {}
+    for tag, r in prof.items():
+        kname = KERNEL_OF_TAG.get(tag, tag)
+        k = by_kernel.setdefault(kname, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+        for f in ("ms", "launches", "flops", "bytes"):
+            k[f] += r[f]
+    dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
+    gpu_ms = sum(k["ms"] for k in by_kernel.values())
+    if dom["flops"] > 0 and dom_name in ("gemm_nt_f32_kernel", "encoder_attention_kernel"):
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        roof = dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS,
+                    unit="TFLOP/s", frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None)
+    else:
+        achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+        roof = dict(bound="hbm", kernel=dom_name, achieved=round(achieved, 2), peak=PEAK_HBM_GBPS, unit="GB/s",
+                    frac=round(achieved / PEAK_HBM_GBPS, 4), traffic=None)
+    roof.update(avg_launch_us=round(1e3 * dom["ms"] / max(dom["launches"], 1), 2), launches=dom["launches"],
+                share_of_gpu_time=round(dom["ms"] / gpu_ms, 3),
+                timing="HIP events around every launch, separate profiled replay of one step")
+    kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"],
+                       tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 3) if v["flops"] and v["ms"] else None,
+                       gbps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] and v["ms"] else None)
+               for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])}
+
+    # ---- CPU baseline: the oracle (torch-CPU port of the reference path) on a bounded sample --------
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle import whisper_oracle as wo
+        import helpers
+        torch.set_num_threads(os.cpu_count() or 1)
+        sess = wo.OracleAlignAtt(wo.to_torch_state_dict(synth.synth_state_dict(dims, 0)), dims, heads,
+                                 prof_proc.model.tokenizer, helpers.mel_filterbank(dims.n_mels),
+                                 wo.OracleConfig())
+        oproc = wo.OracleOnlineProcessor(sess)
+        n = min(args.cpu_chunks, len(audios[0]) // CHUNK)
+        t_cpu = 0.0
+        for i in range(n):
+            oproc.insert_audio_chunk(audios[0][i * CHUNK:(i + 1) * CHUNK], (i + 1) * 0.5)
+            a = time.perf_counter()
+            oproc.process_iter()
+            t_cpu += time.perf_counter() - a
+        cpu = dict(value=round(n * 0.5 / t_cpu, 4), unit="audio_s/s", cores=torch.get_num_threads(), kind="port",
+                   rtf=round(t_cpu / (n * 0.5), 4),
+                   sample=f"first {n} chunks ({n * 0.5:.1f} s) of the same {args.model} stream, "
+                          f"torch {torch.__version__} CPU fp32 oracle, {t_cpu:.1f} s of CPU work")
+
+    if rank == 0:
+        timed = [p for step in procs[args.warmup:] for p in step]
+        n_enc = sum(p.model.counters["encode"] for p in timed)
+        n_dec = sum(p.model.counters["decode"] for p in timed)
+        n_pre = sum(p.model.counters["prefill_tokens"] for p in timed)
+        out = {
+            "metric": "audio seconds transcribed per second (1/RTF), Whisper-base EN simul_whisper AlignAtt, "
+                      "0.5 s chunks; rtf and p50 committed-token latency alongside",
+            "value": round(args.seconds * n_local * world * args.steps / elapsed, 3),
+            "unit": "audio_s/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model} simul_whisper, {n_local} stream(s)/GPU, {args.seconds:g} s "
+                                   f"16 kHz {args.audio}-like stream, 0.5 s chunks, beam 1, frame_threshold 25, "
+                                   "seeded random weights, synthetic vocabulary",
+                       "model": args.model, "streams_per_gpu": n_local, "chunk_s": 0.5},
+            "rtf": round(asr_time / audio_s, 5),
+            "rtf_wall_inclusive": round(elapsed * 1.0 / (args.seconds * args.steps), 5),
+            "p50_committed_token_latency_ms": round(1e3 * statistics.median(lat), 2) if lat else None,
+            "p95_committed_token_latency_ms": round(1e3 * float(np.percentile(lat, 95)), 2) if lat else None,
+            "committed_tokens": len(lat),
+            "calls": len(all_calls),
+            "decode_steps_per_call": round(n_dec / max(n_enc, 1), 2),
+            "prefill_tokens_per_call": round(n_pre / max(n_enc, 1), 2),
+            "p50_call_ms": round(1e3 * statistics.median(c[0] for c in all_calls), 3),
+            "p50_insert_ms": round(1e3 * statistics.median(c[1] for c in all_calls), 3),
+            "swallowed_errors": errors,
+            "roofline": roof,
+            "gpu_kernel_ms_per_step": round(gpu_ms, 2),
+            "kernels": kernels,
+            "cpu_baseline": cpu,
+            "host_cores": os.cpu_count(),
+        }
+        print(json.dumps(out))
+    for step in procs:
+        for p in step:
+            p.close()
+    prof_proc.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,150 @@
+/*
+ * wlk_hip.h - C ABI of libwlk_hip.so, the MI355X (gfx950) backend for WhisperLiveKit's
+ * simul_whisper hot path.
+ *
+ * The reference has no FFI for this path: its plugin boundary is the set of abstract tensor
+ * hooks of AlignAttBase (whisperlivekit/simul_whisper/align_att_base.py:541-649), implemented
+ * in PyTorch by AlignAtt (whisperlivekit/simul_whisper/simul_whisper.py:108-462).  Each entry
+ * point below names the hook(s)/reference code it replaces.  Everything is plain pointers and
+ * sizes; `float*` arguments marked "host" are host memory, "dev" are device (HBM) pointers.
+ *
+ * Conventions
+ *  - every function returns 0 (WLK_OK) or a negative error code; wlk_last_error() returns the
+ *    message of the last failure on the calling thread (the Python shim raises RuntimeError,
+ *    matching the reference's exception convention, simul_whisper/backend.py:266-268).
+ *  - a wlk_model is immutable after wlk_model_finalize() and may be shared by any number of
+ *    sessions / threads; a wlk_session is used by one thread at a time (the reference's
+ *    threading contract).
+ *  - all arithmetic is fp32 (whisper/model.py:39-50 keeps fp32 end to end on this path).
+ */
+#ifndef WLK_HIP_H
+#define WLK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WLK_OK 0
+#define WLK_ERR_ARG (-1)
+#define WLK_ERR_HIP (-2)
+#define WLK_ERR_STATE (-3)
+#define WLK_ERR_CAPACITY (-4)
+
+typedef struct wlk_model wlk_model;
+typedef struct wlk_session wlk_session;
+
+/* ModelDimensions, whisperlivekit/whisper/model.py:26-37 */
+typedef struct wlk_dims {
+    int32_t n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+    int32_t n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
+} wlk_dims;
+
+const char* wlk_last_error(void);
+int wlk_abi_version(void);
+/* number of visible HIP devices (0 if none / runtime unusable); never fails */
+int wlk_device_count(void);
+
+/* ---- weights: one packed fp32 arena per GPU ------------------------------------------------
+ * Replaces load_model()'s `.to(device)` of an nn.Module (whisper/__init__.py:466-596): tensors
+ * keep the reference checkpoint names; conv weights are stored tap-major and q/k/v (k/v for
+ * cross attention) are stored concatenated so each projection is one GEMM - the repacking is
+ * done by the host shim, the layout is defined by wlk_tensor_lookup(). */
+int wlk_arena_floats(const wlk_dims* dims, uint64_t* n_floats);
+int wlk_tensor_lookup(const wlk_dims* dims, const char* packed_name, uint64_t* offset_floats,
+                      uint64_t* numel);
+/* n-th packed tensor name (0 <= index < count); returns WLK_ERR_ARG past the end */
+int wlk_tensor_name(const wlk_dims* dims, int index, const char** name);
+
+/* arena_dev may be NULL (the library hipMallocs it) or a caller-owned device buffer of
+ * wlk_arena_floats() floats (e.g. a torch tensor that torch.distributed broadcasts over RCCL) */
+int wlk_model_create(const wlk_dims* dims, int device, float* arena_dev, wlk_model** out);
+int wlk_model_arena(wlk_model* m, float** arena_dev, uint64_t* n_floats);
+int wlk_model_upload(wlk_model* m, const char* packed_name, const float* host, uint64_t numel);
+/* (decoder layer, head) pairs in alignment-rank order; Whisper.set_alignment_heads,
+ * whisper/model.py:363-370 + simul_whisper.py:151-159 */
+int wlk_model_set_alignment_heads(wlk_model* m, const int32_t* layer_head_pairs, int n_pairs);
+int wlk_model_finalize(wlk_model* m);
+int wlk_model_destroy(wlk_model* m);
+
+/* ---- per-stream session --------------------------------------------------------------------
+ * Owns what DecoderState owns (simul_whisper/decoder_state.py:7-91) that is tensor-valued:
+ * the rolling audio buffer, KV caches, the 16-step cross-attention window, workspaces, and a
+ * HIP stream. */
+int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_session** out);
+int wlk_session_destroy(wlk_session* s);
+/* 1 = keep pre-softmax cross-attention QK of every layer/head and raw logits for wlk_export */
+int wlk_session_set_debug(wlk_session* s, int on);
+
+/* a1: AlignAtt.insert_audio (simul_whisper.py:219-237): append a chunk / evict the oldest
+ * samples / drop everything.  Only the new chunk crosses PCIe. */
+int wlk_audio_append(wlk_session* s, const float* pcm_host, int n);
+int wlk_audio_append_zeros(wlk_session* s, int n);
+int wlk_audio_drop_front(wlk_session* s, int n);
+int wlk_audio_clear(wlk_session* s);
+int wlk_audio_len(wlk_session* s, int* n);
+
+/* a2+a3+a4: AlignAtt._encode (simul_whisper.py:344-352) = log_mel_spectrogram(padding=30 s)
+ * -> first 3000 frames -> AudioEncoder.forward, plus the cross-attention K/V projection of
+ * every decoder layer (MultiHeadAttention.forward's first-use branch, whisper/model.py:117-126).
+ * content_mel_len = int((T_padded - 3000) / 2). */
+int wlk_encode(wlk_session* s, int32_t* content_mel_len);
+
+/* a5: TextDecoder.forward(tokens, xa, kv_cache, return_cross_attn=True) (whisper/model.py:279-332)
+ * via AlignAtt._get_logits_and_cross_attn (simul_whisper.py:357-368).  tokens: host int64
+ * [n_rows, n_tok] row-major, n_rows = beam.  first != 0 starts a new `infer` (empty self-attn
+ * cache and alignment window, i.e. after DecoderState.clean_cache()).  Logits are produced for
+ * the last position and, when first, for position sot_index (the only rows the policy reads,
+ * align_att_base.py:226-229); softmaxed cross-attention rows of the alignment heads go to the
+ * session's 16-step window (align_att_base.py:221-224). Asynchronous on the session stream. */
+int wlk_decode(wlk_session* s, const int64_t* tokens, int n_rows, int n_tok, int first, int sot_index);
+
+/* a6: AlignAtt._check_no_speech (simul_whisper.py:370-377): softmax(logits[:, sot_index])[token] */
+int wlk_no_speech_prob(wlk_session* s, int no_speech_token, float* probs_host /* [n_rows] */);
+
+/* a6+a7+a8 in one launch group and ONE readback:
+ *  - logits[row, ids[i]] += deltas[i] (-inf suppresses: SuppressTokens.apply whisper/decoding.py:427-432,
+ *    _suppress_blank_tokens simul_whisper.py:379-381, DRY penalty align_att_base.py:492-537);
+ *  - log_softmax + top-k (the device part of BeamSearchDecoder.update, whisper/decoding.py:332-338);
+ *  - AlignAtt._process_cross_attention + _get_attended_frames (simul_whisper.py:390-437) over the
+ *    current window: most attended frame of the newest row, per beam row.
+ * adj_row[i] < 0 applies the adjustment to every row. */
+int wlk_select(wlk_session* s, const int32_t* adj_row, const int32_t* adj_ids, const float* adj_deltas,
+               int n_adj, int k, int content_mel_len,
+               float* top_logprobs_host /* [n_rows, k] */, int32_t* top_ids_host /* [n_rows, k] */,
+               int32_t* frames_host /* [n_rows] */);
+
+/* BeamPyTorchInference.rearrange_kv_cache (simul_whisper/beam.py:15-19) */
+int wlk_kv_reorder(wlk_session* s, const int32_t* source_rows, int n_rows);
+
+int wlk_sync(wlk_session* s);
+
+/* Parity/debug exports to host memory.  what: "mel" [n_mels,3000], "enc" [1500,d],
+ * "logits_last" / "logits_sot" [n_rows,V], "attn_last" [n_rows, content_mel_len] (after
+ * wlk_select), "cross_qk:<layer>" [rows, H, 1500] of the latest wlk_decode (debug sessions only),
+ * "self_k:<layer>" [n_rows, len, d], "xattn_w:<rank>" [window rows, 1500]. */
+int wlk_export(wlk_session* s, const char* what, float* host, uint64_t capacity, uint64_t* n_written);
+
+/* Per-kernel timing of the session's stream with HIP events (bench.py roofline leg).
+ * wlk_prof_begin arms it; wlk_prof_end fills, per launch tag (up to cap entries): summed event
+ * time in ms, launch count, and the summed ALGORITHMIC flops / bytes of those launches. */
+int wlk_prof_begin(wlk_session* s);
+int wlk_prof_end(wlk_session* s, int cap, const char** names, float* total_ms, int32_t* launches,
+                 double* flops, double* bytes, int32_t* n_out);
+
+/* ---- diagnostics: one kernel on host data (used by the GPU parity tests only) ---------------- */
+const char* wlk_diag_last_error(void);
+/* c[m,n] = epilogue(a[m,k](row stride lda, a_floats floats in total) . w[n,k]^T + bias); flags:
+ * 1 = exact-erf GELU, 2 = add r[m, ldr] after the activation, 4 = scale columns < scale_cols */
+int wlk_diag_linear(const float* a, int64_t lda, int64_t a_floats, const float* w, const float* bias,
+                    const float* r, int64_t ldr, int m, int n, int k, int flags, float scale, int scale_cols,
+                    int force_gemv, float* c);
+int wlk_diag_layernorm(const float* x, const float* gamma, const float* beta, int rows, int d, float* y);
+/* qkv [t, 3d] with q and k pre-scaled -> softmax(q k^T) v per 64-wide head, out [t, d] */
+int wlk_diag_encoder_attention(const float* qkv, int t, int d, int n_head, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WLK_HIP_H */

@@ -1,0 +1,323 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+(1) plain fp32 torch references of each kernel, (2) the committed golden fixtures produced by the
+reference itself, (3) the CPU oracle on the same seeded inputs, (4) the reference's golden streams
+end to end (bit-exact token ids / frames / timestamps).
+
+Tolerances: north-star says mel/logits within 1e-3 (fp32); the asserts below are tighter where the
+measured error allows and every measured error is also written to gpurun_out/parity_report.json."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from whisperlivekit_amd import _lib, synth
+from whisperlivekit_amd.dims import ALIGNMENT_HEADS, MODEL_DIMS
+from whisperlivekit_amd.melbank import mel_filterbank
+
+pytestmark = pytest.mark.gpu
+
+REPORT = {}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def report(key, **vals):
+    REPORT[key] = {k: (float(v) if isinstance(v, (np.floating, float)) else v) for k, v in vals.items()}
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_report.json"), "w") as fh:
+        json.dump(REPORT, fh, indent=1, sort_keys=True)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lib = _lib.load()
+    assert lib.wlk_device_count() > 0, "no MI355X visible"
+    return lib
+
+
+def vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---------------------------------------------------------------------------------------------
+# kernels in isolation
+# ---------------------------------------------------------------------------------------------
+GEMM_CASES = [
+    # M, N, K, lda, flags, tag
+    (1500, 512, 512, 512, 0, "square"),
+    (1500, 1536, 512, 512, 4, "qkv_scale"),
+    (1500, 2048, 512, 512, 1, "fc1_gelu"),
+    (1500, 512, 2048, 2048, 2, "fc2_resid"),
+    (3000, 384, 240, 80, 1, "conv1_overlap"),
+    (1500, 128, 384, 256, 3, "conv2_stride"),
+    (37, 200, 132, 132, 0, "ragged"),
+    (1, 64, 4, 4, 0, "tiny"),
+    (70, 51864, 128, 128, 0, "vocab_tail"),
+]
+
+
+@pytest.mark.parametrize("M,N,K,lda,flags,tag", GEMM_CASES)
+def test_gemm_matches_torch(lib, M, N, K, lda, flags, tag):
+    rng = np.random.default_rng(1)
+    a_floats = (M - 1) * lda + K
+    a = rng.standard_normal(a_floats).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    r = rng.standard_normal((M, N)).astype(np.float32)
+    scale, scale_cols = 0.3535533905932738, N // 3
+    c = np.empty((M, N), np.float32)
+    rc = lib.wlk_diag_linear(vp(a), lda, a_floats, vp(w), vp(bias), vp(r) if flags & 2 else None, N, M, N, K, flags,
+                             scale, scale_cols, 0, vp(c))
+    assert rc == 0, lib.wlk_diag_last_error()
+    A = torch.from_numpy(np.lib.stride_tricks.as_strided(a, (M, K), (lda * 4, 4)).copy())
+    ref = A.double() @ torch.from_numpy(w).double().T + torch.from_numpy(bias).double()
+    if flags & 4:
+        ref[:, :scale_cols] *= np.float32(scale).astype(np.float64)
+    if flags & 1:
+        ref = torch.nn.functional.gelu(ref)
+    if flags & 2:
+        ref = ref + torch.from_numpy(r).double()
+    err = float((torch.from_numpy(c).double() - ref).abs().max())
+    report(f"gemm_{tag}", max_abs_err=err, ref_abs_max=float(ref.abs().max()))
+    assert err <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 512, 512), (1, 2048, 512), (1, 512, 2048), (2, 1536, 512), (3, 130, 384),
+                                   (4, 51864, 128), (8, 257, 512), (1, 51864, 512)])
+def test_gemv_matches_torch(lib, M, N, K):
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    r = rng.standard_normal((M, N)).astype(np.float32)
+    c = np.empty((M, N), np.float32)
+    rc = lib.wlk_diag_linear(vp(a), K, M * K, vp(w), vp(bias), vp(r), N, M, N, K, 1 | 2 | 4, 0.5, N // 2, 1, vp(c))
+    assert rc == 0, lib.wlk_diag_last_error()
+    ref = torch.from_numpy(a).double() @ torch.from_numpy(w).double().T + torch.from_numpy(bias).double()
+    ref[:, :N // 2] *= 0.5
+    ref = torch.nn.functional.gelu(ref) + torch.from_numpy(r).double()
+    err = float((torch.from_numpy(c).double() - ref).abs().max())
+    report(f"gemv_{M}x{N}x{K}", max_abs_err=err)
+    assert err <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("rows,d", [(1500, 512), (7, 128), (3, 384), (1, 1280)])
+def test_layernorm_matches_torch(lib, rows, d):
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((rows, d)) * 3 + 1).astype(np.float32)
+    g = rng.standard_normal(d).astype(np.float32)
+    b = rng.standard_normal(d).astype(np.float32)
+    y = np.empty_like(x)
+    assert lib.wlk_diag_layernorm(vp(x), vp(g), vp(b), rows, d, vp(y)) == 0, lib.wlk_diag_last_error()
+    ref = torch.nn.functional.layer_norm(torch.from_numpy(x), (d,), torch.from_numpy(g), torch.from_numpy(b)).numpy()
+    err = float(np.abs(y - ref).max())
+    report(f"layernorm_{rows}x{d}", max_abs_err=err)
+    assert err <= 1e-5
+
+
+@pytest.mark.parametrize("T,H", [(1500, 8), (1500, 2), (100, 6), (33, 1)])
+def test_encoder_attention_matches_torch(lib, T, H):
+    d = 64 * H
+    rng = np.random.default_rng(4)
+    qkv = rng.standard_normal((T, 3 * d)).astype(np.float32)
+    qkv[:, :2 * d] *= 0.6
+    qkv[5, :d] *= 6.0                       # a spiky query row: exercises the online-softmax rescale
+    out = np.empty((T, d), np.float32)
+    assert lib.wlk_diag_encoder_attention(vp(qkv), T, d, H, vp(out)) == 0, lib.wlk_diag_last_error()
+    t = torch.from_numpy(qkv).double()
+    q, k, v = (t[:, i * d:(i + 1) * d].view(T, H, 64).permute(1, 0, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).permute(1, 0, 2).reshape(T, d)
+    err = float((torch.from_numpy(out).double() - ref).abs().max())
+    report(f"enc_attention_T{T}_H{H}", max_abs_err=err)
+    assert err <= 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# model-level parity
+# ---------------------------------------------------------------------------------------------
+_models = {}
+
+
+def hip_model(name, seed=0):
+    from whisperlivekit_amd.engine import HipWhisperModel
+    if (name, seed) not in _models:
+        _models[(name, seed)] = HipWhisperModel.synthetic(name, seed)
+    return _models[(name, seed)]
+
+
+MEL_META = H.golden_json("mel.json")
+
+
+@pytest.mark.parametrize("key", sorted(MEL_META))
+def test_mel_matches_reference_golden(key):
+    meta = MEL_META[key]
+    gold = H.golden_npz("mel.npz")
+    name = "micro.en" if meta["n_mels"] == 80 else "large-v3"
+    if meta["n_mels"] == 128:
+        pytest.skip("128-mel front end is covered by test_mel_128_against_oracle (no 6 GB model here)")
+    sess = hip_model(name).new_session()
+    sess.append(H.mel_case_audio(meta))
+    cml = sess.encode()
+    assert cml == meta["content_mel_len"]
+    mel = sess.export("mel").reshape(meta["n_mels"], 3000)
+    worst = 0.0
+    for lo, hi, ref in H.expand_mel_golden(gold[key], meta):
+        worst = max(worst, float(np.abs(mel[:, lo:hi] - ref).max()))
+    tail_err = 0.0
+    if meta["tail_value"] is not None and meta["keep"] < 3000:
+        tail_err = float(np.abs(mel[:, meta["keep"]:] - np.float32(meta["tail_value"])).max())
+    report(f"mel_{key}", max_abs_err=worst, tail_err=tail_err)
+    sess.close()
+    assert worst <= 1e-3 and tail_err <= 1e-6          # north star: mel within 1e-3
+
+
+@pytest.mark.parametrize("name", ["micro.en", "tiny.en", "base.en"])
+def test_encoder_decoder_match_reference_golden(name):
+    gold = H.golden_npz(f"numerics_{name}.npz")
+    dims = MODEL_DIMS[name]
+    sess = hip_model(name).new_session()
+    sess.set_debug(True)
+    sess.append(synth.to_pcm16_roundtrip(synth.speech_like(3.2, 11)))
+    sess.encode()
+    enc = sess.export("enc").reshape(1500, dims.n_audio_state)
+    e_enc = float(np.abs(enc[::50] - gold["enc_rows"]).max())
+    report(f"enc_{name}", max_abs_err=e_enc, abs_mean=float(np.abs(enc).mean()))
+    feeds = [gold["tokens"], np.array([[31000]]), np.array([[46]])]
+    worst_logit, worst_qk = 0.0, 0.0
+    top_ok = True
+    for si, feed in enumerate(feeds):
+        sess.decode(feed, first=(si == 0), sot_index=3)
+        logits = sess.export("logits_last").reshape(-1)
+        worst_logit = max(worst_logit, float(np.abs(logits[H.PROBE_IDS] - gold[f"s{si}_probe"]).max()))
+        top_ok &= (np.argsort(-logits, kind="stable")[:16].tolist() == gold[f"s{si}_top_ids"].tolist())
+        lse = float(torch.logsumexp(torch.from_numpy(logits), -1))
+        worst_logit = max(worst_logit, abs(lse - float(gold[f"s{si}_lse"])))
+        if si == 0:
+            sot = sess.export("logits_sot").reshape(-1)
+            worst_logit = max(worst_logit, float(np.abs(sot[H.PROBE_IDS] - gold["s0_row3_probe"]).max()))
+        rows = feed.shape[1]
+        for (l, h) in ALIGNMENT_HEADS[name]:
+            qk = sess.export(f"cross_qk:{l}").reshape(rows, dims.n_text_head, 1500)
+            worst_qk = max(worst_qk, float(np.abs(qk[:, h, ::3] - gold[f"s{si}_qk_l{l}h{h}"]).max()))
+    report(f"decoder_{name}", logits_max_abs_err=worst_logit, cross_qk_max_abs_err=worst_qk, top16_equal=bool(top_ok))
+    sess.close()
+    assert e_enc <= 1e-3 and worst_logit <= 1e-3 and worst_qk <= 1e-3 and top_ok
+
+
+def test_mel_128_against_oracle():
+    """128-bin front end (large-v3 family) without a 6 GB model: a micro-width model with n_mels=128."""
+    from oracle import whisper_oracle as wo
+    from whisperlivekit_amd.dims import ModelDims
+    from whisperlivekit_amd.engine import HipWhisperModel
+    dims = ModelDims(128, 1500, 128, 2, 1, 51866, 448, 128, 2, 1)
+    sd = synth.synth_state_dict(dims, 5)
+    model = HipWhisperModel.from_state_dict(dims, sd, [(0, 0)])
+    sess = model.new_session()
+    audio = synth.to_pcm16_roundtrip(synth.speech_like(2.0, 1))
+    sess.append(audio)
+    cml = sess.encode()
+    mel = sess.export("mel").reshape(128, 3000)
+    ref, rcml = wo.encoder_input_from_audio(torch.from_numpy(audio), torch.from_numpy(np.array(mel_filterbank(128))))
+    gold = H.golden_npz("mel.npz")["m128_2s"]
+    err = float(np.abs(mel - ref[0].numpy()).max())
+    gerr = float(np.abs(mel[:, :gold.shape[1]] - gold).max())
+    with torch.no_grad():
+        enc_ref = wo.encoder_forward(wo.to_torch_state_dict(sd), dims, ref)
+    enc = sess.export("enc").reshape(1500, 128)
+    eerr = float(np.abs(enc - enc_ref[0].numpy()).max())
+    report("mel128", max_abs_err=err, golden_err=gerr, enc_err=eerr)
+    sess.close(); model.close()
+    assert cml == rcml and err <= 1e-3 and gerr <= 1e-3 and eerr <= 1e-3
+
+
+@pytest.mark.parametrize("name,beam", [("micro.en", 1), ("micro.en", 3), ("tiny.en", 1)])
+def test_select_and_alignment_against_oracle(name, beam):
+    """One infer's worth of decode steps: top-k log-probs, no-speech prob, the AlignAtt row and
+    the attended frame against the oracle on identical tokens."""
+    from oracle import whisper_oracle as wo
+    dims = MODEL_DIMS[name]
+    sd = H.oracle_sd(name)
+    audio = synth.to_pcm16_roundtrip(synth.speech_like(5.0, 7))
+    sess = hip_model(name).new_session(beam=beam)
+    sess.append(audio)
+    cml = sess.encode()
+    with torch.no_grad():
+        mel, rcml = wo.encoder_input_from_audio(torch.from_numpy(audio), torch.from_numpy(np.array(mel_filterbank(dims.n_mels))))
+        enc = wo.encoder_forward(sd, dims, mel)
+    assert cml == rcml
+    cache = wo.DecoderCache(dims.n_text_layer)
+    rng = np.random.default_rng(5)
+    toks = np.tile(np.array([[50257, 50362] + rng.integers(300, 40000, 9).tolist()]), (beam, 1))
+    toks[:, -1] += np.arange(beam)           # beams differ in the last token
+    kept = []
+    worst = dict(lp=0.0, attn=0.0, nsp=0.0)
+    frames_equal = ids_equal = True
+    for step in range(20):                   # > 16 steps: the prefill rows leave the window
+        feed = toks if step == 0 else toks[:, -1:]
+        sess.decode(feed, first=(step == 0), sot_index=0)
+        with torch.no_grad():
+            logits, cross = wo.decoder_forward(sd, dims, torch.from_numpy(feed), enc, cache)
+        kept = (kept + [cross])[-16:]
+        if step == 0:
+            nsp = sess.no_speech_prob(50361)
+            ref = logits[:, 0].float().softmax(-1)[:, 50361].numpy()
+            worst["nsp"] = max(worst["nsp"], float(np.abs(nsp - ref).max() / ref.max()))
+        last = logits[:, -1].clone()
+        adj_ids = [50256, 220, 50257, 50362, int(toks[0, -1])]
+        adj_d = [-np.inf, -np.inf, -np.inf, -np.inf, -2.0]
+        for t, dl in zip(adj_ids, adj_d):
+            last[:, t] += dl
+        lp_ref, id_ref = torch.log_softmax(last, -1).topk(beam + 1)
+        lp, ids, frames = sess.select([-1] * 5, adj_ids, adj_d, beam + 1, cml)
+        attn_ref = wo.alignatt_attention(kept, ALIGNMENT_HEADS[name], dims.n_text_layer, cml, beam)
+        attn = sess.export("attn_last").reshape(beam, 1500)[:, :cml]
+        worst["lp"] = max(worst["lp"], float(np.abs(lp - lp_ref.numpy()).max()))
+        worst["attn"] = max(worst["attn"], float(np.abs(attn - attn_ref[:, -1].numpy()).max()))
+        ids_equal &= ids.tolist() == id_ref.tolist()
+        frames_equal &= frames.tolist() == attn_ref[:, -1].argmax(-1).tolist()
+        nxt = id_ref[:, 0].numpy()
+        toks = np.concatenate([toks, nxt[:, None]], axis=1)
+    report(f"select_{name}_beam{beam}", **worst, ids_equal=bool(ids_equal), frames_equal=bool(frames_equal))
+    sess.close()
+    assert worst["lp"] <= 1e-3 and worst["attn"] <= 1e-3 and worst["nsp"] <= 1e-3 and ids_equal and frames_equal
+
+
+# ---------------------------------------------------------------------------------------------
+# end to end: the reference's golden streams through the real backend (bit-exact ids/frames/words)
+# ---------------------------------------------------------------------------------------------
+from test_oracle_golden import STREAMS, check_stream_against_golden, replay_stream  # noqa: E402
+
+
+def make_hip_processor(model_name, cfg_over):
+    from test_policy_golden import RecordingProcessor
+    from whisperlivekit_amd.backend import HipSimulStreamingASR
+    cfg_over = dict(cfg_over or {})
+    kw = {}
+    if "beam_size" in cfg_over:
+        kw["beams"] = cfg_over.pop("beam_size")
+    kw.update(cfg_over)
+    asr = HipSimulStreamingASR(model_name, hip_model=hip_model(model_name), **kw)
+    return RecordingProcessor(asr)
+
+
+@pytest.mark.parametrize("case", STREAMS)
+def test_stream_matches_reference_golden(case):
+    g, proc, got = replay_stream(case, make_hip_processor)
+    try:
+        n_steps = sum(len(r["steps"]) for r in proc.trace)
+        # diagnostics first: how many decode steps agree with the reference
+        agree = total = 0
+        for rec, ref in zip(proc.trace, g["calls"]):
+            for st, rs in zip(rec["steps"], ref["steps"]):
+                if rs.get("token") is not None and "token" in st:
+                    total += 1
+                    agree += int(st["token"] == rs["token"] and st.get("frame") == rs["frame"])
+        report(f"stream_{case}", decode_steps=n_steps, compared=total, agree=agree,
+               last_error=repr(getattr(proc, "last_error", None)))
+        check_stream_against_golden(g, proc.trace, got, tol=1e-3)
+    finally:
+        proc.close()

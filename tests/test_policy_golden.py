@@ -1,0 +1,89 @@
+"""Host logic of the product (policy.py + align_att.py + backend.py) replayed against the reference's
+golden streams on CPU, with tests/fake_session.py standing in for the C ABI (oracle numerics)."""
+import numpy as np
+import pytest
+
+import helpers as H
+from fake_session import FakeHipModel
+from test_oracle_golden import STREAMS, replay_stream
+from whisperlivekit_amd import policy as P
+from whisperlivekit_amd.backend import HipSimulStreamingASR, HipSimulStreamingOnlineProcessor, has_repetition_loop
+from whisperlivekit_amd.dims import ALIGNMENT_HEADS, MODEL_DIMS
+
+
+class RecordingProcessor(HipSimulStreamingOnlineProcessor):
+    """Adds the per-call numeric trace the golden comparison wants (tokens, frames, sums)."""
+
+    def __init__(self, asr):
+        super().__init__(asr)
+        self.trace = []
+        m = self.model
+        enc0, logit0, ns0, upd0, fr0 = m._encode, m._get_logits_and_cross_attn, m._check_no_speech, \
+            m._update_tokens, m._get_attended_frames
+
+        def _encode(segs):
+            out = enc0(segs)
+            self.trace.append(dict(content_mel_len=out[1], prefill_tokens=None, steps=[]))
+            return out
+
+        def _logits(tokens, enc):
+            rec = self.trace[-1]
+            if rec["prefill_tokens"] is None:
+                rec["prefill_tokens"] = np.asarray(tokens)[0].tolist()
+            rec["steps"].append(dict(fed=int(np.asarray(tokens).shape[1])))
+            return logit0(tokens, enc)
+
+        def _ns(logits):
+            r = ns0(logits)
+            self.trace[-1]["steps"][-1]["no_speech_prob"] = m.last_no_speech_prob
+            return r
+
+        def _upd(tokens, logits, slp):
+            new, done = upd0(tokens, logits, slp)
+            self.trace[-1]["steps"][-1].update(token=int(new[0, -1]), completed=bool(done),
+                                               sum_logprob=float(slp[0]))
+            return new, done
+
+        def _fr(attn):
+            frames, first = fr0(attn)
+            self.trace[-1]["steps"][-1]["frame"] = first
+            return frames, first
+
+        m._encode, m._get_logits_and_cross_attn, m._check_no_speech = _encode, _logits, _ns
+        m._update_tokens, m._get_attended_frames = _upd, _fr
+
+    def new_speaker(self, speaker, start):           # replay_stream passes (speaker, start)
+        return super().new_speaker(P.ChangeSpeaker(speaker=speaker, start=start))
+
+
+def make_fake_processor(model_name, cfg_over):
+    dims = MODEL_DIMS[model_name]
+    fake = FakeHipModel(dims, H.oracle_sd(model_name), ALIGNMENT_HEADS[model_name])
+    cfg_over = dict(cfg_over or {})
+    kw = {}
+    if "beam_size" in cfg_over:
+        kw["beams"] = cfg_over.pop("beam_size")
+    kw.update(cfg_over)
+    asr = HipSimulStreamingASR(model_name, hip_model=fake, **kw)
+    return RecordingProcessor(asr)
+
+
+@pytest.mark.parametrize("case", STREAMS)
+def test_product_host_logic_matches_reference(case):
+    from test_oracle_golden import check_stream_against_golden
+    g, proc, got = replay_stream(case, make_fake_processor)
+    check_stream_against_golden(g, proc.trace, got)
+    last = [ev for ev, _, _ in got if ev["kind"] == "chunk"][-1]
+    assert proc.model.state.context.text == last["context"]
+    assert proc.model.state.last_attend_frame == last["last_attend_frame"]
+    assert abs(proc.model.state.cumulative_time_offset - last["cumulative_time_offset"]) < 1e-9
+
+
+def test_repetition_detectors():
+    assert not has_repetition_loop(["a"] * 7)
+    assert has_repetition_loop(["x"] * 4 + ["a"] * 8)
+    assert has_repetition_loop(("the cat sat " * 5).split())
+    assert not has_repetition_loop("one two three four five six seven eight nine ten eleven twelve".split())
+    words = ("a b " * 4 + "c d e f").split()
+    assert not has_repetition_loop(words)      # 4 x 2 words < 12-word minimum
+    assert has_repetition_loop(("a b c " * 4 + "d e f g").split())   # 4 x 3 = 12 words, 75 % coverage

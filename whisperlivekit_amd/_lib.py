@@ -1,0 +1,119 @@
+"""ctypes binding of libwlk_hip.so (include/wlk_hip.h).  Fails loudly: there is no CPU fallback -
+if the HIP library is missing or cannot be loaded every entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+_LIB_NAME = "libwlk_hip.so"
+_lock = threading.Lock()
+_lib: Optional[C.CDLL] = None
+
+
+class WlkError(RuntimeError):
+    """Raised for every non-zero status of the C ABI (message from wlk_last_error())."""
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
+        "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer")]
+
+
+def lib_path() -> str:
+    return os.environ.get("WLK_HIP_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME))
+
+
+def _declare(lib: C.CDLL) -> None:
+    p, i32, u64, f32p, i32p = C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    cint = C.c_int
+    sig = {
+        "wlk_last_error": (C.c_char_p, []),
+        "wlk_abi_version": (cint, []),
+        "wlk_device_count": (cint, []),
+        "wlk_arena_floats": (cint, [C.POINTER(Dims), C.POINTER(u64)]),
+        "wlk_tensor_lookup": (cint, [C.POINTER(Dims), C.c_char_p, C.POINTER(u64), C.POINTER(u64)]),
+        "wlk_tensor_name": (cint, [C.POINTER(Dims), cint, C.POINTER(C.c_char_p)]),
+        "wlk_model_create": (cint, [C.POINTER(Dims), cint, p, C.POINTER(p)]),
+        "wlk_model_arena": (cint, [p, C.POINTER(p), C.POINTER(u64)]),
+        "wlk_model_upload": (cint, [p, C.c_char_p, p, u64]),
+        "wlk_model_set_alignment_heads": (cint, [p, p, cint]),
+        "wlk_model_finalize": (cint, [p]),
+        "wlk_model_destroy": (cint, [p]),
+        "wlk_session_create": (cint, [p, cint, cint, C.POINTER(p)]),
+        "wlk_session_destroy": (cint, [p]),
+        "wlk_session_set_debug": (cint, [p, cint]),
+        "wlk_audio_append": (cint, [p, p, cint]),
+        "wlk_audio_append_zeros": (cint, [p, cint]),
+        "wlk_audio_drop_front": (cint, [p, cint]),
+        "wlk_audio_clear": (cint, [p]),
+        "wlk_audio_len": (cint, [p, C.POINTER(cint)]),
+        "wlk_encode": (cint, [p, C.POINTER(i32)]),
+        "wlk_decode": (cint, [p, p, cint, cint, cint, cint]),
+        "wlk_no_speech_prob": (cint, [p, cint, p]),
+        "wlk_select": (cint, [p, p, p, p, cint, cint, cint, p, p, p]),
+        "wlk_kv_reorder": (cint, [p, p, cint]),
+        "wlk_sync": (cint, [p]),
+        "wlk_export": (cint, [p, C.c_char_p, p, u64, C.POINTER(u64)]),
+        "wlk_prof_begin": (cint, [p]),
+        "wlk_prof_end": (cint, [p, cint, C.POINTER(C.c_char_p), p, p, p, p, C.POINTER(i32)]),
+        "wlk_diag_last_error": (C.c_char_p, []),
+        "wlk_diag_linear": (cint, [p, C.c_int64, C.c_int64, p, p, p, C.c_int64, cint, cint, cint, cint, C.c_float,
+                                   cint, cint, p]),
+        "wlk_diag_layernorm": (cint, [p, p, p, cint, cint, p]),
+        "wlk_diag_encoder_attention": (cint, [p, cint, cint, cint, p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+
+
+EXPORTED_SYMBOLS = (
+    "wlk_last_error", "wlk_abi_version", "wlk_device_count", "wlk_arena_floats", "wlk_tensor_lookup",
+    "wlk_tensor_name", "wlk_model_create", "wlk_model_arena", "wlk_model_upload",
+    "wlk_model_set_alignment_heads", "wlk_model_finalize", "wlk_model_destroy", "wlk_session_create",
+    "wlk_session_destroy", "wlk_session_set_debug", "wlk_audio_append", "wlk_audio_append_zeros",
+    "wlk_audio_drop_front", "wlk_audio_clear", "wlk_audio_len", "wlk_encode", "wlk_decode",
+    "wlk_no_speech_prob", "wlk_select", "wlk_kv_reorder", "wlk_sync", "wlk_export", "wlk_prof_begin",
+    "wlk_prof_end", "wlk_diag_last_error", "wlk_diag_linear", "wlk_diag_layernorm", "wlk_diag_encoder_attention",
+)
+
+
+def load() -> C.CDLL:
+    """Load (once) and return the library.  Raises WlkError if it is not built / not loadable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            path = lib_path()
+            if not os.path.exists(path):
+                raise WlkError(
+                    f"{path} not found: build it with `python -m whisperlivekit_amd.build` "
+                    "(hipcc, gfx950). There is no CPU fallback for the HIP backend.")
+            try:
+                # torch ships its own libamdhip64.so.7; importing it first makes torch and this
+                # library share ONE HIP runtime (same soname) when both are in the process.
+                import torch  # noqa: F401
+            except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+                pass
+            try:
+                lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError as e:
+                raise WlkError(f"cannot load {path}: {e}") from e
+            _declare(lib)
+            _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().wlk_last_error()
+        raise WlkError(f"wlk_hip error {rc}: {msg.decode('utf-8', 'replace') if msg else '?'}")
+
+
+def device_count() -> int:
+    return int(load().wlk_device_count())

@@ -1,0 +1,1029 @@
+// C ABI of libwlk_hip.so (include/wlk_hip.h): weight arena, per-stream sessions, and the launch
+// sequences for encode / decode / select.  Host-side orchestration only; the arithmetic lives in
+// the kernel files next to this one.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/wlk_hip.h"
+#include "common.h"
+
+namespace wlk {
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+template <typename F>
+static int guarded(F&& f) {
+    try {
+        return f();
+    } catch (const HipError& e) {
+        g_last_error = e.what();
+        return WLK_ERR_HIP;
+    } catch (const std::invalid_argument& e) {
+        g_last_error = e.what();
+        return WLK_ERR_ARG;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return WLK_ERR_STATE;
+    }
+}
+static int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiler: HIP events around every launch on the session stream
+// ------------------------------------------------------------------------------------------------
+struct Profiler {
+    struct Rec {
+        const char* name;
+        hipEvent_t a, b;
+        double flops, bytes;
+    };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t pending = nullptr;
+    const char* pending_name = nullptr;
+    double pending_flops = 0.0, pending_bytes = 0.0;
+    hipEvent_t get() {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        WLK_HIP(hipEventCreate(&e));
+        return e;
+    }
+};
+void prof_before(const LaunchCtx& ctx, const char* name, double flops, double bytes) {
+    Profiler* p = ctx.prof;
+    p->pending = p->get();
+    p->pending_name = name;
+    p->pending_flops = flops;
+    p->pending_bytes = bytes;
+    WLK_HIP(hipEventRecord(p->pending, ctx.stream));
+}
+void prof_after(const LaunchCtx& ctx) {
+    Profiler* p = ctx.prof;
+    hipEvent_t e = p->get();
+    (void)hipEventRecord(e, ctx.stream);
+    p->recs.push_back({p->pending_name, p->pending, e, p->pending_flops, p->pending_bytes});
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed weight arena layout
+// ------------------------------------------------------------------------------------------------
+struct TensorSlot {
+    std::string name;
+    uint64_t offset, numel;
+};
+
+static std::vector<TensorSlot> build_layout(const wlk_dims& D, uint64_t* total) {
+    std::vector<TensorSlot> v;
+    uint64_t off = 0;
+    auto add = [&](const std::string& n, uint64_t numel) {
+        v.push_back({n, off, numel});
+        off += (numel + 63) / 64 * 64;  // 256-byte aligned slots
+    };
+    const uint64_t da = D.n_audio_state, dt = D.n_text_state;
+    add("mel.filters", (uint64_t)D.n_mels * kNFreq);
+    add("mel.window", kNFft);
+    add("enc.conv1.w", da * 3 * D.n_mels);
+    add("enc.conv1.b", da);
+    add("enc.conv2.w", da * 3 * da);
+    add("enc.conv2.b", da);
+    add("enc.pos", (uint64_t)D.n_audio_ctx * da);
+    for (int i = 0; i < D.n_audio_layer; ++i) {
+        const std::string p = "enc." + std::to_string(i) + ".";
+        add(p + "ln1.w", da); add(p + "ln1.b", da);
+        add(p + "qkv.w", 3 * da * da); add(p + "qkv.b", 3 * da);
+        add(p + "out.w", da * da); add(p + "out.b", da);
+        add(p + "ln2.w", da); add(p + "ln2.b", da);
+        add(p + "fc1.w", 4 * da * da); add(p + "fc1.b", 4 * da);
+        add(p + "fc2.w", 4 * da * da); add(p + "fc2.b", da);
+    }
+    add("enc.ln_post.w", da); add("enc.ln_post.b", da);
+    add("dec.tok_emb", (uint64_t)D.n_vocab * dt);
+    add("dec.pos", (uint64_t)D.n_text_ctx * dt);
+    for (int i = 0; i < D.n_text_layer; ++i) {
+        const std::string p = "dec." + std::to_string(i) + ".";
+        add(p + "ln1.w", dt); add(p + "ln1.b", dt);
+        add(p + "qkv.w", 3 * dt * dt); add(p + "qkv.b", 3 * dt);
+        add(p + "out.w", dt * dt); add(p + "out.b", dt);
+        add(p + "lnx.w", dt); add(p + "lnx.b", dt);
+        add(p + "xq.w", dt * dt); add(p + "xq.b", dt);
+        add(p + "xkv.w", 2 * dt * da); add(p + "xkv.b", 2 * dt);
+        add(p + "xout.w", dt * dt); add(p + "xout.b", dt);
+        add(p + "ln2.w", dt); add(p + "ln2.b", dt);
+        add(p + "fc1.w", 4 * dt * dt); add(p + "fc1.b", 4 * dt);
+        add(p + "fc2.w", 4 * dt * dt); add(p + "fc2.b", dt);
+    }
+    add("dec.ln.w", dt); add("dec.ln.b", dt);
+    if (total) *total = off;
+    return v;
+}
+
+static int check_dims(const wlk_dims* d) {
+    if (!d) return fail(WLK_ERR_ARG, "dims is NULL");
+    if (d->n_audio_state != d->n_audio_head * kHeadDim || d->n_text_state != d->n_text_head * kHeadDim)
+        return fail(WLK_ERR_ARG, "only 64-wide attention heads are supported");
+    if (d->n_audio_state != d->n_text_state) return fail(WLK_ERR_ARG, "audio/text widths must match");
+    if (d->n_mels % 4 != 0 || d->n_mels > 256) return fail(WLK_ERR_ARG, "n_mels must be a multiple of 4, <= 256");
+    if (d->n_audio_ctx != 1500) return fail(WLK_ERR_ARG, "n_audio_ctx must be 1500 (30 s window)");
+    if (d->n_text_ctx > 448) return fail(WLK_ERR_ARG, "n_text_ctx must be <= 448");
+    if (d->n_audio_state > 1536) return fail(WLK_ERR_ARG, "model width must be <= 1536");
+    return WLK_OK;
+}
+
+}  // namespace wlk
+
+using namespace wlk;
+
+// ------------------------------------------------------------------------------------------------
+// model
+// ------------------------------------------------------------------------------------------------
+struct wlk_model {
+    wlk_dims D{};
+    int device = 0;
+    float* arena = nullptr;
+    bool owns_arena = false;
+    uint64_t arena_floats = 0;
+    std::vector<TensorSlot> slots;
+    std::map<std::string, const TensorSlot*> by_name;
+    double* twiddle = nullptr;        // [400] fp64 cos table
+    int* filt_lo = nullptr;           // [n_mels]
+    int* filt_hi = nullptr;
+    int* head_rank = nullptr;         // [L][H] alignment rank or -1
+    std::vector<int> align_pairs;     // (layer, head)*
+    int n_align = 0;
+    bool finalized = false;
+
+    const float* w(const std::string& name) const {
+        auto it = by_name.find(name);
+        if (it == by_name.end()) throw std::invalid_argument("unknown tensor " + name);
+        return arena + it->second->offset;
+    }
+};
+
+struct LayerW {
+    const float *ln1w, *ln1b, *qkvw, *qkvb, *outw, *outb, *ln2w, *ln2b, *fc1w, *fc1b, *fc2w, *fc2b;
+    const float *lnxw = nullptr, *lnxb = nullptr, *xqw = nullptr, *xqb = nullptr, *xkvw = nullptr, *xkvb = nullptr,
+                *xoutw = nullptr, *xoutb = nullptr;
+};
+
+static LayerW layer_weights(const wlk_model* m, const char* side, int i, bool cross) {
+    const std::string p = std::string(side) + "." + std::to_string(i) + ".";
+    LayerW L;
+    L.ln1w = m->w(p + "ln1.w"); L.ln1b = m->w(p + "ln1.b");
+    L.qkvw = m->w(p + "qkv.w"); L.qkvb = m->w(p + "qkv.b");
+    L.outw = m->w(p + "out.w"); L.outb = m->w(p + "out.b");
+    L.ln2w = m->w(p + "ln2.w"); L.ln2b = m->w(p + "ln2.b");
+    L.fc1w = m->w(p + "fc1.w"); L.fc1b = m->w(p + "fc1.b");
+    L.fc2w = m->w(p + "fc2.w"); L.fc2b = m->w(p + "fc2.b");
+    if (cross) {
+        L.lnxw = m->w(p + "lnx.w"); L.lnxb = m->w(p + "lnx.b");
+        L.xqw = m->w(p + "xq.w"); L.xqb = m->w(p + "xq.b");
+        L.xkvw = m->w(p + "xkv.w"); L.xkvb = m->w(p + "xkv.b");
+        L.xoutw = m->w(p + "xout.w"); L.xoutb = m->w(p + "xout.b");
+    }
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------------
+// session
+// ------------------------------------------------------------------------------------------------
+struct wlk_session {
+    wlk_model* m = nullptr;
+    int beam = 1;
+    int audio_cap = 0;
+    hipStream_t stream = nullptr;
+    Profiler prof;
+    bool prof_on = false;
+    bool debug = false;
+
+    // audio (two buffers: eviction copies the tail into the other one)
+    float* audio[2] = {nullptr, nullptr};
+    int audio_cur = 0;
+    int audio_len = 0;
+
+    // mel + encoder workspaces
+    float *logmel = nullptr, *frame_max = nullptr, *mel_t = nullptr;
+    int frame_cap = 0;
+    float *x1p = nullptr, *ex = nullptr, *eh = nullptr, *eqkv = nullptr, *eatt = nullptr, *emlp = nullptr,
+          *enc_out = nullptr, *cross_kv = nullptr;
+    bool encoded = false;
+    int content_len = 0;
+
+    // decoder workspaces
+    int max_rows = 0;
+    int* tokens_dev = nullptr;
+    float *dx = nullptr, *dh = nullptr, *dqkv = nullptr, *datt = nullptr, *dq = nullptr, *dmlp = nullptr;
+    float* kcache[2] = {nullptr, nullptr};  // [L][beam][ctx][d]; second pair allocated on first reorder
+    float* vcache[2] = {nullptr, nullptr};
+    int kv_cur = 0;
+    int self_len = 0;
+    int n_steps = 0;
+    int prefill_rows = 0;
+    int last_rows = 0, last_ntok = 0;
+    float *hsel = nullptr, *logits_last = nullptr, *logits_sot = nullptr;
+    bool have_sot = false;
+    int *ring_row = nullptr, *beam_of_row = nullptr;
+    float* ring = nullptr;
+    int ring_rows = 0;
+    float *z = nullptr, *attn_last = nullptr;
+    float* qk_debug = nullptr;  // [L][max_rows][H][T]
+
+    // select scratch (device) + pinned host staging
+    int *adj_row = nullptr, *adj_ids = nullptr, *src_rows = nullptr;
+    float* adj_deltas = nullptr;
+    float* top_vals = nullptr;
+    int *top_ids = nullptr, *frames = nullptr;
+    float* probs = nullptr;
+    static constexpr int kAdjCap = 4096;
+    void* pinned = nullptr;  // 1 MiB
+    static constexpr size_t kPinnedBytes = 1 << 20;
+
+    LaunchCtx ctx() { return LaunchCtx{stream, prof_on ? &prof : nullptr}; }
+};
+
+template <typename T>
+static T* dev_alloc(size_t n) {
+    T* p = nullptr;
+    WLK_HIP(hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));
+    return p;
+}
+template <typename T>
+static T* dev_alloc_zero(size_t n, hipStream_t s) {
+    T* p = dev_alloc<T>(n);
+    WLK_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// extern "C"
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* wlk_last_error(void) { return g_last_error.c_str(); }
+int wlk_abi_version(void) { return 1; }
+
+int wlk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int wlk_arena_floats(const wlk_dims* dims, uint64_t* n_floats) {
+    if (int rc = check_dims(dims)) return rc;
+    if (!n_floats) return fail(WLK_ERR_ARG, "n_floats is NULL");
+    build_layout(*dims, n_floats);
+    return WLK_OK;
+}
+
+int wlk_tensor_lookup(const wlk_dims* dims, const char* packed_name, uint64_t* offset_floats, uint64_t* numel) {
+    if (int rc = check_dims(dims)) return rc;
+    if (!packed_name) return fail(WLK_ERR_ARG, "name is NULL");
+    for (const auto& s : build_layout(*dims, nullptr)) {
+        if (s.name == packed_name) {
+            if (offset_floats) *offset_floats = s.offset;
+            if (numel) *numel = s.numel;
+            return WLK_OK;
+        }
+    }
+    return fail(WLK_ERR_ARG, std::string("unknown tensor ") + packed_name);
+}
+
+int wlk_tensor_name(const wlk_dims* dims, int index, const char** name) {
+    if (int rc = check_dims(dims)) return rc;
+    static thread_local std::string hold;
+    auto v = build_layout(*dims, nullptr);
+    if (index < 0 || index >= (int)v.size() || !name) return fail(WLK_ERR_ARG, "tensor index out of range");
+    hold = v[index].name;
+    *name = hold.c_str();
+    return WLK_OK;
+}
+
+int wlk_model_create(const wlk_dims* dims, int device, float* arena_dev, wlk_model** out) {
+    if (int rc = check_dims(dims)) return rc;
+    if (!out) return fail(WLK_ERR_ARG, "out is NULL");
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(device));
+        auto m = std::make_unique<wlk_model>();
+        m->D = *dims;
+        m->device = device;
+        m->slots = build_layout(*dims, &m->arena_floats);
+        for (const auto& s : m->slots) m->by_name[s.name] = &s;
+        if (arena_dev) {
+            m->arena = arena_dev;
+        } else {
+            m->arena = dev_alloc<float>(m->arena_floats);
+            m->owns_arena = true;
+            WLK_HIP(hipMemset(m->arena, 0, m->arena_floats * sizeof(float)));
+        }
+        std::vector<double> tw(kNFft);
+        for (int i = 0; i < kNFft; ++i) tw[i] = std::cos(2.0 * M_PI * (double)i / (double)kNFft);
+        m->twiddle = dev_alloc<double>(kNFft);
+        WLK_HIP(hipMemcpy(m->twiddle, tw.data(), kNFft * sizeof(double), hipMemcpyHostToDevice));
+        m->filt_lo = dev_alloc<int>(dims->n_mels);
+        m->filt_hi = dev_alloc<int>(dims->n_mels);
+        m->head_rank = dev_alloc<int>((size_t)dims->n_text_layer * dims->n_text_head);
+        std::vector<int> none((size_t)dims->n_text_layer * dims->n_text_head, -1);
+        WLK_HIP(hipMemcpy(m->head_rank, none.data(), none.size() * sizeof(int), hipMemcpyHostToDevice));
+        *out = m.release();
+        return WLK_OK;
+    });
+}
+
+int wlk_model_arena(wlk_model* m, float** arena_dev, uint64_t* n_floats) {
+    if (!m) return fail(WLK_ERR_ARG, "model is NULL");
+    if (arena_dev) *arena_dev = m->arena;
+    if (n_floats) *n_floats = m->arena_floats;
+    return WLK_OK;
+}
+
+int wlk_model_upload(wlk_model* m, const char* packed_name, const float* host, uint64_t numel) {
+    if (!m || !packed_name || !host) return fail(WLK_ERR_ARG, "NULL argument");
+    return guarded([&]() {
+        auto it = m->by_name.find(packed_name);
+        if (it == m->by_name.end()) return fail(WLK_ERR_ARG, std::string("unknown tensor ") + packed_name);
+        if (it->second->numel != numel)
+            return fail(WLK_ERR_ARG, std::string("size mismatch for ") + packed_name + ": expected " +
+                                         std::to_string(it->second->numel) + ", got " + std::to_string(numel));
+        WLK_HIP(hipSetDevice(m->device));
+        WLK_HIP(hipMemcpy(m->arena + it->second->offset, host, numel * sizeof(float), hipMemcpyHostToDevice));
+        return WLK_OK;
+    });
+}
+
+int wlk_model_set_alignment_heads(wlk_model* m, const int32_t* pairs, int n_pairs) {
+    if (!m || (n_pairs > 0 && !pairs) || n_pairs < 0) return fail(WLK_ERR_ARG, "bad alignment head list");
+    return guarded([&]() {
+        const int L = m->D.n_text_layer, H = m->D.n_text_head;
+        std::vector<int> rank((size_t)L * H, -1);
+        for (int i = 0; i < n_pairs; ++i) {
+            const int l = pairs[2 * i], h = pairs[2 * i + 1];
+            if (l < 0 || l >= L || h < 0 || h >= H) return fail(WLK_ERR_ARG, "alignment head out of range");
+            rank[(size_t)l * H + h] = i;
+        }
+        WLK_HIP(hipSetDevice(m->device));
+        WLK_HIP(hipMemcpy(m->head_rank, rank.data(), rank.size() * sizeof(int), hipMemcpyHostToDevice));
+        m->align_pairs.assign(pairs, pairs + 2 * n_pairs);
+        m->n_align = n_pairs;
+        return WLK_OK;
+    });
+}
+
+int wlk_model_finalize(wlk_model* m) {
+    if (!m) return fail(WLK_ERR_ARG, "model is NULL");
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(m->device));
+        // sparse extent of every mel filter row, read back from the arena so that ranks that
+        // received the weights by broadcast derive the same table
+        const int nm = m->D.n_mels;
+        std::vector<float> f((size_t)nm * kNFreq);
+        WLK_HIP(hipMemcpy(f.data(), m->w("mel.filters"), f.size() * sizeof(float), hipMemcpyDeviceToHost));
+        std::vector<int> lo(nm), hi(nm);
+        for (int i = 0; i < nm; ++i) {
+            int a = kNFreq, b = 0;
+            for (int k = 0; k < kNFreq; ++k)
+                if (f[(size_t)i * kNFreq + k] != 0.f) {
+                    a = std::min(a, k);
+                    b = k + 1;
+                }
+            if (b == 0) a = 0;
+            lo[i] = a;
+            hi[i] = b;
+        }
+        WLK_HIP(hipMemcpy(m->filt_lo, lo.data(), nm * sizeof(int), hipMemcpyHostToDevice));
+        WLK_HIP(hipMemcpy(m->filt_hi, hi.data(), nm * sizeof(int), hipMemcpyHostToDevice));
+        m->finalized = true;
+        return WLK_OK;
+    });
+}
+
+int wlk_model_destroy(wlk_model* m) {
+    if (!m) return WLK_OK;
+    (void)hipSetDevice(m->device);
+    if (m->owns_arena) hipFree(m->arena);
+    (void)hipFree(m->twiddle);
+    (void)hipFree(m->filt_lo);
+    (void)hipFree(m->filt_hi);
+    (void)hipFree(m->head_rank);
+    delete m;
+    return WLK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_session** out) {
+    if (!m || !out) return fail(WLK_ERR_ARG, "NULL argument");
+    if (!m->finalized) return fail(WLK_ERR_STATE, "model not finalized");
+    if (beam < 1 || beam > 7) return fail(WLK_ERR_ARG, "beam must be in [1, 7]");
+    if (max_audio_samples < kHop) return fail(WLK_ERR_ARG, "max_audio_samples too small");
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(m->device));
+        auto s = std::make_unique<wlk_session>();
+        s->m = m;
+        s->beam = beam;
+        s->audio_cap = max_audio_samples;
+        WLK_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        hipStream_t st = s->stream;
+        const wlk_dims& D = m->D;
+        const size_t d = D.n_audio_state, T = D.n_audio_ctx, ctx = D.n_text_ctx, V = D.n_vocab;
+        s->audio[0] = dev_alloc_zero<float>(s->audio_cap, st);
+        s->audio[1] = dev_alloc_zero<float>(s->audio_cap, st);
+        s->frame_cap = s->audio_cap / kHop + 4;
+        s->logmel = dev_alloc<float>((size_t)s->frame_cap * D.n_mels);
+        s->frame_max = dev_alloc<float>(s->frame_cap);
+        s->mel_t = dev_alloc_zero<float>((size_t)(kMelFrames + 2) * D.n_mels, st);
+        s->x1p = dev_alloc_zero<float>((size_t)(kMelFrames + 1) * d, st);
+        s->ex = dev_alloc<float>(T * d);
+        s->eh = dev_alloc<float>(T * d);
+        s->eqkv = dev_alloc<float>(T * 3 * d);
+        s->eatt = dev_alloc<float>(T * d);
+        s->emlp = dev_alloc<float>(T * 4 * d);
+        s->enc_out = dev_alloc<float>(T * d);
+        s->cross_kv = dev_alloc<float>((size_t)D.n_text_layer * T * 2 * d);
+
+        s->max_rows = beam * (int)ctx;
+        const size_t R = s->max_rows;
+        s->tokens_dev = dev_alloc<int>(R);
+        s->dx = dev_alloc<float>(R * d);
+        s->dh = dev_alloc<float>(R * d);
+        s->dqkv = dev_alloc<float>(R * 3 * d);
+        s->datt = dev_alloc<float>(R * d);
+        s->dq = dev_alloc<float>(R * d);
+        s->dmlp = dev_alloc<float>(R * 4 * d);
+        const size_t cache = (size_t)D.n_text_layer * beam * ctx * d;
+        s->kcache[0] = dev_alloc<float>(cache);
+        s->vcache[0] = dev_alloc<float>(cache);
+        s->hsel = dev_alloc<float>((size_t)2 * beam * d);
+        s->logits_last = dev_alloc<float>((size_t)beam * V);
+        s->logits_sot = dev_alloc<float>((size_t)beam * V);
+        s->ring_row = dev_alloc<int>(R);
+        s->beam_of_row = dev_alloc<int>(R);
+        s->ring_rows = (int)ctx + kAlignWindow;
+        if (m->n_align > 0) s->ring = dev_alloc<float>((size_t)m->n_align * beam * s->ring_rows * T);
+        s->z = dev_alloc<float>((size_t)beam * std::max(m->n_align, 1) * T);
+        s->attn_last = dev_alloc_zero<float>((size_t)beam * T, st);
+        s->adj_row = dev_alloc<int>(wlk_session::kAdjCap);
+        s->adj_ids = dev_alloc<int>(wlk_session::kAdjCap);
+        s->adj_deltas = dev_alloc<float>(wlk_session::kAdjCap);
+        s->src_rows = dev_alloc<int>(8);
+        s->top_vals = dev_alloc<float>((size_t)beam * 8);
+        s->top_ids = dev_alloc<int>((size_t)beam * 8);
+        s->frames = dev_alloc<int>(beam);
+        s->probs = dev_alloc<float>(beam);
+        WLK_HIP(hipHostMalloc(&s->pinned, wlk_session::kPinnedBytes, hipHostMallocDefault));
+        WLK_HIP(hipStreamSynchronize(st));
+        *out = s.release();
+        return WLK_OK;
+    });
+}
+
+int wlk_session_destroy(wlk_session* s) {
+    if (!s) return WLK_OK;
+    (void)hipSetDevice(s->m->device);
+    (void)hipStreamSynchronize(s->stream);
+    float* fl[] = {s->audio[0], s->audio[1], s->logmel, s->frame_max, s->mel_t, s->x1p, s->ex, s->eh, s->eqkv,
+                   s->eatt, s->emlp, s->enc_out, s->cross_kv, s->dx, s->dh, s->dqkv, s->datt, s->dq, s->dmlp,
+                   s->kcache[0], s->kcache[1], s->vcache[0], s->vcache[1], s->hsel, s->logits_last, s->logits_sot,
+                   s->ring, s->z, s->attn_last, s->qk_debug, s->adj_deltas, s->top_vals, s->probs};
+    for (float* p : fl)
+        if (p) (void)hipFree(p);
+    int* il[] = {s->tokens_dev, s->ring_row, s->beam_of_row, s->adj_row, s->adj_ids, s->src_rows, s->top_ids, s->frames};
+    for (int* p : il)
+        if (p) (void)hipFree(p);
+    if (s->pinned) (void)hipHostFree(s->pinned);
+    for (auto& r : s->prof.recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto e : s->prof.pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(s->stream);
+    delete s;
+    return WLK_OK;
+}
+
+int wlk_session_set_debug(wlk_session* s, int on) {
+    if (!s) return fail(WLK_ERR_ARG, "session is NULL");
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(s->m->device));
+        s->debug = on != 0;
+        if (s->debug && !s->qk_debug) {
+            const wlk_dims& D = s->m->D;
+            s->qk_debug = dev_alloc<float>((size_t)D.n_text_layer * s->max_rows * D.n_text_head * D.n_audio_ctx);
+        }
+        return WLK_OK;
+    });
+}
+
+// ---- audio ----------------------------------------------------------------------------------
+int wlk_audio_append(wlk_session* s, const float* pcm_host, int n) {
+    if (!s || (n > 0 && !pcm_host) || n < 0) return fail(WLK_ERR_ARG, "bad audio chunk");
+    if (s->audio_len + n > s->audio_cap)
+        return fail(WLK_ERR_CAPACITY, "audio buffer capacity exceeded (" + std::to_string(s->audio_len + n) + " > " +
+                                          std::to_string(s->audio_cap) + " samples)");
+    if (n == 0) return WLK_OK;
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(s->m->device));
+        float* dst = s->audio[s->audio_cur] + s->audio_len;
+        size_t done = 0;
+        // stage through pinned memory so the copy is asynchronous and the caller's buffer is free on return
+        while (done < (size_t)n) {
+            const size_t chunk = std::min((size_t)n - done, wlk_session::kPinnedBytes / sizeof(float));
+            WLK_HIP(hipStreamSynchronize(s->stream));  // pinned buffer is single-entry
+            std::memcpy(s->pinned, pcm_host + done, chunk * sizeof(float));
+            WLK_HIP(hipMemcpyAsync(dst + done, s->pinned, chunk * sizeof(float), hipMemcpyHostToDevice, s->stream));
+            done += chunk;
+        }
+        WLK_HIP(hipStreamSynchronize(s->stream));
+        s->audio_len += n;
+        s->encoded = false;
+        return WLK_OK;
+    });
+}
+
+int wlk_audio_append_zeros(wlk_session* s, int n) {
+    if (!s || n < 0) return fail(WLK_ERR_ARG, "bad zero run");
+    if (s->audio_len + n > s->audio_cap) return fail(WLK_ERR_CAPACITY, "audio buffer capacity exceeded");
+    if (n == 0) return WLK_OK;
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(s->m->device));
+        WLK_HIP(hipMemsetAsync(s->audio[s->audio_cur] + s->audio_len, 0, (size_t)n * sizeof(float), s->stream));
+        s->audio_len += n;
+        s->encoded = false;
+        return WLK_OK;
+    });
+}
+
+int wlk_audio_drop_front(wlk_session* s, int n) {
+    if (!s || n < 0 || n > s->audio_len) return fail(WLK_ERR_ARG, "bad eviction length");
+    if (n == 0) return WLK_OK;
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(s->m->device));
+        const int keep = s->audio_len - n;
+        if (keep > 0)
+            WLK_HIP(hipMemcpyAsync(s->audio[s->audio_cur ^ 1], s->audio[s->audio_cur] + n, (size_t)keep * sizeof(float),
+                                   hipMemcpyDeviceToDevice, s->stream));
+        s->audio_cur ^= 1;
+        s->audio_len = keep;
+        s->encoded = false;
+        return WLK_OK;
+    });
+}
+
+int wlk_audio_clear(wlk_session* s) {
+    if (!s) return fail(WLK_ERR_ARG, "session is NULL");
+    s->audio_len = 0;
+    s->encoded = false;
+    return WLK_OK;
+}
+
+int wlk_audio_len(wlk_session* s, int* n) {
+    if (!s || !n) return fail(WLK_ERR_ARG, "NULL argument");
+    *n = s->audio_len;
+    return WLK_OK;
+}
+
+// ---- encode ---------------------------------------------------------------------------------
+static void transformer_mlp(const LaunchCtx& c, const LayerW& L, float* x, float* h, float* mlp, int rows, int d,
+                            const char* t_ln, const char* t_fc1, const char* t_fc2) {
+    launch_layernorm(c, x, d, L.ln2w, L.ln2b, h, d, rows, d, t_ln);
+    GemmArgs g;
+    g.A = h; g.lda = d; g.W = L.fc1w; g.bias = L.fc1b; g.C = mlp; g.ldc = 4 * d; g.M = rows; g.N = 4 * d; g.K = d;
+    g.flags = kGemmGelu;
+    launch_linear(c, g, t_fc1);
+    GemmArgs g2;
+    g2.A = mlp; g2.lda = 4 * d; g2.W = L.fc2w; g2.bias = L.fc2b; g2.C = x; g2.ldc = d; g2.M = rows; g2.N = d;
+    g2.K = 4 * d; g2.flags = kGemmResidual; g2.R = x; g2.ldr = d;
+    launch_linear(c, g2, t_fc2);
+}
+
+int wlk_encode(wlk_session* s, int32_t* content_mel_len) {
+    if (!s) return fail(WLK_ERR_ARG, "session is NULL");
+    return guarded([&]() {
+        wlk_model* m = s->m;
+        const wlk_dims& D = m->D;
+        WLK_HIP(hipSetDevice(m->device));
+        const LaunchCtx c = s->ctx();
+        const int N = s->audio_len;
+        const int n_total = (N + kPadSamples) / kHop;               // stft frames minus the dropped last one
+        int n_active = N > 0 ? (N + kNFft / 2 + kHop - 1) / kHop : 0;  // frames that see a non-zero sample
+        if (n_active > n_total) n_active = n_total;
+        if (n_active > s->frame_cap) return fail(WLK_ERR_CAPACITY, "audio longer than the session's frame capacity");
+        const int content = (n_total - kMelFrames) / 2;
+        const int d = D.n_audio_state, T = D.n_audio_ctx;
+
+        MelArgs ma;
+        ma.audio = s->audio[s->audio_cur]; ma.n_samples = N;
+        ma.window = m->w("mel.window"); ma.twiddle = m->twiddle; ma.filters = m->w("mel.filters");
+        ma.filt_lo = m->filt_lo; ma.filt_hi = m->filt_hi; ma.n_mels = D.n_mels;
+        ma.logmel = s->logmel; ma.frame_max = s->frame_max; ma.mel_t = s->mel_t;
+        ma.n_active = n_active; ma.n_total = n_total;
+        launch_mel(c, ma);
+
+        {   // conv1 (k=3, pad=1) + GELU: rows of A overlap (lda = n_mels < K = 3 n_mels)
+            GemmArgs g;
+            g.A = s->mel_t; g.lda = D.n_mels; g.W = m->w("enc.conv1.w"); g.bias = m->w("enc.conv1.b");
+            g.C = s->x1p + d; g.ldc = d; g.M = kMelFrames; g.N = d; g.K = 3 * D.n_mels; g.flags = kGemmGelu;
+            launch_gemm(c, g, "enc_conv1");
+        }
+        {   // conv2 (k=3, stride=2, pad=1) + GELU + positional embedding
+            GemmArgs g;
+            g.A = s->x1p; g.lda = 2 * d; g.W = m->w("enc.conv2.w"); g.bias = m->w("enc.conv2.b");
+            g.C = s->ex; g.ldc = d; g.M = T; g.N = d; g.K = 3 * d; g.flags = kGemmGelu | kGemmResidual;
+            g.R = m->w("enc.pos"); g.ldr = d;
+            launch_gemm(c, g, "enc_conv2");
+        }
+        const float scale = std::pow((float)kHeadDim, -0.25f);
+        for (int i = 0; i < D.n_audio_layer; ++i) {
+            const LayerW L = layer_weights(m, "enc", i, false);
+            launch_layernorm(c, s->ex, d, L.ln1w, L.ln1b, s->eh, d, T, d, "enc_ln1");
+            GemmArgs g;
+            g.A = s->eh; g.lda = d; g.W = L.qkvw; g.bias = L.qkvb; g.C = s->eqkv; g.ldc = 3 * d; g.M = T; g.N = 3 * d;
+            g.K = d; g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = 2 * d;
+            launch_gemm(c, g, "enc_qkv");
+            launch_encoder_attention(c, s->eqkv, s->eatt, T, d, D.n_audio_head);
+            GemmArgs o;
+            o.A = s->eatt; o.lda = d; o.W = L.outw; o.bias = L.outb; o.C = s->ex; o.ldc = d; o.M = T; o.N = d; o.K = d;
+            o.flags = kGemmResidual; o.R = s->ex; o.ldr = d;
+            launch_gemm(c, o, "enc_out");
+            transformer_mlp(c, L, s->ex, s->eh, s->emlp, T, d, "enc_ln2", "enc_fc1", "enc_fc2");
+        }
+        launch_layernorm(c, s->ex, d, m->w("enc.ln_post.w"), m->w("enc.ln_post.b"), s->enc_out, d, T, d, "enc_ln_post");
+        for (int i = 0; i < D.n_text_layer; ++i) {  // cross-attention K (scaled) and V of every decoder layer
+            const LayerW L = layer_weights(m, "dec", i, true);
+            GemmArgs g;
+            g.A = s->enc_out; g.lda = d; g.W = L.xkvw; g.bias = L.xkvb; g.C = s->cross_kv + (size_t)i * T * 2 * d;
+            g.ldc = 2 * d; g.M = T; g.N = 2 * d; g.K = d; g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = d;
+            launch_gemm(c, g, "dec_cross_kv");
+        }
+        s->encoded = true;
+        s->content_len = content;
+        s->self_len = 0;
+        s->n_steps = 0;
+        if (content_mel_len) *content_mel_len = content;
+        return WLK_OK;
+    });
+}
+
+// ---- decode ---------------------------------------------------------------------------------
+int wlk_decode(wlk_session* s, const int64_t* tokens, int n_rows, int n_tok, int first, int sot_index) {
+    if (!s || !tokens) return fail(WLK_ERR_ARG, "NULL argument");
+    if (!s->encoded) return fail(WLK_ERR_STATE, "wlk_decode before wlk_encode");
+    if (n_rows != s->beam) return fail(WLK_ERR_ARG, "n_rows must equal the session's beam size");
+    if (n_tok < 1) return fail(WLK_ERR_ARG, "n_tok must be >= 1");
+    if (!first && n_tok != 1) return fail(WLK_ERR_ARG, "only one token per row may be fed after the first call");
+    if (!first && s->n_steps == 0) return fail(WLK_ERR_STATE, "first decode of an infer must set first=1");
+    if (first && (sot_index < 0 || sot_index >= n_tok)) return fail(WLK_ERR_ARG, "sot_index out of range");
+    return guarded([&]() {
+        wlk_model* m = s->m;
+        const wlk_dims& D = m->D;
+        WLK_HIP(hipSetDevice(m->device));
+        const LaunchCtx c = s->ctx();
+        if (first) {
+            s->self_len = 0;
+            s->n_steps = 0;
+        }
+        const int offset = s->self_len;
+        const int ctx_len = D.n_text_ctx;
+        if (offset + n_tok > ctx_len) return fail(WLK_ERR_CAPACITY, "text context exceeded");
+        const int R = n_rows * n_tok;
+        const int d = D.n_text_state, T = D.n_audio_ctx, H = D.n_text_head, V = D.n_vocab;
+
+        // host -> device: tokens (as int32) and the alignment-window row map
+        WLK_HIP(hipStreamSynchronize(s->stream));  // pinned staging is single-entry
+        int* stage = static_cast<int*>(s->pinned);
+        if ((size_t)R * 3 * sizeof(int) > wlk_session::kPinnedBytes) return fail(WLK_ERR_CAPACITY, "too many rows");
+        int slot_row;
+        if (first) slot_row = 0;
+        else slot_row = ctx_len + ((s->n_steps - 1) % kAlignWindow);
+        for (int b = 0; b < n_rows; ++b)
+            for (int p = 0; p < n_tok; ++p) {
+                const int64_t t = tokens[(size_t)b * n_tok + p];
+                if (t < 0 || t >= V) return fail(WLK_ERR_ARG, "token id out of range");
+                stage[b * n_tok + p] = (int)t;
+                stage[R + b * n_tok + p] = first ? p : slot_row;
+                stage[2 * R + b * n_tok + p] = b;
+            }
+        WLK_HIP(hipMemcpyAsync(s->tokens_dev, stage, R * sizeof(int), hipMemcpyHostToDevice, s->stream));
+        WLK_HIP(hipMemcpyAsync(s->ring_row, stage + R, R * sizeof(int), hipMemcpyHostToDevice, s->stream));
+        WLK_HIP(hipMemcpyAsync(s->beam_of_row, stage + 2 * R, R * sizeof(int), hipMemcpyHostToDevice, s->stream));
+
+        launch_embed(c, s->tokens_dev, m->w("dec.tok_emb"), m->w("dec.pos"), s->dx, n_rows, n_tok, offset, d);
+        const float scale = std::pow((float)kHeadDim, -0.25f);
+        const size_t cache_layer = (size_t)s->beam * ctx_len * d;
+        for (int i = 0; i < D.n_text_layer; ++i) {
+            const LayerW L = layer_weights(m, "dec", i, true);
+            float* kc = s->kcache[s->kv_cur] + i * cache_layer;
+            float* vc = s->vcache[s->kv_cur] + i * cache_layer;
+            launch_layernorm(c, s->dx, d, L.ln1w, L.ln1b, s->dh, d, R, d, "dec_ln1");
+            GemmArgs g;
+            g.A = s->dh; g.lda = d; g.W = L.qkvw; g.bias = L.qkvb; g.C = s->dqkv; g.ldc = 3 * d; g.M = R; g.N = 3 * d;
+            g.K = d; g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = 2 * d;
+            launch_linear(c, g, "dec_qkv");
+            launch_kv_append(c, s->dqkv, kc, vc, n_rows, n_tok, offset, d, ctx_len);
+            launch_decoder_self_attention(c, s->dqkv, kc, vc, s->datt, n_rows, n_tok, offset, d, H, ctx_len);
+            GemmArgs o;
+            o.A = s->datt; o.lda = d; o.W = L.outw; o.bias = L.outb; o.C = s->dx; o.ldc = d; o.M = R; o.N = d; o.K = d;
+            o.flags = kGemmResidual; o.R = s->dx; o.ldr = d;
+            launch_linear(c, o, "dec_out");
+
+            launch_layernorm(c, s->dx, d, L.lnxw, L.lnxb, s->dh, d, R, d, "dec_lnx");
+            GemmArgs q;
+            q.A = s->dh; q.lda = d; q.W = L.xqw; q.bias = L.xqb; q.C = s->dq; q.ldc = d; q.M = R; q.N = d; q.K = d;
+            q.flags = kGemmScaleCols; q.scale = scale; q.scale_cols = d;
+            launch_linear(c, q, "dec_xq");
+            CrossAttnArgs ca;
+            ca.q = s->dq;
+            ca.k = s->cross_kv + (size_t)i * T * 2 * d;
+            ca.v = ca.k + d;
+            ca.ldkv = 2 * d;
+            ca.out = s->datt;
+            ca.rows = R; ca.d = d; ca.n_head = H; ca.T = T;
+            ca.head_rank = m->n_align > 0 ? m->head_rank + (size_t)i * H : nullptr;
+            ca.ring = s->ring;
+            ca.ring_row = s->ring_row;
+            ca.beam_of_row = s->beam_of_row;
+            ca.ring_rows = s->ring_rows;
+            ca.n_beam = s->beam;
+            ca.qk_debug = s->debug ? s->qk_debug + (size_t)i * s->max_rows * H * T : nullptr;
+            launch_decoder_cross_attention(c, ca);
+            GemmArgs xo;
+            xo.A = s->datt; xo.lda = d; xo.W = L.xoutw; xo.bias = L.xoutb; xo.C = s->dx; xo.ldc = d; xo.M = R; xo.N = d;
+            xo.K = d; xo.flags = kGemmResidual; xo.R = s->dx; xo.ldr = d;
+            launch_linear(c, xo, "dec_xout");
+            transformer_mlp(c, L, s->dx, s->dh, s->dmlp, R, d, "dec_ln2", "dec_fc1", "dec_fc2");
+        }
+        // final LayerNorm + vocabulary projection only for the rows the policy reads
+        const float* lnw = m->w("dec.ln.w");
+        const float* lnb = m->w("dec.ln.b");
+        launch_layernorm(c, s->dx + (size_t)(n_tok - 1) * d, (long)n_tok * d, lnw, lnb, s->hsel, d, n_rows, d, "dec_ln_f");
+        GemmArgs lg;
+        lg.A = s->hsel; lg.lda = d; lg.W = m->w("dec.tok_emb"); lg.C = s->logits_last; lg.ldc = V; lg.M = n_rows;
+        lg.N = V; lg.K = d;
+        launch_linear(c, lg, "dec_logits");
+        s->have_sot = false;
+        if (first) {
+            float* hs = s->hsel + (size_t)n_rows * d;
+            launch_layernorm(c, s->dx + (size_t)sot_index * d, (long)n_tok * d, lnw, lnb, hs, d, n_rows, d, "dec_ln_f");
+            GemmArgs ls = lg;
+            ls.A = hs; ls.C = s->logits_sot;
+            launch_linear(c, ls, "dec_logits");
+            s->have_sot = true;
+            s->prefill_rows = n_tok;
+        }
+        s->self_len += n_tok;
+        s->n_steps += 1;
+        s->last_rows = n_rows;
+        s->last_ntok = n_tok;
+        return WLK_OK;
+    });
+}
+
+int wlk_no_speech_prob(wlk_session* s, int no_speech_token, float* probs_host) {
+    if (!s || !probs_host) return fail(WLK_ERR_ARG, "NULL argument");
+    if (!s->have_sot) return fail(WLK_ERR_STATE, "no sot-row logits: call after the first decode of an infer");
+    if (no_speech_token < 0 || no_speech_token >= s->m->D.n_vocab) return fail(WLK_ERR_ARG, "token out of range");
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(s->m->device));
+        const LaunchCtx c = s->ctx();
+        launch_token_prob(c, s->logits_sot, s->m->D.n_vocab, s->beam, no_speech_token, s->probs);
+        WLK_HIP(hipMemcpyAsync(s->pinned, s->probs, s->beam * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        WLK_HIP(hipStreamSynchronize(s->stream));
+        std::memcpy(probs_host, s->pinned, s->beam * sizeof(float));
+        return WLK_OK;
+    });
+}
+
+int wlk_select(wlk_session* s, const int32_t* adj_row, const int32_t* adj_ids, const float* adj_deltas, int n_adj,
+               int k, int content_mel_len, float* top_logprobs_host, int32_t* top_ids_host, int32_t* frames_host) {
+    if (!s || !top_logprobs_host || !top_ids_host || !frames_host) return fail(WLK_ERR_ARG, "NULL argument");
+    if (s->n_steps == 0) return fail(WLK_ERR_STATE, "wlk_select before wlk_decode");
+    if (n_adj < 0 || n_adj > wlk_session::kAdjCap) return fail(WLK_ERR_ARG, "too many logit adjustments");
+    if (n_adj > 0 && (!adj_row || !adj_ids || !adj_deltas)) return fail(WLK_ERR_ARG, "NULL adjustment arrays");
+    if (k < 1 || k > 8) return fail(WLK_ERR_ARG, "k must be in [1, 8]");
+    if (content_mel_len < 0 || content_mel_len > s->m->D.n_audio_ctx) return fail(WLK_ERR_ARG, "content_mel_len out of range");
+    return guarded([&]() {
+        wlk_model* m = s->m;
+        const wlk_dims& D = m->D;
+        WLK_HIP(hipSetDevice(m->device));
+        const LaunchCtx c = s->ctx();
+        const int B = s->beam, V = D.n_vocab;
+        if (n_adj > 0) {
+            WLK_HIP(hipStreamSynchronize(s->stream));
+            char* st = static_cast<char*>(s->pinned);
+            std::memcpy(st, adj_row, n_adj * sizeof(int));
+            std::memcpy(st + n_adj * 4, adj_ids, n_adj * sizeof(int));
+            std::memcpy(st + n_adj * 8, adj_deltas, n_adj * sizeof(float));
+            WLK_HIP(hipMemcpyAsync(s->adj_row, st, n_adj * 4, hipMemcpyHostToDevice, s->stream));
+            WLK_HIP(hipMemcpyAsync(s->adj_ids, st + n_adj * 4, n_adj * 4, hipMemcpyHostToDevice, s->stream));
+            WLK_HIP(hipMemcpyAsync(s->adj_deltas, st + n_adj * 8, n_adj * 4, hipMemcpyHostToDevice, s->stream));
+            launch_apply_adjust(c, s->logits_last, V, B, s->adj_row, s->adj_ids, s->adj_deltas, n_adj);
+        }
+        launch_logsoftmax_topk(c, s->logits_last, V, B, k, s->top_vals, s->top_ids);
+
+        AlignArgs a;
+        a.ring = s->ring; a.n_align = m->n_align; a.n_beam = B; a.ring_rows = s->ring_rows; a.T = D.n_audio_ctx;
+        a.prefill_rows = s->n_steps <= kAlignWindow ? s->prefill_rows : 0;
+        a.n_single = std::min(s->n_steps - 1, kAlignWindow);
+        a.single_base = D.n_text_ctx;
+        a.newest_row = s->n_steps == 1 ? s->prefill_rows - 1 : D.n_text_ctx + ((s->n_steps - 2) % kAlignWindow);
+        a.content_len = content_mel_len;
+        a.z = s->z; a.attn_last = s->attn_last; a.frames = s->frames;
+        launch_alignatt(c, a);
+
+        // one readback: [top_vals B*k | top_ids B*k | frames B]
+        char* out = static_cast<char*>(s->pinned) + 65536;
+        WLK_HIP(hipMemcpyAsync(out, s->top_vals, B * k * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        WLK_HIP(hipMemcpyAsync(out + 1024, s->top_ids, B * k * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        WLK_HIP(hipMemcpyAsync(out + 2048, s->frames, B * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        WLK_HIP(hipStreamSynchronize(s->stream));
+        std::memcpy(top_logprobs_host, out, B * k * sizeof(float));
+        std::memcpy(top_ids_host, out + 1024, B * k * sizeof(int));
+        std::memcpy(frames_host, out + 2048, B * sizeof(int));
+        return WLK_OK;
+    });
+}
+
+int wlk_kv_reorder(wlk_session* s, const int32_t* source_rows, int n_rows) {
+    if (!s || !source_rows || n_rows != s->beam) return fail(WLK_ERR_ARG, "bad reorder request");
+    bool identity = true;
+    for (int i = 0; i < n_rows; ++i) {
+        if (source_rows[i] < 0 || source_rows[i] >= n_rows) return fail(WLK_ERR_ARG, "source row out of range");
+        identity &= source_rows[i] == i;
+    }
+    if (identity || s->self_len == 0) return WLK_OK;
+    return guarded([&]() {
+        const wlk_dims& D = s->m->D;
+        WLK_HIP(hipSetDevice(s->m->device));
+        const LaunchCtx c = s->ctx();
+        const size_t cache = (size_t)D.n_text_layer * s->beam * D.n_text_ctx * D.n_text_state;
+        if (!s->kcache[1]) {
+            s->kcache[1] = dev_alloc<float>(cache);
+            s->vcache[1] = dev_alloc<float>(cache);
+        }
+        WLK_HIP(hipStreamSynchronize(s->stream));
+        std::memcpy(s->pinned, source_rows, n_rows * sizeof(int));
+        WLK_HIP(hipMemcpyAsync(s->src_rows, s->pinned, n_rows * sizeof(int), hipMemcpyHostToDevice, s->stream));
+        const int cur = s->kv_cur;
+        launch_kv_gather(c, s->kcache[cur], s->kcache[cur ^ 1], s->src_rows, n_rows, s->self_len, D.n_text_state,
+                         D.n_text_ctx, D.n_text_layer);
+        launch_kv_gather(c, s->vcache[cur], s->vcache[cur ^ 1], s->src_rows, n_rows, s->self_len, D.n_text_state,
+                         D.n_text_ctx, D.n_text_layer);
+        s->kv_cur ^= 1;
+        return WLK_OK;
+    });
+}
+
+int wlk_sync(wlk_session* s) {
+    if (!s) return fail(WLK_ERR_ARG, "session is NULL");
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(s->m->device));
+        WLK_HIP(hipStreamSynchronize(s->stream));
+        return WLK_OK;
+    });
+}
+
+// ---- exports --------------------------------------------------------------------------------
+static int copy_out(wlk_session* s, const float* dev, uint64_t n, float* host, uint64_t cap, uint64_t* n_written) {
+    if (n_written) *n_written = n;
+    if (n > cap) return fail(WLK_ERR_CAPACITY, "export buffer too small: need " + std::to_string(n) + " floats");
+    WLK_HIP(hipStreamSynchronize(s->stream));
+    WLK_HIP(hipMemcpy(host, dev, n * sizeof(float), hipMemcpyDeviceToHost));
+    return WLK_OK;
+}
+
+int wlk_export(wlk_session* s, const char* what, float* host, uint64_t capacity, uint64_t* n_written) {
+    if (!s || !what || !host) return fail(WLK_ERR_ARG, "NULL argument");
+    return guarded([&]() {
+        const wlk_dims& D = s->m->D;
+        WLK_HIP(hipSetDevice(s->m->device));
+        const std::string w(what);
+        const uint64_t T = D.n_audio_ctx, d = D.n_text_state;
+        if (w == "mel") {  // reference layout [n_mels][3000]
+            const uint64_t n = (uint64_t)D.n_mels * kMelFrames;
+            if (n_written) *n_written = n;
+            if (n > capacity) return fail(WLK_ERR_CAPACITY, "export buffer too small");
+            std::vector<float> tm(n);
+            WLK_HIP(hipStreamSynchronize(s->stream));
+            WLK_HIP(hipMemcpy(tm.data(), s->mel_t + D.n_mels, n * sizeof(float), hipMemcpyDeviceToHost));
+            for (int t = 0; t < kMelFrames; ++t)
+                for (int mm = 0; mm < D.n_mels; ++mm) host[(size_t)mm * kMelFrames + t] = tm[(size_t)t * D.n_mels + mm];
+            return WLK_OK;
+        }
+        if (w == "enc") return copy_out(s, s->enc_out, T * d, host, capacity, n_written);
+        if (w == "logits_last") return copy_out(s, s->logits_last, (uint64_t)s->beam * D.n_vocab, host, capacity, n_written);
+        if (w == "logits_sot") return copy_out(s, s->logits_sot, (uint64_t)s->beam * D.n_vocab, host, capacity, n_written);
+        if (w == "attn_last") return copy_out(s, s->attn_last, (uint64_t)s->beam * T, host, capacity, n_written);
+        if (w == "dec_x") return copy_out(s, s->dx, (uint64_t)s->last_rows * s->last_ntok * d, host, capacity, n_written);
+        const auto colon = w.find(':');
+        if (colon != std::string::npos) {
+            const std::string kind = w.substr(0, colon);
+            const int idx = std::atoi(w.c_str() + colon + 1);
+            if (kind == "cross_qk") {
+                if (!s->qk_debug) return fail(WLK_ERR_STATE, "cross_qk export needs a debug session");
+                if (idx < 0 || idx >= D.n_text_layer) return fail(WLK_ERR_ARG, "layer out of range");
+                const uint64_t rows = (uint64_t)s->last_rows * s->last_ntok;
+                return copy_out(s, s->qk_debug + (size_t)idx * s->max_rows * D.n_text_head * T,
+                                rows * D.n_text_head * T, host, capacity, n_written);
+            }
+            if (kind == "self_k" || kind == "self_v") {
+                if (idx < 0 || idx >= D.n_text_layer) return fail(WLK_ERR_ARG, "layer out of range");
+                const float* base = (kind == "self_k" ? s->kcache : s->vcache)[s->kv_cur] +
+                                    (size_t)idx * s->beam * D.n_text_ctx * d;
+                const uint64_t n = (uint64_t)s->beam * s->self_len * d;
+                if (n_written) *n_written = n;
+                if (n > capacity) return fail(WLK_ERR_CAPACITY, "export buffer too small");
+                WLK_HIP(hipStreamSynchronize(s->stream));
+                for (int b = 0; b < s->beam; ++b)
+                    WLK_HIP(hipMemcpy(host + (size_t)b * s->self_len * d, base + (size_t)b * D.n_text_ctx * d,
+                                      (size_t)s->self_len * d * sizeof(float), hipMemcpyDeviceToHost));
+                return WLK_OK;
+            }
+            if (kind == "xattn_w") {  // beam 0 window rows of one alignment head: prefill rows then single slots
+                if (idx < 0 || idx >= s->m->n_align) return fail(WLK_ERR_ARG, "alignment rank out of range");
+                const int pre = s->n_steps <= kAlignWindow ? s->prefill_rows : 0;
+                const int ns = std::min(s->n_steps - 1, kAlignWindow);
+                const uint64_t n = (uint64_t)(pre + ns) * T;
+                if (n_written) *n_written = n;
+                if (n > capacity) return fail(WLK_ERR_CAPACITY, "export buffer too small");
+                const float* base = s->ring + (size_t)idx * s->beam * s->ring_rows * T;
+                WLK_HIP(hipStreamSynchronize(s->stream));
+                if (pre) WLK_HIP(hipMemcpy(host, base, (size_t)pre * T * sizeof(float), hipMemcpyDeviceToHost));
+                if (ns)
+                    WLK_HIP(hipMemcpy(host + (size_t)pre * T, base + (size_t)D.n_text_ctx * T, (size_t)ns * T * sizeof(float),
+                                      hipMemcpyDeviceToHost));
+                return WLK_OK;
+            }
+        }
+        return fail(WLK_ERR_ARG, "unknown export '" + w + "'");
+    });
+}
+
+// ---- profiling ------------------------------------------------------------------------------
+int wlk_prof_begin(wlk_session* s) {
+    if (!s) return fail(WLK_ERR_ARG, "session is NULL");
+    for (auto& r : s->prof.recs) {
+        s->prof.pool.push_back(r.a);
+        s->prof.pool.push_back(r.b);
+    }
+    s->prof.recs.clear();
+    s->prof_on = true;
+    return WLK_OK;
+}
+
+int wlk_prof_end(wlk_session* s, int cap, const char** names, float* total_ms, int32_t* launches, double* flops,
+                 double* bytes, int32_t* n_out) {
+    if (!s || !n_out) return fail(WLK_ERR_ARG, "NULL argument");
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(s->m->device));
+        WLK_HIP(hipStreamSynchronize(s->stream));
+        s->prof_on = false;
+        std::vector<const char*> order;
+        std::map<std::string, std::pair<double, int>> acc;
+        std::map<std::string, std::pair<double, double>> work;
+        std::map<std::string, const char*> cname;
+        for (auto& r : s->prof.recs) {
+            float ms = 0.f;
+            WLK_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+            work[r.name].first += r.flops;
+            work[r.name].second += r.bytes;
+            auto it = acc.find(r.name);
+            if (it == acc.end()) {
+                acc[r.name] = {ms, 1};
+                cname[r.name] = r.name;
+                order.push_back(r.name);
+            } else {
+                it->second.first += ms;
+                it->second.second += 1;
+            }
+        }
+        int n = 0;
+        for (const char* nm : order) {
+            if (n >= cap) break;
+            if (names) names[n] = cname[nm];
+            if (total_ms) total_ms[n] = (float)acc[nm].first;
+            if (launches) launches[n] = acc[nm].second;
+            if (flops) flops[n] = work[nm].first;
+            if (bytes) bytes[n] = work[nm].second;
+            ++n;
+        }
+        *n_out = n;
+        return WLK_OK;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,155 @@
+// Internal declarations shared by the kernel files and the C-ABI layer.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+namespace wlk {
+
+constexpr int kNFft = 400;
+constexpr int kHop = 160;
+constexpr int kNFreq = 201;
+constexpr int kMelFrames = 3000;     // frames fed to the encoder (30 s)
+constexpr int kPadSamples = 480000;  // zero padding the streaming path appends (simul_whisper.py:346)
+constexpr int kHeadDim = 64;         // every Whisper size uses 64-wide heads
+constexpr int kAlignWindow = 16;     // decode steps kept for AlignAtt (align_att_base.py:223)
+
+struct HipError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+inline void hip_check(hipError_t e, const char* what, const char* file, int line) {
+    if (e != hipSuccess) {
+        throw HipError(std::string(what) + " failed: " + hipGetErrorString(e) + " (" + file + ":" +
+                       std::to_string(line) + ")");
+    }
+}
+#define WLK_HIP(expr) ::wlk::hip_check((expr), #expr, __FILE__, __LINE__)
+
+// optional per-kernel HIP-event timing (wlk_prof_begin/end)
+struct Profiler;
+struct LaunchCtx {
+    hipStream_t stream = nullptr;
+    Profiler* prof = nullptr;
+};
+// flops / bytes are the ALGORITHMIC work of the launch (what the roofline fraction is computed from)
+void prof_before(const LaunchCtx& ctx, const char* name, double flops, double bytes);
+void prof_after(const LaunchCtx& ctx);
+
+struct KernelScope {  // RAII: brackets one launch with events when profiling is armed
+    const LaunchCtx& ctx;
+    KernelScope(const LaunchCtx& c, const char* name, double flops = 0.0, double bytes = 0.0) : ctx(c) {
+        if (ctx.prof) prof_before(ctx, name, flops, bytes);
+    }
+    ~KernelScope() {
+        if (ctx.prof) prof_after(ctx);
+    }
+};
+
+// ---- gemm_f32.hip ---------------------------------------------------------------------------
+// C[M,N] = epilogue(A[M,K] * W[N,K]^T + bias[N]); fp32 MFMA (v_mfma_f32_32x32x2_f32).
+enum GemmFlags : int {
+    kGemmGelu = 1,      // exact-erf GELU after bias
+    kGemmResidual = 2,  // += R[m*ldr + n] (after GELU); R may alias C
+    kGemmScaleCols = 4, // columns n < scale_cols are multiplied by `scale` (after bias)
+};
+struct GemmArgs {
+    const float* A = nullptr;
+    long lda = 0;
+    const float* W = nullptr;  // [N][K] row-major
+    const float* bias = nullptr;
+    float* C = nullptr;
+    long ldc = 0;
+    const float* R = nullptr;
+    long ldr = 0;
+    int M = 0, N = 0, K = 0;
+    int flags = 0;
+    float scale = 1.f;
+    int scale_cols = 0;
+};
+void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag);
+// weight-streaming path for M <= 8 rows (decode steps); same contract as launch_gemm
+void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag);
+inline int gemv_row_bucket(int M) { return M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : 8; }
+inline bool gemv_applicable(int M, int K) {
+    return M <= 8 && (long)gemv_row_bucket(M) * K * 4 <= 64 * 1024 && K % 4 == 0;
+}
+inline void launch_linear(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
+    if (gemv_applicable(g.M, g.K)) launch_gemv(ctx, g, tag);
+    else launch_gemm(ctx, g, tag);
+}
+
+// ---- layernorm.hip --------------------------------------------------------------------------
+void launch_layernorm(const LaunchCtx& ctx, const float* x, long ldx, const float* gamma, const float* beta,
+                      float* y, long ldy, int rows, int d, const char* tag);
+
+// ---- mel.hip --------------------------------------------------------------------------------
+struct MelArgs {
+    const float* audio;    // device, n_samples valid
+    int n_samples;
+    const float* window;   // [400] periodic hann
+    const double* twiddle; // [400] cos(2*pi*i/400) in fp64
+    const float* filters;  // [n_mels][201]
+    const int* filt_lo;    // [n_mels] first non-zero bin
+    const int* filt_hi;    // [n_mels] one past the last non-zero bin
+    int n_mels;
+    float* logmel;         // [n_active][n_mels] scratch: log10(clamp(mel))
+    float* frame_max;      // [n_active]
+    float* mel_t;          // [(3000+2)][n_mels] time-major, row 0 and row 3001 stay zero (conv padding)
+    int n_active;          // frames that can see a non-zero sample (computed by the caller)
+    int n_total;           // frames the reference's STFT yields before trimming to 3000
+};
+void launch_mel(const LaunchCtx& ctx, const MelArgs& a);
+
+// ---- attention.hip --------------------------------------------------------------------------
+// encoder self-attention over qkv[T][3d] (q and k pre-scaled), out[T][d]; flash-style, fp32 MFMA
+void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out, int T, int d, int n_head);
+
+// ---- decoder.hip ----------------------------------------------------------------------------
+void launch_embed(const LaunchCtx& ctx, const int* tokens, const float* tok_emb, const float* pos_emb,
+                  float* x, int n_rows, int n_tok, int offset, int d);
+void launch_kv_append(const LaunchCtx& ctx, const float* qkv, float* kc, float* vc, int n_rows, int n_tok,
+                      int offset, int d, int ctx_len);
+void launch_decoder_self_attention(const LaunchCtx& ctx, const float* qkv, const float* kc, const float* vc,
+                                   float* out, int n_rows, int n_tok, int offset, int d, int n_head, int ctx_len);
+struct CrossAttnArgs {
+    const float* q;        // [rows][d], pre-scaled
+    const float* k;        // [T][ldkv] pre-scaled keys of this layer
+    const float* v;        // [T][ldkv]
+    long ldkv;
+    float* out;            // [rows][d]
+    int rows, d, n_head, T;
+    const int* head_rank;  // [n_head]: alignment rank of (layer, head) or -1
+    float* ring;           // alignment window base [n_align][n_rows_beam][ring_rows][T]
+    const int* ring_row;   // [rows]: destination ring row of each query row
+    const int* beam_of_row;// [rows]
+    int ring_rows, n_beam;
+    float* qk_debug;       // [rows][n_head][T] or nullptr
+};
+void launch_decoder_cross_attention(const LaunchCtx& ctx, const CrossAttnArgs& a);
+void launch_kv_gather(const LaunchCtx& ctx, const float* src, float* dst, const int* source_rows, int n_rows,
+                      int len, int d, int ctx_len, int n_layer);
+
+// ---- select.hip -----------------------------------------------------------------------------
+void launch_apply_adjust(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, const int* adj_row,
+                         const int* adj_ids, const float* adj_deltas, int n_adj);
+void launch_logsoftmax_topk(const LaunchCtx& ctx, const float* logits, int n_vocab, int n_rows, int k,
+                            float* top_vals, int* top_ids);
+void launch_token_prob(const LaunchCtx& ctx, const float* logits, int n_vocab, int n_rows, int token, float* probs);
+struct AlignArgs {
+    const float* ring;   // [n_align][n_beam][ring_rows][T]
+    int n_align, n_beam, ring_rows, T;
+    int prefill_rows;    // rows of the first (prefill) step still inside the window, else 0
+    int n_single;        // valid single-step slots (<= 16)
+    int newest_row;      // ring row of the newest query row
+    int single_base;     // first ring row of the single-step slots
+    int content_len;
+    float* z;            // scratch [n_beam][n_align][T]
+    float* attn_last;    // [n_beam][T] head-mean of the median-filtered newest row
+    int* frames;         // [n_beam]
+};
+void launch_alignatt(const LaunchCtx& ctx, const AlignArgs& a);
+
+}  // namespace wlk

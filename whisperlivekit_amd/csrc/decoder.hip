@@ -1,0 +1,260 @@
+// Decoder-side kernels that are not plain linear layers (whisper/model.py:100-173, 279-332):
+// token+position embedding, self-attention over the growing KV cache, and cross-attention over
+// the 1500 encoder positions that ALSO produces what AlignAtt needs - the softmaxed attention
+// row of every alignment head - without ever writing the [H, q, 1500] QK tensor the reference
+// returns from each layer (model.py:170-173, simul_whisper.py:402-417).
+//
+// These are HBM/L2-bound byte movers (one pass over K and V per query row); the rules that
+// matter are coalescing (16 lanes x float4 = one 256-byte head row per load), wavefront
+// reductions for the softmax, and keeping scores in LDS.
+#include "common.h"
+
+namespace wlk {
+
+__global__ __launch_bounds__(128) void embed_kernel(const int* __restrict__ tokens,
+                                                    const float* __restrict__ tok_emb,
+                                                    const float* __restrict__ pos_emb, float* __restrict__ x,
+                                                    int n_tok, int offset, int d) {
+    const int row = blockIdx.x;             // row = beam * n_tok + p
+    const int p = row % n_tok;
+    const float* e = tok_emb + (long)tokens[row] * d;
+    const float* pe = pos_emb + (long)(offset + p) * d;
+    for (int c = threadIdx.x; c < d; c += 128) x[(long)row * d + c] = e[c] + pe[c];
+}
+
+void launch_embed(const LaunchCtx& ctx, const int* tokens, const float* tok_emb, const float* pos_emb,
+                  float* x, int n_rows, int n_tok, int offset, int d) {
+    KernelScope ks(ctx, "dec_embed");
+    hipLaunchKernelGGL(embed_kernel, dim3(n_rows * n_tok), dim3(128), 0, ctx.stream, tokens, tok_emb, pos_emb, x,
+                       n_tok, offset, d);
+    WLK_HIP(hipGetLastError());
+}
+
+// qkv rows are [q | k | v] (3d floats); append k and v of every row to the per-beam caches
+__global__ __launch_bounds__(256) void kv_append_kernel(const float* __restrict__ qkv, float* __restrict__ kc,
+                                                        float* __restrict__ vc, int n_tok, int offset, int d,
+                                                        int ctx_len) {
+    const int row = blockIdx.x;
+    const int b = row / n_tok, p = row - b * n_tok;
+    const float* src = qkv + (long)row * 3 * d;
+    const long dst = ((long)b * ctx_len + offset + p) * d;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        kc[dst + c] = src[d + c];
+        vc[dst + c] = src[2 * d + c];
+    }
+}
+
+void launch_kv_append(const LaunchCtx& ctx, const float* qkv, float* kc, float* vc, int n_rows, int n_tok,
+                      int offset, int d, int ctx_len) {
+    KernelScope ks(ctx, "dec_kv_append");
+    hipLaunchKernelGGL(kv_append_kernel, dim3(n_rows * n_tok), dim3(256), 0, ctx.stream, qkv, kc, vc, n_tok,
+                       offset, d, ctx_len);
+    WLK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// Self-attention, one wave per (query row, head).  Causal: row p of the fed block sees cache
+// positions 0..offset+p (model.py:164-166 adds mask[:n_ctx,:n_ctx]; with a cache and one fed
+// token that mask is the single 0, i.e. everything cached is visible).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void decoder_self_attention_kernel(const float* __restrict__ qkv,
+                                                                    const float* __restrict__ kc,
+                                                                    const float* __restrict__ vc,
+                                                                    float* __restrict__ out, int n_tok, int offset,
+                                                                    int d, int ctx_len) {
+    __shared__ float qs[64];
+    __shared__ float sc[448 + 64];
+    const int lane = threadIdx.x;
+    const int row = blockIdx.x;
+    const int head = blockIdx.y;
+    const int b = row / n_tok, p = row - b * n_tok;
+    const int n_keys = offset + p + 1;
+    qs[lane] = qkv[(long)row * 3 * d + head * 64 + lane];
+    __syncthreads();
+    const float* kb = kc + (long)b * ctx_len * d + head * 64;
+    const float* vb = vc + (long)b * ctx_len * d + head * 64;
+
+    float mx = -INFINITY;
+    for (int j = lane; j < n_keys; j += 64) {
+        const float4* kr = reinterpret_cast<const float4*>(kb + (long)j * d);
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float4 k4 = kr[c];
+            acc = fmaf(qs[c * 4 + 0], k4.x, acc);
+            acc = fmaf(qs[c * 4 + 1], k4.y, acc);
+            acc = fmaf(qs[c * 4 + 2], k4.z, acc);
+            acc = fmaf(qs[c * 4 + 3], k4.w, acc);
+        }
+        sc[j] = acc;
+        mx = fmaxf(mx, acc);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float sum = 0.f;
+    for (int j = lane; j < n_keys; j += 64) {
+        const float e = expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    for (int j = lane; j < n_keys; j += 64) sc[j] = sc[j] / sum;
+    __syncthreads();
+    float acc = 0.f;
+    for (int j = 0; j < n_keys; ++j) acc = fmaf(sc[j], vb[(long)j * d + lane], acc);
+    out[(long)row * d + head * 64 + lane] = acc;
+}
+
+void launch_decoder_self_attention(const LaunchCtx& ctx, const float* qkv, const float* kc, const float* vc,
+                                   float* out, int n_rows, int n_tok, int offset, int d, int n_head, int ctx_len) {
+    if (offset + n_tok > 448 + 64) throw std::invalid_argument("self-attention: context too long");
+    KernelScope ks(ctx, "dec_self_attention");
+    hipLaunchKernelGGL(decoder_self_attention_kernel, dim3(n_rows * n_tok, n_head), dim3(64), 0, ctx.stream, qkv,
+                       kc, vc, out, n_tok, offset, d, ctx_len);
+    WLK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cross-attention, one 256-thread workgroup per (query row, head).
+//   pass 1: scores s_j = q . K_j for the T = 1500 encoder positions.  A 16-lane group reads one
+//           256-byte key row (float4 per lane), a wave covers 4 keys per instruction, the dot is
+//           folded with 4 xor-shuffles.
+//   pass 2: softmax over all T positions (the reference softmaxes the full 1500 BEFORE trimming
+//           to content_mel_len, simul_whisper.py:411,432) - wave reductions + one LDS exchange.
+//           If (layer, head) is an alignment head the probabilities go to the session's
+//           alignment window row (they are exactly F.softmax(qk) that _process_cross_attention
+//           recomputes); in debug sessions the raw scores are exported too.
+//   pass 3: out_d = sum_j w_j V_j[d] with the same 16-lane row mapping, partials merged in LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCrossMaxT = 1536;
+
+__global__ __launch_bounds__(256) void decoder_cross_attention_kernel(CrossAttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float qs[64];
+    __shared__ float sc[kCrossMaxT];
+    __shared__ float red[8];
+    __shared__ __attribute__((aligned(16))) float part[16 * 64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int row = blockIdx.x;
+    const int head = blockIdx.y;
+    const int sub = lane & 15;   // float4 slot inside the 64-wide head
+    const int kq = lane >> 4;    // which of the 4 keys of this wave-instruction
+    if (tid < 64) qs[tid] = a.q[(long)row * a.d + head * 64 + tid];
+    __syncthreads();
+    const float4 q4 = reinterpret_cast<const float4*>(qs)[sub];
+    const float* kb = a.k + head * 64 + sub * 4;
+    const float* vb = a.v + head * 64 + sub * 4;
+
+    // pass 1
+    float mx = -INFINITY;
+    for (int j0 = wave * 4; j0 < a.T; j0 += 16) {
+        const int j = j0 + kq;
+        float acc = 0.f;
+        if (j < a.T) {
+            const float4 k4 = *reinterpret_cast<const float4*>(kb + (long)j * a.ldkv);
+            acc = fmaf(q4.x, k4.x, acc);
+            acc = fmaf(q4.y, k4.y, acc);
+            acc = fmaf(q4.z, k4.z, acc);
+            acc = fmaf(q4.w, k4.w, acc);
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        acc += __shfl_xor(acc, 8, 64);
+        if (j < a.T) {
+            if (sub == 0) sc[j] = acc;
+            mx = fmaxf(mx, acc);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+
+    if (a.qk_debug) {
+        float* dst = a.qk_debug + ((long)row * a.n_head + head) * a.T;
+        for (int j = tid; j < a.T; j += 256) dst[j] = sc[j];
+    }
+
+    // pass 2
+    float sum = 0.f;
+    for (int j = tid; j < a.T; j += 256) {
+        const float e = expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    const int rank = a.head_rank ? a.head_rank[head] : -1;
+    float* ring_dst = nullptr;
+    if (rank >= 0) {
+        ring_dst = a.ring + (((long)rank * a.n_beam + a.beam_of_row[row]) * a.ring_rows + a.ring_row[row]) * a.T;
+    }
+    for (int j = tid; j < a.T; j += 256) {
+        const float w = sc[j] / sum;
+        sc[j] = w;
+        if (ring_dst) ring_dst[j] = w;
+    }
+    __syncthreads();
+
+    // pass 3
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j0 = wave * 4; j0 < a.T; j0 += 16) {
+        const int j = j0 + kq;
+        if (j < a.T) {
+            const float w = sc[j];
+            const float4 v4 = *reinterpret_cast<const float4*>(vb + (long)j * a.ldkv);
+            o.x = fmaf(w, v4.x, o.x);
+            o.y = fmaf(w, v4.y, o.y);
+            o.z = fmaf(w, v4.z, o.z);
+            o.w = fmaf(w, v4.w, o.w);
+        }
+    }
+    reinterpret_cast<float4*>(part)[(wave * 4 + kq) * 16 + sub] = o;
+    __syncthreads();
+    if (tid < 64) {
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc += part[s * 64 + tid];
+        a.out[(long)row * a.d + head * 64 + tid] = acc;
+    }
+}
+
+void launch_decoder_cross_attention(const LaunchCtx& ctx, const CrossAttnArgs& a) {
+    if (a.T > kCrossMaxT) throw std::invalid_argument("cross-attention: T too large");
+    // per (row, head): read K and V slices once (T x 64 floats each)
+    KernelScope ks(ctx, "dec_cross_attention", 4.0 * a.rows * (double)a.T * a.d,
+                   4.0 * 2.0 * a.rows * (double)a.T * a.d);
+    hipLaunchKernelGGL(decoder_cross_attention_kernel, dim3(a.rows, a.n_head), dim3(256), 0, ctx.stream, a);
+    WLK_HIP(hipGetLastError());
+}
+
+// beam reorder of the self-attention caches: dst[l][b] = src[l][source_rows[b]]
+__global__ __launch_bounds__(256) void kv_gather_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                        const int* __restrict__ source_rows, int n_rows, int len,
+                                                        int d, int ctx_len) {
+    const int l = blockIdx.z, b = blockIdx.y, t = blockIdx.x;
+    if (t >= len) return;
+    const long layer = (long)l * n_rows * ctx_len * d;
+    const float* s = src + layer + ((long)source_rows[b] * ctx_len + t) * d;
+    float* o = dst + layer + ((long)b * ctx_len + t) * d;
+    for (int c = threadIdx.x; c < d; c += 256) o[c] = s[c];
+}
+
+void launch_kv_gather(const LaunchCtx& ctx, const float* src, float* dst, const int* source_rows, int n_rows,
+                      int len, int d, int ctx_len, int n_layer) {
+    if (len <= 0) return;
+    KernelScope ks(ctx, "dec_kv_gather");
+    hipLaunchKernelGGL(kv_gather_kernel, dim3(len, n_rows, n_layer), dim3(256), 0, ctx.stream, src, dst,
+                       source_rows, n_rows, len, d, ctx_len);
+    WLK_HIP(hipGetLastError());
+}
+
+}  // namespace wlk

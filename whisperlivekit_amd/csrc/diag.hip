@@ -1,0 +1,73 @@
+// Kernel-level diagnostics behind the C ABI: run ONE kernel on host data and hand the result back,
+// so the GPU parity tests can compare each building block with a plain fp32 reference.
+#include <vector>
+
+#include "../../include/wlk_hip.h"
+#include "common.h"
+
+using namespace wlk;
+
+namespace {
+thread_local std::string g_diag_error;
+struct DevBuf {
+    float* p = nullptr;
+    explicit DevBuf(size_t n, const float* host = nullptr) {
+        WLK_HIP(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(float)));
+        if (host) WLK_HIP(hipMemcpy(p, host, n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    ~DevBuf() { (void)hipFree(p); }
+};
+template <typename F>
+int run(F&& f) {
+    try {
+        f();
+        WLK_HIP(hipDeviceSynchronize());
+        return WLK_OK;
+    } catch (const std::exception& e) {
+        g_diag_error = e.what();
+        return WLK_ERR_HIP;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+const char* wlk_diag_last_error(void) { return g_diag_error.c_str(); }
+
+int wlk_diag_linear(const float* a, int64_t lda, int64_t a_floats, const float* w, const float* bias, const float* r,
+                    int64_t ldr, int m, int n, int k, int flags, float scale, int scale_cols, int force_gemv, float* c) {
+    return run([&]() {
+        DevBuf A(a_floats, a), W((size_t)n * k, w), B(n, bias), R(r ? (size_t)m * ldr : 1, r), Cc((size_t)m * n);
+        GemmArgs g;
+        g.A = A.p; g.lda = lda; g.W = W.p; g.bias = bias ? B.p : nullptr; g.C = Cc.p; g.ldc = n;
+        g.R = r ? R.p : nullptr; g.ldr = ldr; g.M = m; g.N = n; g.K = k; g.flags = flags; g.scale = scale;
+        g.scale_cols = scale_cols;
+        LaunchCtx ctx;
+        if (force_gemv) launch_gemv(ctx, g, "diag_gemv");
+        else launch_gemm(ctx, g, "diag_gemm");
+        WLK_HIP(hipDeviceSynchronize());
+        WLK_HIP(hipMemcpy(c, Cc.p, (size_t)m * n * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+
+int wlk_diag_layernorm(const float* x, const float* gamma, const float* beta, int rows, int d, float* y) {
+    return run([&]() {
+        DevBuf X((size_t)rows * d, x), G(d, gamma), Bt(d, beta), Y((size_t)rows * d);
+        LaunchCtx ctx;
+        launch_layernorm(ctx, X.p, d, G.p, Bt.p, Y.p, d, rows, d, "diag_ln");
+        WLK_HIP(hipDeviceSynchronize());
+        WLK_HIP(hipMemcpy(y, Y.p, (size_t)rows * d * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+
+int wlk_diag_encoder_attention(const float* qkv, int t, int d, int n_head, float* out) {
+    return run([&]() {
+        DevBuf Q((size_t)t * 3 * d, qkv), O((size_t)t * d);
+        LaunchCtx ctx;
+        launch_encoder_attention(ctx, Q.p, O.p, t, d, n_head);
+        WLK_HIP(hipDeviceSynchronize());
+        WLK_HIP(hipMemcpy(out, O.p, (size_t)t * d * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,239 @@
+// fp32 GEMM / GEMV for the Whisper encoder and decoder on gfx950.
+//
+//   C[M,N] = epilogue( A[M,K] . W[N,K]^T + bias[N] )
+//
+// Both operands are K-contiguous ("NT"), which is how the reference stores activations
+// [tokens, features] and nn.Linear weights [out, in] (whisper/model.py:44-50).  The two 1-D
+// convolutions of the encoder stem (whisper/model.py:230-231,244-245) are the same GEMM with
+// overlapping A rows (lda < K) over a time-major, zero-padded activation buffer, so no im2col
+// buffer is ever materialised.
+//
+// Matrix core: v_mfma_f32_32x32x2_f32 - exact fp32 (bitwise an fmaf chain), 64 cycles per
+// instruction per SIMD, 157 TFLOP/s chip peak.  One wave owns a 32x32 tile (16 accumulator
+// VGPRs); a 256-thread workgroup owns 64x64 and walks K in steps of 32 through a double-
+// buffered LDS stage.  LDS rows are padded to 36 floats so that the per-lane ds_read_b128 of
+// 4 consecutive k values is conflict-free in every 16-lane service group (bank = 4*(9*row mod 16)).
+//
+// k-permutation trick: MFMA step j of k-group s takes k = 8s+j from lanes 0-31 and k = 8s+4+j
+// from lanes 32-63, for A and B alike.  A contraction is order-free, so each lane fetches its
+// four k values with ONE 16-byte LDS read instead of four strided 4-byte reads.
+#include "common.h"
+
+namespace wlk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = BK + 4;
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float4 load4_guard(const float* p, bool ok) {
+    return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Ws[2][BN * LDS_LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+
+    // staging map: 512 float4 per operand tile, two per thread
+    int st_row[2], st_c4[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int idx = tid + 256 * i;
+        st_row[i] = idx >> 3;
+        st_c4[i] = idx & 7;
+    }
+    const float* a_ptr[2];
+    const float* w_ptr[2];
+    bool a_ok[2], w_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a_ok[i] = (m0 + st_row[i]) < g.M;
+        w_ok[i] = (n0 + st_row[i]) < g.N;
+        a_ptr[i] = g.A + (long)(m0 + st_row[i]) * g.lda + st_c4[i] * 4;
+        w_ptr[i] = g.W + (long)(n0 + st_row[i]) * g.K + st_c4[i] * 4;
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    const int nk = (g.K + BK - 1) / BK;
+    float4 ra[2], rw[2];
+    auto fetch = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool kin = (k0 + st_c4[i] * 4) < g.K;  // K % 4 == 0 is required by the launcher
+            ra[i] = load4_guard(a_ptr[i] + k0, a_ok[i] && kin);
+            rw[i] = load4_guard(w_ptr[i] + k0, w_ok[i] && kin);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<float4*>(&As[buf][st_row[i] * LDS_LD + st_c4[i] * 4]) = ra[i];
+            *reinterpret_cast<float4*>(&Ws[buf][st_row[i] * LDS_LD + st_c4[i] * 4]) = rw[i];
+        }
+    };
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+
+    const int a_off = (wr * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+    const int w_off = (wc * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) fetch(kt + 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][a_off + s * 8]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&Ws[buf][w_off + s * 8]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+        if (kt + 1 < nk) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // epilogue: acc[r] is C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31] of the wave tile
+    const int col = n0 + wc * 32 + (lane & 31);
+    if (col < g.N) {
+        const float b = g.bias ? g.bias[col] : 0.f;
+        const bool do_scale = (g.flags & kGemmScaleCols) && col < g.scale_cols;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < g.M) {
+                float v = acc[r] + b;
+                if (do_scale) v *= g.scale;
+                if (g.flags & kGemmGelu) v = gelu_erf(v);
+                if (g.flags & kGemmResidual) v += g.R[(long)row * g.ldr + col];
+                g.C[(long)row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
+void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
+    if (g.M <= 0 || g.N <= 0) return;
+    if (g.K % 4 != 0 || g.lda % 4 != 0) throw std::invalid_argument("gemm: K and lda must be multiples of 4");
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
+    KernelScope ks(ctx, tag, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    hipLaunchKernelGGL(gemm_nt_f32_kernel, grid, dim3(256), 0, ctx.stream, g);
+    WLK_HIP(hipGetLastError());
+}
+
+// -------------------------------------------------------------------------------------------------
+// GEMV path: M <= 8 activation rows (one decode step, beam <= 8).  Pure weight streaming: every
+// wave owns 4 consecutive output features, its 64 lanes stride over K in float4 units
+// (1 KiB coalesced per wave-instruction), the M x K activations sit in LDS, and the partial
+// sums are folded with DPP-free xor shuffles.  HBM-bound by construction: K*4 bytes per output
+// feature against 2*M*K flops.
+// -------------------------------------------------------------------------------------------------
+template <int MR>
+__global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [MR][K]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int K4 = g.K >> 2;
+    for (int i = tid; i < MR * K4; i += 256) {
+        const int m = i / K4, c = i - m * K4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < g.M) v = *reinterpret_cast<const float4*>(g.A + (long)m * g.lda + c * 4);
+        reinterpret_cast<float4*>(xs)[i] = v;
+    }
+    __syncthreads();
+
+    constexpr int RPW = 4;  // output features per wave per pass
+    const int n_groups = (g.N + RPW - 1) / RPW;
+    for (int grp = blockIdx.x * 4 + wave; grp < n_groups; grp += gridDim.x * 4) {
+        const int n_base = grp * RPW;
+        float acc[RPW][MR];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int m = 0; m < MR; ++m) acc[r][m] = 0.f;
+        for (int c = lane; c < K4; c += 64) {
+            float4 w[RPW];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int n = min(n_base + r, g.N - 1);
+                w[r] = *reinterpret_cast<const float4*>(g.W + (long)n * g.K + c * 4);
+            }
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                const float4 x = reinterpret_cast<const float4*>(xs)[m * K4 + c];
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    acc[r][m] = fmaf(w[r].x, x.x, acc[r][m]);
+                    acc[r][m] = fmaf(w[r].y, x.y, acc[r][m]);
+                    acc[r][m] = fmaf(w[r].z, x.z, acc[r][m]);
+                    acc[r][m] = fmaf(w[r].w, x.w, acc[r][m]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                float v = acc[r][m];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+                acc[r][m] = v;
+            }
+        if (lane < RPW * MR) {
+            const int r = lane / MR, m = lane - r * MR;
+            const int n = n_base + r;
+            if (n < g.N && m < g.M) {
+                float v = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+                    for (int mm = 0; mm < MR; ++mm)
+                        if (rr == r && mm == m) v = acc[rr][mm];
+                if (g.bias) v += g.bias[n];
+                if ((g.flags & kGemmScaleCols) && n < g.scale_cols) v *= g.scale;
+                if (g.flags & kGemmGelu) v = gelu_erf(v);
+                if (g.flags & kGemmResidual) v += g.R[(long)m * g.ldr + n];
+                g.C[(long)m * g.ldc + n] = v;
+            }
+        }
+    }
+}
+
+void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
+    if (g.M <= 0 || g.N <= 0) return;
+    if (!gemv_applicable(g.M, g.K) || g.lda % 4 != 0) throw std::invalid_argument("gemv: unsupported shape");
+    const int mr = gemv_row_bucket(g.M);
+    const int n_groups = (g.N + 3) / 4;
+    int blocks = (n_groups + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    const size_t lds = (size_t)mr * g.K * sizeof(float);
+    KernelScope ks(ctx, tag, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    switch (mr) {
+        case 1: hipLaunchKernelGGL(gemv_f32_kernel<1>, dim3(blocks), dim3(256), lds, ctx.stream, g); break;
+        case 2: hipLaunchKernelGGL(gemv_f32_kernel<2>, dim3(blocks), dim3(256), lds, ctx.stream, g); break;
+        case 4: hipLaunchKernelGGL(gemv_f32_kernel<4>, dim3(blocks), dim3(256), lds, ctx.stream, g); break;
+        default: hipLaunchKernelGGL(gemv_f32_kernel<8>, dim3(blocks), dim3(256), lds, ctx.stream, g); break;
+    }
+    WLK_HIP(hipGetLastError());
+}
+
+}  // namespace wlk

@@ -1,0 +1,254 @@
+// Token selection and AlignAtt read-out - the device half of one decode step's tail:
+//   * logit adjustments (suppression = add -inf, DRY penalty = subtract)       a6
+//   * log_softmax over the vocabulary + top-k                                   a7
+//   * softmax probability of one token (no-speech check)                        a6
+//   * AlignAtt: column mean/std over the windowed attention rows -> z-score of the newest row
+//     -> width-7 median filter (reflect) -> mean over alignment heads -> arg-max over
+//     [0, content_mel_len)                                                      a8
+// Reference: whisper/decoding.py:317-338,427-432; simul_whisper/simul_whisper.py:370-437;
+// whisper/timing.py:19-54.  Everything here is a small HBM/L2-bound reduction; wavefront
+// shuffles do the folding and nothing is copied to the host except k+1 numbers per beam row.
+#include "common.h"
+
+namespace wlk {
+
+__global__ void apply_adjust_kernel(float* logits, int n_vocab, int n_rows, const int* adj_row, const int* adj_ids,
+                                    const float* adj_deltas, int n_adj) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_adj) return;
+    const int id = adj_ids[i];
+    if (id < 0 || id >= n_vocab) return;
+    const float dl = adj_deltas[i];
+    const int r = adj_row[i];
+    if (r >= 0) {
+        if (r < n_rows) logits[(long)r * n_vocab + id] += dl;
+    } else {
+        for (int b = 0; b < n_rows; ++b) logits[(long)b * n_vocab + id] += dl;
+    }
+}
+
+void launch_apply_adjust(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, const int* adj_row,
+                         const int* adj_ids, const float* adj_deltas, int n_adj) {
+    if (n_adj <= 0) return;
+    KernelScope ks(ctx, "sel_adjust");
+    hipLaunchKernelGGL(apply_adjust_kernel, dim3((n_adj + 255) / 256), dim3(256), 0, ctx.stream, logits, n_vocab,
+                       n_rows, adj_row, adj_ids, adj_deltas, n_adj);
+    WLK_HIP(hipGetLastError());
+}
+
+constexpr int kSelThreads = 1024;
+constexpr int kMaxTopK = 8;
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = fmaxf(r, red[w]);
+    return r;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += red[w];
+    return r;
+}
+
+// one workgroup per beam row: log_softmax(x)[i] = (x_i - max) - log(sum exp(x - max)); top-k by
+// k rounds of (value, lowest index) arg-max.
+__global__ __launch_bounds__(kSelThreads) void logsoftmax_topk_kernel(const float* __restrict__ logits,
+                                                                      int n_vocab, int k,
+                                                                      float* __restrict__ top_vals,
+                                                                      int* __restrict__ top_ids) {
+    __shared__ float red[16];
+    __shared__ float cand_v[16];
+    __shared__ int cand_i[16];
+    __shared__ int taken[kMaxTopK];
+    const int tid = threadIdx.x;
+    const float* x = logits + (long)blockIdx.x * n_vocab;
+
+    float mx = -INFINITY;
+    for (int i = tid; i < n_vocab; i += kSelThreads) mx = fmaxf(mx, x[i]);
+    mx = block_max(mx, red);
+    float sum = 0.f;
+    for (int i = tid; i < n_vocab; i += kSelThreads) sum += expf(x[i] - mx);
+    sum = block_sum(sum, red);
+    const float lse = logf(sum);
+
+    for (int round = 0; round < k; ++round) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < n_vocab; i += kSelThreads) {
+            bool skip = false;
+            for (int t = 0; t < round; ++t) skip |= (taken[t] == i);
+            const float v = x[i];
+            if (!skip && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { cand_v[tid >> 6] = bv; cand_i[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < kSelThreads / 64; ++w)
+                if (cand_v[w] > bv || (cand_v[w] == bv && cand_i[w] < bi)) { bv = cand_v[w]; bi = cand_i[w]; }
+            taken[round] = bi;
+            top_ids[blockIdx.x * k + round] = bi;
+            top_vals[blockIdx.x * k + round] = (bv - mx) - lse;
+        }
+        __syncthreads();
+    }
+}
+
+void launch_logsoftmax_topk(const LaunchCtx& ctx, const float* logits, int n_vocab, int n_rows, int k,
+                            float* top_vals, int* top_ids) {
+    if (k < 1 || k > kMaxTopK) throw std::invalid_argument("top-k: k must be in [1, 8]");
+    KernelScope ks(ctx, "sel_logsoftmax_topk");
+    hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(n_rows), dim3(kSelThreads), 0, ctx.stream, logits, n_vocab, k,
+                       top_vals, top_ids);
+    WLK_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(kSelThreads) void token_prob_kernel(const float* __restrict__ logits, int n_vocab,
+                                                                 int token, float* __restrict__ probs) {
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    const float* x = logits + (long)blockIdx.x * n_vocab;
+    float mx = -INFINITY;
+    for (int i = tid; i < n_vocab; i += kSelThreads) mx = fmaxf(mx, x[i]);
+    mx = block_max(mx, red);
+    float sum = 0.f;
+    for (int i = tid; i < n_vocab; i += kSelThreads) sum += expf(x[i] - mx);
+    sum = block_sum(sum, red);
+    if (tid == 0) probs[blockIdx.x] = expf(x[token] - mx) / sum;
+}
+
+void launch_token_prob(const LaunchCtx& ctx, const float* logits, int n_vocab, int n_rows, int token, float* probs) {
+    KernelScope ks(ctx, "sel_token_prob");
+    hipLaunchKernelGGL(token_prob_kernel, dim3(n_rows), dim3(kSelThreads), 0, ctx.stream, logits, n_vocab, token,
+                       probs);
+    WLK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// AlignAtt.  Window rows of alignment head `a`, beam `b` live at ring[(a*n_beam+b)*ring_rows + r]:
+// rows [0, prefill_rows) belong to the first step of this `infer` (as long as it is among the
+// last 16 steps), rows single_base + [0, n_single) are later single-token steps.
+// Step 1 (this kernel): per frame column, mean and population std over the window rows in fp64
+// (torch.std_mean(unbiased=False) accumulates in double on CPU), then the z-score of the newest row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void align_zscore_kernel(AlignArgs a) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const int al = blockIdx.y, b = blockIdx.z;
+    if (f >= a.T) return;
+    const float* base = a.ring + ((long)(al * a.n_beam + b) * a.ring_rows) * a.T + f;
+    const int n = a.prefill_rows + a.n_single;
+    double sum = 0.0;
+    for (int r = 0; r < a.prefill_rows; ++r) sum += (double)base[(long)r * a.T];
+    for (int r = 0; r < a.n_single; ++r) sum += (double)base[(long)(a.single_base + r) * a.T];
+    const double mean = sum / n;
+    double sq = 0.0;
+    for (int r = 0; r < a.prefill_rows; ++r) {
+        const double t = (double)base[(long)r * a.T] - mean;
+        sq += t * t;
+    }
+    for (int r = 0; r < a.n_single; ++r) {
+        const double t = (double)base[(long)(a.single_base + r) * a.T] - mean;
+        sq += t * t;
+    }
+    const float stdv = (float)sqrt(sq / n);
+    const float meanf = (float)mean;
+    const float w = base[(long)a.newest_row * a.T];
+    a.z[((long)b * a.n_align + al) * a.T + f] = (w - meanf) / (stdv + 1e-8f);
+}
+
+__device__ __forceinline__ float median7(float v0, float v1, float v2, float v3, float v4, float v5, float v6) {
+    float v[7] = {v0, v1, v2, v3, v4, v5, v6};
+#pragma unroll
+    for (int i = 1; i < 7; ++i) {
+#pragma unroll
+        for (int j = i; j > 0; --j) {
+            const float lo = fminf(v[j - 1], v[j]);
+            const float hi = fmaxf(v[j - 1], v[j]);
+            v[j - 1] = lo;
+            v[j] = hi;
+        }
+    }
+    return v[3];
+}
+
+// Step 2: one workgroup per beam row - median filter each head's z row (reflect padding over the
+// full T before the content_mel_len cut, timing.py:35), average the heads, first arg-max.
+__global__ __launch_bounds__(256) void align_argmax_kernel(AlignArgs a) {
+    __shared__ float bestv[256];
+    __shared__ int besti[256];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const float* zb = a.z + (long)b * a.n_align * a.T;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int f = tid; f < a.T; f += 256) {
+        float acc = 0.f;
+        for (int al = 0; al < a.n_align; ++al) {
+            const float* z = zb + (long)al * a.T;
+            float v[7];
+#pragma unroll
+            for (int o = -3; o <= 3; ++o) {
+                int idx = f + o;
+                if (idx < 0) idx = -idx;
+                if (idx >= a.T) idx = 2 * (a.T - 1) - idx;
+                v[o + 3] = z[idx];
+            }
+            acc += a.T > 3 ? median7(v[0], v[1], v[2], v[3], v[4], v[5], v[6]) : z[f];
+        }
+        const float m = acc / (float)a.n_align;
+        a.attn_last[(long)b * a.T + f] = m;
+        if (f < a.content_len && (m > bv || (m == bv && f < bi))) { bv = m; bi = f; }
+    }
+    bestv[tid] = bv;
+    besti[tid] = bi;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (tid < s) {
+            const float ov = bestv[tid + s];
+            const int oi = besti[tid + s];
+            if (ov > bestv[tid] || (ov == bestv[tid] && oi < besti[tid])) { bestv[tid] = ov; besti[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) a.frames[b] = besti[0] == 0x7fffffff ? 0 : besti[0];
+}
+
+void launch_alignatt(const LaunchCtx& ctx, const AlignArgs& a) {
+    if (a.n_align <= 0) {
+        WLK_HIP(hipMemsetAsync(a.frames, 0, sizeof(int) * a.n_beam, ctx.stream));
+        WLK_HIP(hipMemsetAsync(a.attn_last, 0, sizeof(float) * a.n_beam * a.T, ctx.stream));
+        return;
+    }
+    {
+        KernelScope ks(ctx, "align_zscore");
+        hipLaunchKernelGGL(align_zscore_kernel, dim3((a.T + 255) / 256, a.n_align, a.n_beam), dim3(256), 0,
+                           ctx.stream, a);
+        WLK_HIP(hipGetLastError());
+    }
+    {
+        KernelScope ks(ctx, "align_argmax");
+        hipLaunchKernelGGL(align_argmax_kernel, dim3(a.n_beam), dim3(256), 0, ctx.stream, a);
+        WLK_HIP(hipGetLastError());
+    }
+}
+
+}  // namespace wlk
