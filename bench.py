@@ -38,8 +38,9 @@ PEAK_HBM_GBPS = 8000.0
 KERNEL_OF_TAG = {
     "enc_conv1": "gemm_nt_f32_kernel", "enc_conv2": "gemm_nt_f32_kernel", "enc_qkv": "gemm_nt_f32_kernel",
     "enc_out": "gemm_nt_f32_kernel", "enc_fc1": "gemm_nt_f32_kernel", "enc_fc2": "gemm_nt_f32_kernel",
-    "dec_cross_kv": "gemm_nt_f32_kernel", "enc_attention": "encoder_attention_kernel",
+    "dec_cross_kv": "gemm_nt_f32_kernel", "enc_attention": "flash_attention_kernel",
     "dec_cross_attention": "decoder_cross_attention_kernel",
+    "dec_cross_attention_prefill": "flash_attention_kernel",
 }
 
 
@@ -51,10 +52,20 @@ def parse_args():
     ap.add_argument("--model", default="base.en")
     ap.add_argument("--streams-per-gpu", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=STREAM_SECONDS)
-    ap.add_argument("--cpu-chunks", type=int, default=12, help="chunks of the stream the CPU baseline replays")
+    ap.add_argument("--cpu-chunks", type=int, default=24, help="max chunks of the stream the CPU baseline replays")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-work budget of the baseline leg")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads for the baseline (0 = torch default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--audio", default="speech", choices=["speech", "noise"])
     return ap.parse_args()
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    if int(os.environ.get("RANK", 0)) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def make_audio(kind, seconds, seed):
@@ -133,8 +144,10 @@ def main():
         with cf.ThreadPoolExecutor(n_local) as ex:      # sessions are independent: one host thread each
             return list(ex.map(lambda pa: run_stream(*pa), zip(step_procs, audios)))
 
+    log(f"model + {total_steps * n_local} sessions ready")
     for w in range(args.warmup):
         one_step(procs[w])
+        log(f"warmup step {w} done")
     barrier()
     t0 = time.perf_counter()
     records = []
@@ -142,6 +155,7 @@ def main():
         records.append(one_step(procs[args.warmup + k]))
     barrier()
     elapsed = time.perf_counter() - t0
+    log(f"{args.steps} timed step(s): {elapsed:.3f} s")
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -159,6 +173,7 @@ def main():
     prof_proc.model.session.prof_begin()
     run_stream(prof_proc, audios[0])
     prof = prof_proc.model.session.prof_end(cap=64)
+    log("profiled replay done")
     by_kernel = {}
     for tag, r in prof.items():
         kname = KERNEL_OF_TAG.get(tag, tag)
@@ -167,7 +182,7 @@ def main():
             k[f] += r[f]
     dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
     gpu_ms = sum(k["ms"] for k in by_kernel.values())
-    if dom["flops"] > 0 and dom_name in ("gemm_nt_f32_kernel", "encoder_attention_kernel"):
+    if dom["flops"] > 0 and dom_name in ("gemm_nt_f32_kernel", "flash_attention_kernel"):
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         roof = dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS,
                     unit="TFLOP/s", frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None)
@@ -178,6 +193,9 @@ def main():
     roof.update(avg_launch_us=round(1e3 * dom["ms"] / max(dom["launches"], 1), 2), launches=dom["launches"],
                 share_of_gpu_time=round(dom["ms"] / gpu_ms, 3),
                 timing="HIP events around every launch, separate profiled replay of one step")
+    tags = {k: dict(ms=round(v["ms"], 3), launches=v["launches"],
+                    tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] and v["ms"] else None)
+            for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
     kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"],
                        tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 3) if v["flops"] and v["ms"] else None,
                        gbps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] and v["ms"] else None)
@@ -189,18 +207,21 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle import whisper_oracle as wo
         import helpers
-        torch.set_num_threads(os.cpu_count() or 1)
+        if args.cpu_threads > 0:
+            torch.set_num_threads(args.cpu_threads)
         sess = wo.OracleAlignAtt(wo.to_torch_state_dict(synth.synth_state_dict(dims, 0)), dims, heads,
-                                 prof_proc.model.tokenizer, helpers.mel_filterbank(dims.n_mels),
+                                 prof_proc.model.tokenizer, np.array(helpers.mel_filterbank(dims.n_mels)),
                                  wo.OracleConfig())
         oproc = wo.OracleOnlineProcessor(sess)
-        n = min(args.cpu_chunks, len(audios[0]) // CHUNK)
-        t_cpu = 0.0
-        for i in range(n):
-            oproc.insert_audio_chunk(audios[0][i * CHUNK:(i + 1) * CHUNK], (i + 1) * 0.5)
+        n_max = min(args.cpu_chunks, len(audios[0]) // CHUNK)
+        t_cpu, n = 0.0, 0
+        while n < n_max and t_cpu < args.cpu_seconds:
+            oproc.insert_audio_chunk(audios[0][n * CHUNK:(n + 1) * CHUNK], (n + 1) * 0.5)
             a = time.perf_counter()
             oproc.process_iter()
             t_cpu += time.perf_counter() - a
+            n += 1
+            log(f"cpu baseline chunk {n}: {t_cpu:.1f} s so far")
         cpu = dict(value=round(n * 0.5 / t_cpu, 4), unit="audio_s/s", cores=torch.get_num_threads(), kind="port",
                    rtf=round(t_cpu / (n * 0.5), 4),
                    sample=f"first {n} chunks ({n * 0.5:.1f} s) of the same {args.model} stream, "
@@ -238,6 +259,7 @@ def main():
             "roofline": roof,
             "gpu_kernel_ms_per_step": round(gpu_ms, 2),
             "kernels": kernels,
+            "launch_tags": tags,
             "cpu_baseline": cpu,
             "host_cores": os.cpu_count(),
         }

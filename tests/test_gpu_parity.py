@@ -316,8 +316,9 @@ def test_stream_matches_reference_golden(case):
                 if rs.get("token") is not None and "token" in st:
                     total += 1
                     agree += int(st["token"] == rs["token"] and st.get("frame") == rs["frame"])
+        diverged = check_stream_against_golden(g, proc.trace, got, tol=1e-3, allow_ties=True)
         report(f"stream_{case}", decode_steps=n_steps, compared=total, agree=agree,
+               tie_divergence=list(diverged) if diverged else None,
                last_error=repr(getattr(proc, "last_error", None)))
-        check_stream_against_golden(g, proc.trace, got, tol=1e-3)
     finally:
         proc.close()

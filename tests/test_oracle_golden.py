@@ -79,28 +79,47 @@ def replay_stream(case, make_processor):
     return g, proc, got
 
 
-def check_stream_against_golden(g, trace, got, tol=1e-4):
-    """trace: list of per-infer dicts with content_mel_len / prefill_tokens / steps / hypothesis."""
-    assert len(trace) == len(g["calls"])
-    for rec, ref in zip(trace, g["calls"]):
+TIE_EPS = 2e-5   # a reference decision whose winning margin is below this is a tie in fp32
+
+
+def check_stream_against_golden(g, trace, got, tol=1e-4, allow_ties=False):
+    """trace: list of per-infer dicts with content_mel_len / prefill_tokens / steps / hypothesis.
+
+    Bit-exact comparison of every decision (token id, completed flag, attended frame) and of the
+    emitted words.  With ``allow_ties`` (GPU runs) a mismatch is accepted ONLY if the reference's
+    own winning margin for that decision (top-2 AlignAtt values for a frame, top-2 log-probs for a
+    token) is below TIE_EPS - the "near-tie" case SURVEY.md section 7 warns about; the stream then
+    legitimately takes a different path, so comparison stops there and the divergence point is
+    returned as (call index, step index, kind)."""
+    for ci, (rec, ref) in enumerate(zip(trace, g["calls"])):
         assert rec["content_mel_len"] == ref["content_mel_len"]
-        assert len(rec["steps"]) == len(ref["steps"])
         if ref["steps"] and ref["steps"][0]["fed_tokens"] is not None:
             assert rec["prefill_tokens"] == ref["steps"][0]["fed_tokens"]
-        for st, rs in zip(rec["steps"], ref["steps"]):
+        for si, (st, rs) in enumerate(zip(rec["steps"], ref["steps"])):
             assert st["fed"] == rs["fed"]
             if "no_speech_prob" in rs and rs["no_speech_prob"] is not None:
                 assert abs(st["no_speech_prob"] - rs["no_speech_prob"]) <= 1e-6
-            if rs.get("token") is not None:
-                assert st["token"] == rs["token"]
-                assert st["completed"] == rs["completed"]
-                assert st["frame"] == rs["frame"]
-                assert abs(st["sum_logprob"] - rs["sum_logprobs"][0]) <= tol
+            if rs.get("token") is None:
+                continue
+            if st["token"] != rs["token"]:
+                margin = rs["lp_top_vals"][0] - rs["lp_top_vals"][1]
+                assert allow_ties and margin < TIE_EPS, f"token mismatch at call {ci} step {si}, margin {margin}"
+                return (ci, si, "token-tie")
+            assert st["completed"] == rs["completed"]
+            if st["frame"] != rs["frame"]:
+                vals = rs["attn_top_vals"]
+                margin = vals[0] - vals[1] if len(vals) > 1 else 1.0
+                assert allow_ties and margin < TIE_EPS, f"frame mismatch at call {ci} step {si}, margin {margin}"
+                return (ci, si, "frame-tie")
+            assert abs(st["sum_logprob"] - rs["sum_logprobs"][0]) <= tol
+        assert len(rec["steps"]) == len(ref["steps"])
+    assert len(trace) == len(g["calls"])
     for ev, toks, upto in got:
         want = ev["tokens"]
         assert [(round(t.start, 2), round(t.end, 2), t.text, t.speaker) for t in toks] == \
                [(round(s, 2), round(e, 2), x, sp) for s, e, x, sp in want]
         assert abs(upto - ev["upto"]) < 1e-9
+    return None
 
 
 @pytest.mark.parametrize("case", STREAMS)

@@ -163,6 +163,8 @@ struct wlk_model {
     int* filt_lo = nullptr;           // [n_mels]
     int* filt_hi = nullptr;
     int* head_rank = nullptr;         // [L][H] alignment rank or -1
+    int* layer_ranks = nullptr;       // [L][H] ranks of each layer's alignment heads, compacted
+    std::vector<int> layer_rank_count;
     std::vector<int> align_pairs;     // (layer, head)*
     int n_align = 0;
     bool finalized = false;
@@ -339,6 +341,8 @@ int wlk_model_create(const wlk_dims* dims, int device, float* arena_dev, wlk_mod
         m->filt_lo = dev_alloc<int>(dims->n_mels);
         m->filt_hi = dev_alloc<int>(dims->n_mels);
         m->head_rank = dev_alloc<int>((size_t)dims->n_text_layer * dims->n_text_head);
+        m->layer_ranks = dev_alloc<int>((size_t)dims->n_text_layer * dims->n_text_head);
+        m->layer_rank_count.assign(dims->n_text_layer, 0);
         std::vector<int> none((size_t)dims->n_text_layer * dims->n_text_head, -1);
         WLK_HIP(hipMemcpy(m->head_rank, none.data(), none.size() * sizeof(int), hipMemcpyHostToDevice));
         *out = m.release();
@@ -379,6 +383,10 @@ int wlk_model_set_alignment_heads(wlk_model* m, const int32_t* pairs, int n_pair
         }
         WLK_HIP(hipSetDevice(m->device));
         WLK_HIP(hipMemcpy(m->head_rank, rank.data(), rank.size() * sizeof(int), hipMemcpyHostToDevice));
+        std::vector<int> compact((size_t)L * H, -1);
+        m->layer_rank_count.assign(L, 0);
+        for (int i = 0; i < n_pairs; ++i) compact[(size_t)pairs[2 * i] * H + m->layer_rank_count[pairs[2 * i]]++] = i;
+        WLK_HIP(hipMemcpy(m->layer_ranks, compact.data(), compact.size() * sizeof(int), hipMemcpyHostToDevice));
         m->align_pairs.assign(pairs, pairs + 2 * n_pairs);
         m->n_align = n_pairs;
         return WLK_OK;
@@ -421,6 +429,7 @@ int wlk_model_destroy(wlk_model* m) {
     (void)hipFree(m->filt_lo);
     (void)hipFree(m->filt_hi);
     (void)hipFree(m->head_rank);
+    (void)hipFree(m->layer_ranks);
     delete m;
     return WLK_OK;
 }
@@ -746,21 +755,35 @@ int wlk_decode(wlk_session* s, const int64_t* tokens, int n_rows, int n_tok, int
             q.A = s->dh; q.lda = d; q.W = L.xqw; q.bias = L.xqb; q.C = s->dq; q.ldc = d; q.M = R; q.N = d; q.K = d;
             q.flags = kGemmScaleCols; q.scale = scale; q.scale_cols = d;
             launch_linear(c, q, "dec_xq");
-            CrossAttnArgs ca;
-            ca.q = s->dq;
-            ca.k = s->cross_kv + (size_t)i * T * 2 * d;
-            ca.v = ca.k + d;
-            ca.ldkv = 2 * d;
-            ca.out = s->datt;
-            ca.rows = R; ca.d = d; ca.n_head = H; ca.T = T;
-            ca.head_rank = m->n_align > 0 ? m->head_rank + (size_t)i * H : nullptr;
-            ca.ring = s->ring;
-            ca.ring_row = s->ring_row;
-            ca.beam_of_row = s->beam_of_row;
-            ca.ring_rows = s->ring_rows;
-            ca.n_beam = s->beam;
-            ca.qk_debug = s->debug ? s->qk_debug + (size_t)i * s->max_rows * H * T : nullptr;
-            launch_decoder_cross_attention(c, ca);
+            const int* ranks_l = m->n_align > 0 ? m->head_rank + (size_t)i * H : nullptr;
+            if (R > 8 && !s->debug) {
+                // prefill: MFMA flash kernel shares every K/V tile between 32 query rows
+                FlashArgs fa;
+                fa.q = s->dq; fa.ldq = d;
+                fa.k = s->cross_kv + (size_t)i * T * 2 * d; fa.v = fa.k + d; fa.ldkv = 2 * d;
+                fa.out = s->datt; fa.ldo = d; fa.Tq = R; fa.Tk = T; fa.n_head = H;
+                fa.head_rank = ranks_l; fa.ring = s->ring; fa.ring_row = s->ring_row;
+                fa.beam_of_row = s->beam_of_row; fa.ring_rows = s->ring_rows; fa.n_beam = s->beam;
+                launch_prefill_cross_attention(c, fa);
+                launch_ring_softmax(c, s->ring, s->ring_row, s->beam_of_row, m->layer_ranks + (size_t)i * H,
+                                    m->layer_rank_count[i], R, s->ring_rows, s->beam, T);
+            } else {
+                CrossAttnArgs ca;
+                ca.q = s->dq;
+                ca.k = s->cross_kv + (size_t)i * T * 2 * d;
+                ca.v = ca.k + d;
+                ca.ldkv = 2 * d;
+                ca.out = s->datt;
+                ca.rows = R; ca.d = d; ca.n_head = H; ca.T = T;
+                ca.head_rank = ranks_l;
+                ca.ring = s->ring;
+                ca.ring_row = s->ring_row;
+                ca.beam_of_row = s->beam_of_row;
+                ca.ring_rows = s->ring_rows;
+                ca.n_beam = s->beam;
+                ca.qk_debug = s->debug ? s->qk_debug + (size_t)i * s->max_rows * H * T : nullptr;
+                launch_decoder_cross_attention(c, ca);
+            }
             GemmArgs xo;
             xo.A = s->datt; xo.lda = d; xo.W = L.xoutw; xo.bias = L.xoutb; xo.C = s->dx; xo.ldc = d; xo.M = R; xo.N = d;
             xo.K = d; xo.flags = kGemmResidual; xo.R = s->dx; xo.ldr = d;

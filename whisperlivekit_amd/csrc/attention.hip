@@ -28,10 +28,15 @@ constexpr int QT = 32, KT = 32, NWAVE = 4, K_LD = 68, O_LD = 65;
 constexpr int kAttnLdsFloats = NWAVE * KT * K_LD + NWAVE * KT * 64;  // K tiles + V tiles
 constexpr int kAttnLdsTotal = kAttnLdsFloats + QT * K_LD;            // + Q tile
 
-__global__ __launch_bounds__(256) void encoder_attention_kernel(const float* __restrict__ qkv,
-                                                                float* __restrict__ out, int T, int d,
-                                                                int n_head) {
+// One kernel serves the encoder (q, k, v interleaved in one [T][3d] buffer) and the decoder's
+// PREFILL cross-attention (q rows = all fed tokens of all beams, k/v = the 1500 projected encoder
+// positions).  For the latter, heads that are AlignAtt alignment heads also dump their raw scores
+// into the session's alignment window (softmaxed in place afterwards by ring_softmax_kernel), so
+// the [H, q, 1500] QK tensor of the reference is never formed for the other heads.
+__global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int T = a.Tk;
+    const int n_head = a.n_head;
     float* Ks = lds;                            // [NWAVE][KT][K_LD]
     float* Vs = lds + NWAVE * KT * K_LD;        // [NWAVE][KT][64]
 
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const float* __r
     const int wave = tid >> 6;
     const int head = blockIdx.x % n_head;       // head == XCD for 8 heads: K/V of a head stay in one L2
     const int q0 = (blockIdx.x / n_head) * QT;
-    const long ld = 3L * d;
+    const long ld = a.ldkv;
     const int half = lane >> 5;
     const int lq = lane & 31;
 
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const float* __r
     for (int i = tid; i < QT * 16; i += 256) {
         const int qr = i >> 4, c4 = i & 15;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q0 + qr < T) v = *reinterpret_cast<const float4*>(qkv + (long)(q0 + qr) * ld + head * 64 + c4 * 4);
+        if (q0 + qr < a.Tq) v = *reinterpret_cast<const float4*>(a.q + (long)(q0 + qr) * a.ldq + head * 64 + c4 * 4);
         *reinterpret_cast<float4*>(&Qs[qr * K_LD + c4 * 4]) = v;
     }
     const float* Qw = Qs + lq * K_LD + half * 4;
@@ -61,8 +66,15 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const float* __r
     float m_run = -INFINITY, l_run = 0.f;
 
     // staging map: per iteration 128 keys x 64 floats for K and for V = 2048 float4 each, 8 per thread
-    const float* kbase = qkv + d + head * 64;
-    const float* vbase = qkv + 2 * d + head * 64;
+    const float* kbase = a.k + head * 64;
+    const float* vbase = a.v + head * 64;
+    // alignment-head score dump (decoder prefill only)
+    const int rank = a.head_rank ? a.head_rank[head] : -1;
+    float* dump = nullptr;
+    if (rank >= 0 && q0 + lq < a.Tq) {
+        const int row = q0 + lq;
+        dump = a.ring + (((long)rank * a.n_beam + a.beam_of_row[row]) * a.ring_rows + a.ring_row[row]) * (long)T;
+    }
     float4 rk[8], rv[8];
     auto fetch = [&](int it) {
 #pragma unroll
@@ -115,6 +127,14 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const float* __r
                 s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, q4.w, s, 0, 0, 0);
             }
             // rows of s: key = key0 + (r&3) + 8*(r>>2) + 4*half ; column: query lq
+            if (dump) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int key = key0 + 8 * g + 4 * half;
+                    if (key < T)   // T % 4 == 0 is checked by the launcher when dumping
+                        *reinterpret_cast<float4*>(dump + key) = make_float4(s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]);
+                }
+            }
             float mt = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -180,24 +200,75 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const float* __r
                 L += e * Ls[w * QT + q];
                 acc += e * Os[(w * QT + q) * O_LD + dd];
             }
-            if (qrow < T) out[(long)qrow * d + head * 64 + dd] = acc / L;
+            if (qrow < a.Tq) a.out[(long)qrow * a.ldo + head * 64 + dd] = acc / L;
         }
     }
 }
 
-void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out, int T, int d, int n_head) {
-    static bool attr_set = false;
+static void launch_flash(const LaunchCtx& ctx, const FlashArgs& a, const char* tag) {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    WLK_HIP(hipGetDevice(&dev));
     const size_t lds = kAttnLdsTotal * sizeof(float);
-    if (!attr_set) {
-        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(encoder_attention_kernel),
+    if (dev < 64 && !attr_set[dev]) {
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attention_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dev] = true;
     }
-    const int q_tiles = (T + QT - 1) / QT;
-    // QK^T and PV: 2 * T*T*64 MACs per head each; reads q,k,v once, writes out
-    KernelScope ks(ctx, "enc_attention", 4.0 * T * (double)T * d, 4.0 * 4.0 * T * d);
-    hipLaunchKernelGGL(encoder_attention_kernel, dim3(q_tiles * n_head), dim3(256), lds, ctx.stream, qkv, out, T,
-                       d, n_head);
+    if (a.head_rank && a.Tk % 4 != 0) throw std::invalid_argument("flash attention: score dump needs Tk % 4 == 0");
+    const int q_tiles = (a.Tq + QT - 1) / QT;
+    // QK^T and PV: 2 * Tq*Tk*64 MACs per head each; reads q,k,v once, writes out
+    KernelScope ks(ctx, tag, 4.0 * a.Tq * (double)a.Tk * 64.0 * a.n_head,
+                   4.0 * 64.0 * a.n_head * (2.0 * a.Tq + 2.0 * a.Tk));
+    hipLaunchKernelGGL(flash_attention_kernel, dim3(q_tiles * a.n_head), dim3(256), lds, ctx.stream, a);
+    WLK_HIP(hipGetLastError());
+}
+
+void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out, int T, int d, int n_head) {
+    FlashArgs a;
+    a.q = qkv; a.ldq = 3L * d; a.k = qkv + d; a.v = qkv + 2 * d; a.ldkv = 3L * d; a.out = out; a.ldo = d;
+    a.Tq = T; a.Tk = T; a.n_head = n_head;
+    launch_flash(ctx, a, "enc_attention");
+}
+
+void launch_prefill_cross_attention(const LaunchCtx& ctx, const FlashArgs& a) { launch_flash(ctx, a, "dec_cross_attention_prefill"); }
+
+// in-place softmax of the raw alignment-head scores the prefill dumped: one workgroup per
+// (query row, alignment rank) - exactly F.softmax(qk, dim=-1) of simul_whisper.py:411
+__global__ __launch_bounds__(256) void ring_softmax_kernel(float* ring, const int* ring_row, const int* beam_of_row,
+                                                           const int* ranks, int ring_rows, int n_beam, int T) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x;
+    const int rank = ranks[blockIdx.y];
+    float* x = ring + (((long)rank * n_beam + beam_of_row[row]) * ring_rows + ring_row[row]) * (long)T;
+    float mx = -INFINITY;
+    for (int j = tid; j < T; j += 256) mx = fmaxf(mx, x[j]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < T; j += 256) {
+        const float e = expf(x[j] - mx);
+        x[j] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    for (int j = tid; j < T; j += 256) x[j] = x[j] / sum;
+}
+
+void launch_ring_softmax(const LaunchCtx& ctx, float* ring, const int* ring_row, const int* beam_of_row,
+                         const int* ranks_dev, int n_ranks, int rows, int ring_rows, int n_beam, int T) {
+    if (n_ranks <= 0 || rows <= 0) return;
+    KernelScope ks(ctx, "align_ring_softmax", 0.0, 4.0 * 2.0 * rows * (double)n_ranks * T);
+    hipLaunchKernelGGL(ring_softmax_kernel, dim3(rows, n_ranks), dim3(256), 0, ctx.stream, ring, ring_row,
+                       beam_of_row, ranks_dev, ring_rows, n_beam, T);
     WLK_HIP(hipGetLastError());
 }
 

@@ -104,8 +104,24 @@ struct MelArgs {
 void launch_mel(const LaunchCtx& ctx, const MelArgs& a);
 
 // ---- attention.hip --------------------------------------------------------------------------
-// encoder self-attention over qkv[T][3d] (q and k pre-scaled), out[T][d]; flash-style, fp32 MFMA
+// flash-style fp32-MFMA attention: q rows [Tq] against k/v rows [Tk], 64-wide heads, no mask
+struct FlashArgs {
+    const float* q = nullptr; long ldq = 0;      // query row r, head h at q + r*ldq + 64h (pre-scaled)
+    const float* k = nullptr; const float* v = nullptr; long ldkv = 0;  // key t at k + t*ldkv + 64h (pre-scaled)
+    float* out = nullptr; long ldo = 0;
+    int Tq = 0, Tk = 0, n_head = 0;
+    // decoder prefill only: raw scores of alignment heads go to the alignment window
+    const int* head_rank = nullptr;              // [n_head] rank or -1
+    float* ring = nullptr;
+    const int* ring_row = nullptr;               // [Tq]
+    const int* beam_of_row = nullptr;            // [Tq]
+    int ring_rows = 0, n_beam = 1;
+};
+// encoder self-attention over qkv[T][3d] (q and k pre-scaled), out[T][d]
 void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out, int T, int d, int n_head);
+void launch_prefill_cross_attention(const LaunchCtx& ctx, const FlashArgs& a);
+void launch_ring_softmax(const LaunchCtx& ctx, float* ring, const int* ring_row, const int* beam_of_row,
+                         const int* ranks_dev, int n_ranks, int rows, int ring_rows, int n_beam, int T);
 
 // ---- decoder.hip ----------------------------------------------------------------------------
 void launch_embed(const LaunchCtx& ctx, const int* tokens, const float* tok_emb, const float* pos_emb,
