@@ -322,3 +322,14 @@ def test_stream_matches_reference_golden(case):
                last_error=repr(getattr(proc, "last_error", None)))
     finally:
         proc.close()
+
+
+def test_stream_without_hipgraph_matches_too(monkeypatch):
+    """Same golden stream with graph replay disabled (WLK_NO_GRAPH=1): the eager launch sequence and
+    the captured one must be the same arithmetic."""
+    monkeypatch.setenv("WLK_NO_GRAPH", "1")
+    g, proc, got = replay_stream("micro_12s", make_hip_processor)
+    try:
+        assert check_stream_against_golden(g, proc.trace, got, tol=1e-3, allow_ties=True) is None
+    finally:
+        proc.close()

@@ -2,6 +2,7 @@
 // sequences for encode / decode / select.  Host-side orchestration only; the arithmetic lives in
 // the kernel files next to this one.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -148,6 +149,12 @@ static int check_dims(const wlk_dims* d) {
 
 using namespace wlk;
 
+struct LayerW {
+    const float *ln1w, *ln1b, *qkvw, *qkvb, *outw, *outb, *ln2w, *ln2b, *fc1w, *fc1b, *fc2w, *fc2b;
+    const float *lnxw = nullptr, *lnxb = nullptr, *xqw = nullptr, *xqb = nullptr, *xkvw = nullptr, *xkvb = nullptr,
+                *xoutw = nullptr, *xoutb = nullptr;
+};
+
 // ------------------------------------------------------------------------------------------------
 // model
 // ------------------------------------------------------------------------------------------------
@@ -168,18 +175,14 @@ struct wlk_model {
     std::vector<int> align_pairs;     // (layer, head)*
     int n_align = 0;
     bool finalized = false;
+    std::vector<LayerW> enc_layers, dec_layers;   // resolved once at finalize
+    const float *w_tok_emb = nullptr, *w_dec_pos = nullptr, *w_ln_w = nullptr, *w_ln_b = nullptr;
 
     const float* w(const std::string& name) const {
         auto it = by_name.find(name);
         if (it == by_name.end()) throw std::invalid_argument("unknown tensor " + name);
         return arena + it->second->offset;
     }
-};
-
-struct LayerW {
-    const float *ln1w, *ln1b, *qkvw, *qkvb, *outw, *outb, *ln2w, *ln2b, *fc1w, *fc1b, *fc2w, *fc2b;
-    const float *lnxw = nullptr, *lnxb = nullptr, *xqw = nullptr, *xqb = nullptr, *xkvw = nullptr, *xkvb = nullptr,
-                *xoutw = nullptr, *xoutb = nullptr;
 };
 
 static LayerW layer_weights(const wlk_model* m, const char* side, int i, bool cross) {
@@ -211,6 +214,8 @@ struct wlk_session {
     Profiler prof;
     bool prof_on = false;
     bool debug = false;
+    bool use_graph = true;
+    hipGraphExec_t step_exec[2] = {nullptr, nullptr};   // single-token decode step, per KV buffer
 
     // audio (two buffers: eviction copies the tail into the other one)
     float* audio[2] = {nullptr, nullptr};
@@ -238,7 +243,7 @@ struct wlk_session {
     int last_rows = 0, last_ntok = 0;
     float *hsel = nullptr, *logits_last = nullptr, *logits_sot = nullptr;
     bool have_sot = false;
-    int *ring_row = nullptr, *beam_of_row = nullptr;
+    int *ring_row = nullptr, *beam_of_row = nullptr, *d_offset = nullptr;
     float* ring = nullptr;
     int ring_rows = 0;
     float *z = nullptr, *attn_last = nullptr;
@@ -248,6 +253,7 @@ struct wlk_session {
     int *adj_row = nullptr, *adj_ids = nullptr, *src_rows = nullptr;
     float* adj_deltas = nullptr;
     float* top_vals = nullptr;
+    void* topk_scratch = nullptr;
     int *top_ids = nullptr, *frames = nullptr;
     float* probs = nullptr;
     static constexpr int kAdjCap = 4096;
@@ -416,6 +422,14 @@ int wlk_model_finalize(wlk_model* m) {
         }
         WLK_HIP(hipMemcpy(m->filt_lo, lo.data(), nm * sizeof(int), hipMemcpyHostToDevice));
         WLK_HIP(hipMemcpy(m->filt_hi, hi.data(), nm * sizeof(int), hipMemcpyHostToDevice));
+        m->enc_layers.clear();
+        m->dec_layers.clear();
+        for (int i = 0; i < m->D.n_audio_layer; ++i) m->enc_layers.push_back(layer_weights(m, "enc", i, false));
+        for (int i = 0; i < m->D.n_text_layer; ++i) m->dec_layers.push_back(layer_weights(m, "dec", i, true));
+        m->w_tok_emb = m->w("dec.tok_emb");
+        m->w_dec_pos = m->w("dec.pos");
+        m->w_ln_w = m->w("dec.ln.w");
+        m->w_ln_b = m->w("dec.ln.b");
         m->finalized = true;
         return WLK_OK;
     });
@@ -424,7 +438,7 @@ int wlk_model_finalize(wlk_model* m) {
 int wlk_model_destroy(wlk_model* m) {
     if (!m) return WLK_OK;
     (void)hipSetDevice(m->device);
-    if (m->owns_arena) hipFree(m->arena);
+    if (m->owns_arena) (void)hipFree(m->arena);
     (void)hipFree(m->twiddle);
     (void)hipFree(m->filt_lo);
     (void)hipFree(m->filt_hi);
@@ -447,6 +461,7 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         s->beam = beam;
         s->audio_cap = max_audio_samples;
         WLK_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        if (const char* e = std::getenv("WLK_NO_GRAPH")) s->use_graph = !(e[0] == '1');
         hipStream_t st = s->stream;
         const wlk_dims& D = m->D;
         const size_t d = D.n_audio_state, T = D.n_audio_ctx, ctx = D.n_text_ctx, V = D.n_vocab;
@@ -482,6 +497,7 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         s->logits_sot = dev_alloc<float>((size_t)beam * V);
         s->ring_row = dev_alloc<int>(R);
         s->beam_of_row = dev_alloc<int>(R);
+        s->d_offset = dev_alloc<int>(4);
         s->ring_rows = (int)ctx + kAlignWindow;
         if (m->n_align > 0) s->ring = dev_alloc<float>((size_t)m->n_align * beam * s->ring_rows * T);
         s->z = dev_alloc<float>((size_t)beam * std::max(m->n_align, 1) * T);
@@ -491,6 +507,7 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         s->adj_deltas = dev_alloc<float>(wlk_session::kAdjCap);
         s->src_rows = dev_alloc<int>(8);
         s->top_vals = dev_alloc<float>((size_t)beam * 8);
+        WLK_HIP(hipMalloc(&s->topk_scratch, topk_scratch_bytes(beam)));
         s->top_ids = dev_alloc<int>((size_t)beam * 8);
         s->frames = dev_alloc<int>(beam);
         s->probs = dev_alloc<float>(beam);
@@ -511,9 +528,12 @@ int wlk_session_destroy(wlk_session* s) {
                    s->ring, s->z, s->attn_last, s->qk_debug, s->adj_deltas, s->top_vals, s->probs};
     for (float* p : fl)
         if (p) (void)hipFree(p);
-    int* il[] = {s->tokens_dev, s->ring_row, s->beam_of_row, s->adj_row, s->adj_ids, s->src_rows, s->top_ids, s->frames};
+    int* il[] = {s->d_offset, s->tokens_dev, s->ring_row, s->beam_of_row, s->adj_row, s->adj_ids, s->src_rows, s->top_ids, s->frames};
     for (int* p : il)
         if (p) (void)hipFree(p);
+    for (auto& e : s->step_exec)
+        if (e) (void)hipGraphExecDestroy(e);
+    if (s->topk_scratch) (void)hipFree(s->topk_scratch);
     if (s->pinned) (void)hipHostFree(s->pinned);
     for (auto& r : s->prof.recs) {
         (void)hipEventDestroy(r.a);
@@ -608,12 +628,18 @@ int wlk_audio_len(wlk_session* s, int* n) {
 
 // ---- encode ---------------------------------------------------------------------------------
 static void transformer_mlp(const LaunchCtx& c, const LayerW& L, float* x, float* h, float* mlp, int rows, int d,
-                            const char* t_ln, const char* t_fc1, const char* t_fc2) {
-    launch_layernorm(c, x, d, L.ln2w, L.ln2b, h, d, rows, d, t_ln);
+                            const char* t_ln, const char* t_fc1, const char* t_fc2, bool fuse_ln = false) {
     GemmArgs g;
-    g.A = h; g.lda = d; g.W = L.fc1w; g.bias = L.fc1b; g.C = mlp; g.ldc = 4 * d; g.M = rows; g.N = 4 * d; g.K = d;
+    g.lda = d; g.W = L.fc1w; g.bias = L.fc1b; g.C = mlp; g.ldc = 4 * d; g.M = rows; g.N = 4 * d; g.K = d;
     g.flags = kGemmGelu;
-    launch_linear(c, g, t_fc1);
+    if (fuse_ln) {
+        g.A = x; g.ln_gamma = L.ln2w; g.ln_beta = L.ln2b;
+        launch_gemv(c, g, "dec_ln2_fc1");
+    } else {
+        launch_layernorm(c, x, d, L.ln2w, L.ln2b, h, d, rows, d, t_ln);
+        g.A = h;
+        launch_linear(c, g, t_fc1);
+    }
     GemmArgs g2;
     g2.A = mlp; g2.lda = 4 * d; g2.W = L.fc2w; g2.bias = L.fc2b; g2.C = x; g2.ldc = d; g2.M = rows; g2.N = d;
     g2.K = 4 * d; g2.flags = kGemmResidual; g2.R = x; g2.ldr = d;
@@ -658,7 +684,7 @@ int wlk_encode(wlk_session* s, int32_t* content_mel_len) {
         }
         const float scale = std::pow((float)kHeadDim, -0.25f);
         for (int i = 0; i < D.n_audio_layer; ++i) {
-            const LayerW L = layer_weights(m, "enc", i, false);
+            const LayerW& L = m->enc_layers[i];
             launch_layernorm(c, s->ex, d, L.ln1w, L.ln1b, s->eh, d, T, d, "enc_ln1");
             GemmArgs g;
             g.A = s->eh; g.lda = d; g.W = L.qkvw; g.bias = L.qkvb; g.C = s->eqkv; g.ldc = 3 * d; g.M = T; g.N = 3 * d;
@@ -673,7 +699,7 @@ int wlk_encode(wlk_session* s, int32_t* content_mel_len) {
         }
         launch_layernorm(c, s->ex, d, m->w("enc.ln_post.w"), m->w("enc.ln_post.b"), s->enc_out, d, T, d, "enc_ln_post");
         for (int i = 0; i < D.n_text_layer; ++i) {  // cross-attention K (scaled) and V of every decoder layer
-            const LayerW L = layer_weights(m, "dec", i, true);
+            const LayerW& L = m->dec_layers[i];
             GemmArgs g;
             g.A = s->enc_out; g.lda = d; g.W = L.xkvw; g.bias = L.xkvb; g.C = s->cross_kv + (size_t)i * T * 2 * d;
             g.ldc = 2 * d; g.M = T; g.N = 2 * d; g.K = d; g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = d;
@@ -689,6 +715,120 @@ int wlk_encode(wlk_session* s, int32_t* content_mel_len) {
 }
 
 // ---- decode ---------------------------------------------------------------------------------
+// Enqueue one decoder forward on the session stream.  Everything that changes from call to call
+// (tokens, alignment-window row map, cache offset) is read from the pinned staging block through
+// memcpy nodes / device scalars, so the single-token form of this sequence can be captured once
+// into a hipGraph and replayed.
+static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n_tok, bool first, int sot_index) {
+    wlk_model* m = s->m;
+    const wlk_dims& D = m->D;
+    const int ctx_len = D.n_text_ctx;
+    const int R = n_rows * n_tok;
+    const int d = D.n_text_state, T = D.n_audio_ctx, H = D.n_text_head, V = D.n_vocab;
+    const int* stage = static_cast<const int*>(s->pinned);
+    WLK_HIP(hipMemcpyAsync(s->tokens_dev, stage, R * sizeof(int), hipMemcpyHostToDevice, s->stream));
+    WLK_HIP(hipMemcpyAsync(s->ring_row, stage + R, R * sizeof(int), hipMemcpyHostToDevice, s->stream));
+    WLK_HIP(hipMemcpyAsync(s->beam_of_row, stage + 2 * R, R * sizeof(int), hipMemcpyHostToDevice, s->stream));
+    WLK_HIP(hipMemcpyAsync(s->d_offset, stage + 3 * R, sizeof(int), hipMemcpyHostToDevice, s->stream));
+    // decode steps (<= 8 rows): LayerNorm and the KV-cache append are fused into the weight-streaming
+    // GEMV launches; prefill keeps them as separate kernels in front of the MFMA GEMMs
+    const bool fused = gemv_applicable(R, d) && n_tok == 1;
+
+    launch_embed(c, s->tokens_dev, m->w_tok_emb, m->w_dec_pos, s->dx, n_rows, n_tok, s->d_offset, d);
+    const float scale = std::pow((float)kHeadDim, -0.25f);
+    const size_t cache_layer = (size_t)s->beam * ctx_len * d;
+    for (int i = 0; i < D.n_text_layer; ++i) {
+        const LayerW& L = m->dec_layers[i];
+        float* kc = s->kcache[s->kv_cur] + i * cache_layer;
+        float* vc = s->vcache[s->kv_cur] + i * cache_layer;
+        GemmArgs g;
+        g.W = L.qkvw; g.bias = L.qkvb; g.C = s->dqkv; g.ldc = 3 * d; g.M = R; g.N = 3 * d;
+        g.K = d; g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = 2 * d; g.lda = d;
+        if (fused) {
+            g.A = s->dx; g.ln_gamma = L.ln1w; g.ln_beta = L.ln1b;
+            g.kcache = kc; g.vcache = vc; g.kv_pos = s->d_offset; g.kv_d = d; g.kv_ctx = ctx_len;
+            launch_gemv(c, g, "dec_ln1_qkv_kv");
+        } else {
+            launch_layernorm(c, s->dx, d, L.ln1w, L.ln1b, s->dh, d, R, d, "dec_ln1");
+            g.A = s->dh;
+            launch_linear(c, g, "dec_qkv");
+            launch_kv_append(c, s->dqkv, kc, vc, n_rows, n_tok, s->d_offset, d, ctx_len);
+        }
+        launch_decoder_self_attention(c, s->dqkv, kc, vc, s->datt, n_rows, n_tok, s->d_offset, d, H, ctx_len);
+        GemmArgs o;
+        o.A = s->datt; o.lda = d; o.W = L.outw; o.bias = L.outb; o.C = s->dx; o.ldc = d; o.M = R; o.N = d; o.K = d;
+        o.flags = kGemmResidual; o.R = s->dx; o.ldr = d;
+        launch_linear(c, o, "dec_out");
+
+        GemmArgs q;
+        q.lda = d; q.W = L.xqw; q.bias = L.xqb; q.C = s->dq; q.ldc = d; q.M = R; q.N = d; q.K = d;
+        q.flags = kGemmScaleCols; q.scale = scale; q.scale_cols = d;
+        if (fused) {
+            q.A = s->dx; q.ln_gamma = L.lnxw; q.ln_beta = L.lnxb;
+            launch_gemv(c, q, "dec_lnx_xq");
+        } else {
+            launch_layernorm(c, s->dx, d, L.lnxw, L.lnxb, s->dh, d, R, d, "dec_lnx");
+            q.A = s->dh;
+            launch_linear(c, q, "dec_xq");
+        }
+        const int* ranks_l = m->n_align > 0 ? m->head_rank + (size_t)i * H : nullptr;
+        if (R > 8 && !s->debug) {
+            // prefill: MFMA flash kernel shares every K/V tile between 32 query rows
+            FlashArgs fa;
+            fa.q = s->dq; fa.ldq = d;
+            fa.k = s->cross_kv + (size_t)i * T * 2 * d; fa.v = fa.k + d; fa.ldkv = 2 * d;
+            fa.out = s->datt; fa.ldo = d; fa.Tq = R; fa.Tk = T; fa.n_head = H;
+            fa.head_rank = ranks_l; fa.ring = s->ring; fa.ring_row = s->ring_row;
+            fa.beam_of_row = s->beam_of_row; fa.ring_rows = s->ring_rows; fa.n_beam = s->beam;
+            launch_prefill_cross_attention(c, fa);
+            launch_ring_softmax(c, s->ring, s->ring_row, s->beam_of_row, m->layer_ranks + (size_t)i * H,
+                                m->layer_rank_count[i], R, s->ring_rows, s->beam, T);
+        } else {
+            CrossAttnArgs ca;
+            ca.q = s->dq;
+            ca.k = s->cross_kv + (size_t)i * T * 2 * d;
+            ca.v = ca.k + d;
+            ca.ldkv = 2 * d;
+            ca.out = s->datt;
+            ca.rows = R; ca.d = d; ca.n_head = H; ca.T = T;
+            ca.head_rank = ranks_l;
+            ca.ring = s->ring;
+            ca.ring_row = s->ring_row;
+            ca.beam_of_row = s->beam_of_row;
+            ca.ring_rows = s->ring_rows;
+            ca.n_beam = s->beam;
+            ca.qk_debug = s->debug ? s->qk_debug + (size_t)i * s->max_rows * H * T : nullptr;
+            launch_decoder_cross_attention(c, ca);
+        }
+        GemmArgs xo;
+        xo.A = s->datt; xo.lda = d; xo.W = L.xoutw; xo.bias = L.xoutb; xo.C = s->dx; xo.ldc = d; xo.M = R; xo.N = d;
+        xo.K = d; xo.flags = kGemmResidual; xo.R = s->dx; xo.ldr = d;
+        launch_linear(c, xo, "dec_xout");
+        transformer_mlp(c, L, s->dx, s->dh, s->dmlp, R, d, "dec_ln2", "dec_fc1", "dec_fc2", fused);
+    }
+    // final LayerNorm + vocabulary projection only for the rows the policy reads
+    GemmArgs lg;
+    lg.lda = d; lg.W = m->w_tok_emb; lg.C = s->logits_last; lg.ldc = V; lg.M = n_rows; lg.N = V; lg.K = d;
+    if (fused) {   // n_tok == 1: the last row of beam b is row b
+        lg.A = s->dx; lg.ln_gamma = m->w_ln_w; lg.ln_beta = m->w_ln_b;
+        launch_gemv(c, lg, "dec_lnf_logits");
+    } else {
+        launch_layernorm(c, s->dx + (size_t)(n_tok - 1) * d, (long)n_tok * d, m->w_ln_w, m->w_ln_b, s->hsel, d,
+                         n_rows, d, "dec_ln_f");
+        lg.A = s->hsel;
+        launch_linear(c, lg, "dec_logits");
+    }
+    if (first) {
+        float* hs = s->hsel + (size_t)n_rows * d;
+        launch_layernorm(c, s->dx + (size_t)sot_index * d, (long)n_tok * d, m->w_ln_w, m->w_ln_b, hs, d, n_rows, d,
+                         "dec_ln_f");
+        GemmArgs ls = lg;
+        ls.ln_gamma = ls.ln_beta = nullptr;
+        ls.A = hs; ls.C = s->logits_sot;
+        launch_linear(c, ls, "dec_logits");
+    }
+}
+
 int wlk_decode(wlk_session* s, const int64_t* tokens, int n_rows, int n_tok, int first, int sot_index) {
     if (!s || !tokens) return fail(WLK_ERR_ARG, "NULL argument");
     if (!s->encoded) return fail(WLK_ERR_STATE, "wlk_decode before wlk_encode");
@@ -710,101 +850,46 @@ int wlk_decode(wlk_session* s, const int64_t* tokens, int n_rows, int n_tok, int
         const int ctx_len = D.n_text_ctx;
         if (offset + n_tok > ctx_len) return fail(WLK_ERR_CAPACITY, "text context exceeded");
         const int R = n_rows * n_tok;
-        const int d = D.n_text_state, T = D.n_audio_ctx, H = D.n_text_head, V = D.n_vocab;
+        if ((size_t)(R * 3 + 4) * sizeof(int) > wlk_session::kPinnedBytes) return fail(WLK_ERR_CAPACITY, "too many rows");
 
-        // host -> device: tokens (as int32) and the alignment-window row map
-        WLK_HIP(hipStreamSynchronize(s->stream));  // pinned staging is single-entry
+        // staging block (pinned): tokens as int32 | alignment-window row of each query row | beam of row | offset
+        WLK_HIP(hipStreamSynchronize(s->stream));  // the previous call's copies out of this block are done
         int* stage = static_cast<int*>(s->pinned);
-        if ((size_t)R * 3 * sizeof(int) > wlk_session::kPinnedBytes) return fail(WLK_ERR_CAPACITY, "too many rows");
-        int slot_row;
-        if (first) slot_row = 0;
-        else slot_row = ctx_len + ((s->n_steps - 1) % kAlignWindow);
+        const int slot_row = first ? 0 : ctx_len + ((s->n_steps - 1) % kAlignWindow);
         for (int b = 0; b < n_rows; ++b)
             for (int p = 0; p < n_tok; ++p) {
                 const int64_t t = tokens[(size_t)b * n_tok + p];
-                if (t < 0 || t >= V) return fail(WLK_ERR_ARG, "token id out of range");
+                if (t < 0 || t >= D.n_vocab) return fail(WLK_ERR_ARG, "token id out of range");
                 stage[b * n_tok + p] = (int)t;
                 stage[R + b * n_tok + p] = first ? p : slot_row;
                 stage[2 * R + b * n_tok + p] = b;
             }
-        WLK_HIP(hipMemcpyAsync(s->tokens_dev, stage, R * sizeof(int), hipMemcpyHostToDevice, s->stream));
-        WLK_HIP(hipMemcpyAsync(s->ring_row, stage + R, R * sizeof(int), hipMemcpyHostToDevice, s->stream));
-        WLK_HIP(hipMemcpyAsync(s->beam_of_row, stage + 2 * R, R * sizeof(int), hipMemcpyHostToDevice, s->stream));
+        stage[3 * R] = offset;
 
-        launch_embed(c, s->tokens_dev, m->w("dec.tok_emb"), m->w("dec.pos"), s->dx, n_rows, n_tok, offset, d);
-        const float scale = std::pow((float)kHeadDim, -0.25f);
-        const size_t cache_layer = (size_t)s->beam * ctx_len * d;
-        for (int i = 0; i < D.n_text_layer; ++i) {
-            const LayerW L = layer_weights(m, "dec", i, true);
-            float* kc = s->kcache[s->kv_cur] + i * cache_layer;
-            float* vc = s->vcache[s->kv_cur] + i * cache_layer;
-            launch_layernorm(c, s->dx, d, L.ln1w, L.ln1b, s->dh, d, R, d, "dec_ln1");
-            GemmArgs g;
-            g.A = s->dh; g.lda = d; g.W = L.qkvw; g.bias = L.qkvb; g.C = s->dqkv; g.ldc = 3 * d; g.M = R; g.N = 3 * d;
-            g.K = d; g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = 2 * d;
-            launch_linear(c, g, "dec_qkv");
-            launch_kv_append(c, s->dqkv, kc, vc, n_rows, n_tok, offset, d, ctx_len);
-            launch_decoder_self_attention(c, s->dqkv, kc, vc, s->datt, n_rows, n_tok, offset, d, H, ctx_len);
-            GemmArgs o;
-            o.A = s->datt; o.lda = d; o.W = L.outw; o.bias = L.outb; o.C = s->dx; o.ldc = d; o.M = R; o.N = d; o.K = d;
-            o.flags = kGemmResidual; o.R = s->dx; o.ldr = d;
-            launch_linear(c, o, "dec_out");
-
-            launch_layernorm(c, s->dx, d, L.lnxw, L.lnxb, s->dh, d, R, d, "dec_lnx");
-            GemmArgs q;
-            q.A = s->dh; q.lda = d; q.W = L.xqw; q.bias = L.xqb; q.C = s->dq; q.ldc = d; q.M = R; q.N = d; q.K = d;
-            q.flags = kGemmScaleCols; q.scale = scale; q.scale_cols = d;
-            launch_linear(c, q, "dec_xq");
-            const int* ranks_l = m->n_align > 0 ? m->head_rank + (size_t)i * H : nullptr;
-            if (R > 8 && !s->debug) {
-                // prefill: MFMA flash kernel shares every K/V tile between 32 query rows
-                FlashArgs fa;
-                fa.q = s->dq; fa.ldq = d;
-                fa.k = s->cross_kv + (size_t)i * T * 2 * d; fa.v = fa.k + d; fa.ldkv = 2 * d;
-                fa.out = s->datt; fa.ldo = d; fa.Tq = R; fa.Tk = T; fa.n_head = H;
-                fa.head_rank = ranks_l; fa.ring = s->ring; fa.ring_row = s->ring_row;
-                fa.beam_of_row = s->beam_of_row; fa.ring_rows = s->ring_rows; fa.n_beam = s->beam;
-                launch_prefill_cross_attention(c, fa);
-                launch_ring_softmax(c, s->ring, s->ring_row, s->beam_of_row, m->layer_ranks + (size_t)i * H,
-                                    m->layer_rank_count[i], R, s->ring_rows, s->beam, T);
-            } else {
-                CrossAttnArgs ca;
-                ca.q = s->dq;
-                ca.k = s->cross_kv + (size_t)i * T * 2 * d;
-                ca.v = ca.k + d;
-                ca.ldkv = 2 * d;
-                ca.out = s->datt;
-                ca.rows = R; ca.d = d; ca.n_head = H; ca.T = T;
-                ca.head_rank = ranks_l;
-                ca.ring = s->ring;
-                ca.ring_row = s->ring_row;
-                ca.beam_of_row = s->beam_of_row;
-                ca.ring_rows = s->ring_rows;
-                ca.n_beam = s->beam;
-                ca.qk_debug = s->debug ? s->qk_debug + (size_t)i * s->max_rows * H * T : nullptr;
-                launch_decoder_cross_attention(c, ca);
+        const bool graphable = !first && n_tok == 1 && gemv_applicable(R, D.n_text_state) && !s->debug &&
+                               !s->prof_on && s->use_graph;
+        if (graphable) {
+            hipGraphExec_t& exec = s->step_exec[s->kv_cur];
+            if (!exec) {
+                hipGraph_t graph = nullptr;
+                WLK_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+                try {
+                    enqueue_decode(s, c, n_rows, n_tok, false, sot_index);
+                } catch (...) {
+                    (void)hipStreamEndCapture(s->stream, &graph);
+                    if (graph) (void)hipGraphDestroy(graph);
+                    throw;
+                }
+                WLK_HIP(hipStreamEndCapture(s->stream, &graph));
+                WLK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
             }
-            GemmArgs xo;
-            xo.A = s->datt; xo.lda = d; xo.W = L.xoutw; xo.bias = L.xoutb; xo.C = s->dx; xo.ldc = d; xo.M = R; xo.N = d;
-            xo.K = d; xo.flags = kGemmResidual; xo.R = s->dx; xo.ldr = d;
-            launch_linear(c, xo, "dec_xout");
-            transformer_mlp(c, L, s->dx, s->dh, s->dmlp, R, d, "dec_ln2", "dec_fc1", "dec_fc2");
+            WLK_HIP(hipGraphLaunch(exec, s->stream));
+        } else {
+            enqueue_decode(s, c, n_rows, n_tok, first != 0, sot_index);
         }
-        // final LayerNorm + vocabulary projection only for the rows the policy reads
-        const float* lnw = m->w("dec.ln.w");
-        const float* lnb = m->w("dec.ln.b");
-        launch_layernorm(c, s->dx + (size_t)(n_tok - 1) * d, (long)n_tok * d, lnw, lnb, s->hsel, d, n_rows, d, "dec_ln_f");
-        GemmArgs lg;
-        lg.A = s->hsel; lg.lda = d; lg.W = m->w("dec.tok_emb"); lg.C = s->logits_last; lg.ldc = V; lg.M = n_rows;
-        lg.N = V; lg.K = d;
-        launch_linear(c, lg, "dec_logits");
         s->have_sot = false;
         if (first) {
-            float* hs = s->hsel + (size_t)n_rows * d;
-            launch_layernorm(c, s->dx + (size_t)sot_index * d, (long)n_tok * d, lnw, lnb, hs, d, n_rows, d, "dec_ln_f");
-            GemmArgs ls = lg;
-            ls.A = hs; ls.C = s->logits_sot;
-            launch_linear(c, ls, "dec_logits");
             s->have_sot = true;
             s->prefill_rows = n_tok;
         }
@@ -856,7 +941,7 @@ int wlk_select(wlk_session* s, const int32_t* adj_row, const int32_t* adj_ids, c
             WLK_HIP(hipMemcpyAsync(s->adj_deltas, st + n_adj * 8, n_adj * 4, hipMemcpyHostToDevice, s->stream));
             launch_apply_adjust(c, s->logits_last, V, B, s->adj_row, s->adj_ids, s->adj_deltas, n_adj);
         }
-        launch_logsoftmax_topk(c, s->logits_last, V, B, k, s->top_vals, s->top_ids);
+        launch_logsoftmax_topk(c, s->logits_last, V, B, k, s->top_vals, s->top_ids, s->topk_scratch);
 
         AlignArgs a;
         a.ring = s->ring; a.n_align = m->n_align; a.n_beam = B; a.ring_rows = s->ring_rows; a.T = D.n_audio_ctx;

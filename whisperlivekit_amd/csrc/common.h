@@ -68,6 +68,15 @@ struct GemmArgs {
     int flags = 0;
     float scale = 1.f;
     int scale_cols = 0;
+    // GEMV path only (decode steps): fused pre-LayerNorm of the A rows (eps 1e-5) ...
+    const float* ln_gamma = nullptr;
+    const float* ln_beta = nullptr;
+    // ... and fused KV-cache append: output columns [kv_d, 2kv_d) / [2kv_d, 3kv_d) of row m are ALSO
+    // written to kcache/vcache[(m*kv_ctx + *kv_pos) * kv_d + col] (one fed token per row)
+    float* kcache = nullptr;
+    float* vcache = nullptr;
+    const int* kv_pos = nullptr;
+    int kv_d = 0, kv_ctx = 0;
 };
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag);
 // weight-streaming path for M <= 8 rows (decode steps); same contract as launch_gemm
@@ -125,11 +134,12 @@ void launch_ring_softmax(const LaunchCtx& ctx, float* ring, const int* ring_row,
 
 // ---- decoder.hip ----------------------------------------------------------------------------
 void launch_embed(const LaunchCtx& ctx, const int* tokens, const float* tok_emb, const float* pos_emb,
-                  float* x, int n_rows, int n_tok, int offset, int d);
+                  float* x, int n_rows, int n_tok, const int* offset_dev, int d);
 void launch_kv_append(const LaunchCtx& ctx, const float* qkv, float* kc, float* vc, int n_rows, int n_tok,
-                      int offset, int d, int ctx_len);
+                      const int* offset_dev, int d, int ctx_len);
 void launch_decoder_self_attention(const LaunchCtx& ctx, const float* qkv, const float* kc, const float* vc,
-                                   float* out, int n_rows, int n_tok, int offset, int d, int n_head, int ctx_len);
+                                   float* out, int n_rows, int n_tok, const int* offset_dev, int d, int n_head,
+                                   int ctx_len);
 struct CrossAttnArgs {
     const float* q;        // [rows][d], pre-scaled
     const float* k;        // [T][ldkv] pre-scaled keys of this layer
@@ -152,7 +162,8 @@ void launch_kv_gather(const LaunchCtx& ctx, const float* src, float* dst, const 
 void launch_apply_adjust(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, const int* adj_row,
                          const int* adj_ids, const float* adj_deltas, int n_adj);
 void launch_logsoftmax_topk(const LaunchCtx& ctx, const float* logits, int n_vocab, int n_rows, int k,
-                            float* top_vals, int* top_ids);
+                            float* top_vals, int* top_ids, void* scratch);
+size_t topk_scratch_bytes(int n_rows);
 void launch_token_prob(const LaunchCtx& ctx, const float* logits, int n_vocab, int n_rows, int token, float* probs);
 struct AlignArgs {
     const float* ring;   // [n_align][n_beam][ring_rows][T]

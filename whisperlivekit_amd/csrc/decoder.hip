@@ -14,16 +14,17 @@ namespace wlk {
 __global__ __launch_bounds__(128) void embed_kernel(const int* __restrict__ tokens,
                                                     const float* __restrict__ tok_emb,
                                                     const float* __restrict__ pos_emb, float* __restrict__ x,
-                                                    int n_tok, int offset, int d) {
+                                                    int n_tok, const int* __restrict__ offset_p, int d) {
     const int row = blockIdx.x;             // row = beam * n_tok + p
     const int p = row % n_tok;
+    const int offset = *offset_p;           // device scalar: keeps the launch replayable from a hipGraph
     const float* e = tok_emb + (long)tokens[row] * d;
     const float* pe = pos_emb + (long)(offset + p) * d;
     for (int c = threadIdx.x; c < d; c += 128) x[(long)row * d + c] = e[c] + pe[c];
 }
 
 void launch_embed(const LaunchCtx& ctx, const int* tokens, const float* tok_emb, const float* pos_emb,
-                  float* x, int n_rows, int n_tok, int offset, int d) {
+                  float* x, int n_rows, int n_tok, const int* offset, int d) {
     KernelScope ks(ctx, "dec_embed");
     hipLaunchKernelGGL(embed_kernel, dim3(n_rows * n_tok), dim3(128), 0, ctx.stream, tokens, tok_emb, pos_emb, x,
                        n_tok, offset, d);
@@ -32,8 +33,9 @@ void launch_embed(const LaunchCtx& ctx, const int* tokens, const float* tok_emb,
 
 // qkv rows are [q | k | v] (3d floats); append k and v of every row to the per-beam caches
 __global__ __launch_bounds__(256) void kv_append_kernel(const float* __restrict__ qkv, float* __restrict__ kc,
-                                                        float* __restrict__ vc, int n_tok, int offset, int d,
-                                                        int ctx_len) {
+                                                        float* __restrict__ vc, int n_tok,
+                                                        const int* __restrict__ offset_p, int d, int ctx_len) {
+    const int offset = *offset_p;
     const int row = blockIdx.x;
     const int b = row / n_tok, p = row - b * n_tok;
     const float* src = qkv + (long)row * 3 * d;
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const float* __restrict_
 }
 
 void launch_kv_append(const LaunchCtx& ctx, const float* qkv, float* kc, float* vc, int n_rows, int n_tok,
-                      int offset, int d, int ctx_len) {
+                      const int* offset, int d, int ctx_len) {
     KernelScope ks(ctx, "dec_kv_append");
     hipLaunchKernelGGL(kv_append_kernel, dim3(n_rows * n_tok), dim3(256), 0, ctx.stream, qkv, kc, vc, n_tok,
                        offset, d, ctx_len);
@@ -60,11 +62,13 @@ void launch_kv_append(const LaunchCtx& ctx, const float* qkv, float* kc, float* 
 __global__ __launch_bounds__(64) void decoder_self_attention_kernel(const float* __restrict__ qkv,
                                                                     const float* __restrict__ kc,
                                                                     const float* __restrict__ vc,
-                                                                    float* __restrict__ out, int n_tok, int offset,
-                                                                    int d, int ctx_len) {
+                                                                    float* __restrict__ out, int n_tok,
+                                                                    const int* __restrict__ offset_p, int d,
+                                                                    int ctx_len) {
     __shared__ float qs[64];
     __shared__ float sc[448 + 64];
     const int lane = threadIdx.x;
+    const int offset = *offset_p;
     const int row = blockIdx.x;
     const int head = blockIdx.y;
     const int b = row / n_tok, p = row - b * n_tok;
@@ -107,8 +111,9 @@ __global__ __launch_bounds__(64) void decoder_self_attention_kernel(const float*
 }
 
 void launch_decoder_self_attention(const LaunchCtx& ctx, const float* qkv, const float* kc, const float* vc,
-                                   float* out, int n_rows, int n_tok, int offset, int d, int n_head, int ctx_len) {
-    if (offset + n_tok > 448 + 64) throw std::invalid_argument("self-attention: context too long");
+                                   float* out, int n_rows, int n_tok, const int* offset, int d, int n_head,
+                                   int ctx_len) {
+    if (ctx_len > 448 + 64) throw std::invalid_argument("self-attention: context too long");
     KernelScope ks(ctx, "dec_self_attention");
     hipLaunchKernelGGL(decoder_self_attention_kernel, dim3(n_rows * n_tok, n_head), dim3(64), 0, ctx.stream, qkv,
                        kc, vc, out, n_tok, offset, d, ctx_len);
@@ -148,25 +153,33 @@ __global__ __launch_bounds__(256) void decoder_cross_attention_kernel(CrossAttnA
     const float* kb = a.k + head * 64 + sub * 4;
     const float* vb = a.v + head * 64 + sub * 4;
 
-    // pass 1
+    // pass 1: 8 key-row loads (8 KiB per wave) in flight before the first dot product is folded
     float mx = -INFINITY;
-    for (int j0 = wave * 4; j0 < a.T; j0 += 16) {
-        const int j = j0 + kq;
-        float acc = 0.f;
-        if (j < a.T) {
-            const float4 k4 = *reinterpret_cast<const float4*>(kb + (long)j * a.ldkv);
-            acc = fmaf(q4.x, k4.x, acc);
-            acc = fmaf(q4.y, k4.y, acc);
-            acc = fmaf(q4.z, k4.z, acc);
-            acc = fmaf(q4.w, k4.w, acc);
+    for (int base = wave * 4; base < a.T; base += 16 * 8) {
+        float4 kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = base + 16 * u + kq;
+            const bool ok = j < a.T;
+            const float4 t = *reinterpret_cast<const float4*>(kb + (long)(ok ? j : 0) * a.ldkv);
+            kk[u] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 4, 64);
-        acc += __shfl_xor(acc, 8, 64);
-        if (j < a.T) {
-            if (sub == 0) sc[j] = acc;
-            mx = fmaxf(mx, acc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = base + 16 * u + kq;
+            float acc = 0.f;
+            acc = fmaf(q4.x, kk[u].x, acc);
+            acc = fmaf(q4.y, kk[u].y, acc);
+            acc = fmaf(q4.z, kk[u].z, acc);
+            acc = fmaf(q4.w, kk[u].w, acc);
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            acc += __shfl_xor(acc, 8, 64);
+            if (j < a.T) {
+                if (sub == 0) sc[j] = acc;
+                mx = fmaxf(mx, acc);
+            }
         }
     }
 #pragma unroll
@@ -206,15 +219,23 @@ __global__ __launch_bounds__(256) void decoder_cross_attention_kernel(CrossAttnA
 
     // pass 3
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j0 = wave * 4; j0 < a.T; j0 += 16) {
-        const int j = j0 + kq;
-        if (j < a.T) {
-            const float w = sc[j];
-            const float4 v4 = *reinterpret_cast<const float4*>(vb + (long)j * a.ldkv);
-            o.x = fmaf(w, v4.x, o.x);
-            o.y = fmaf(w, v4.y, o.y);
-            o.z = fmaf(w, v4.z, o.z);
-            o.w = fmaf(w, v4.w, o.w);
+    for (int base = wave * 4; base < a.T; base += 16 * 8) {
+        float4 vv[8];
+        float ww[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = base + 16 * u + kq;
+            const bool ok = j < a.T;
+            const float4 t = *reinterpret_cast<const float4*>(vb + (long)(ok ? j : 0) * a.ldkv);
+            vv[u] = t;
+            ww[u] = ok ? sc[j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            o.x = fmaf(ww[u], vv[u].x, o.x);
+            o.y = fmaf(ww[u], vv[u].y, o.y);
+            o.z = fmaf(ww[u], vv[u].z, o.z);
+            o.w = fmaf(ww[u], vv[u].w, o.w);
         }
     }
     reinterpret_cast<float4*>(part)[(wave * 4 + kq) * 16 + sub] = o;

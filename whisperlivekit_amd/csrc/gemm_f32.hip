@@ -160,6 +160,28 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
         reinterpret_cast<float4*>(xs)[i] = v;
     }
     __syncthreads();
+    if (g.ln_gamma) {
+        // fused LayerNorm of the staged rows; same reduction order as layernorm_kernel (lane-strided
+        // partial sums, xor-shuffle fold), so fused and unfused paths agree bit for bit
+        for (int m = wave; m < g.M; m += 4) {
+            float* xr = xs + m * g.K;
+            float sum = 0.f;
+            for (int c = lane; c < g.K; c += 64) sum += xr[c];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+            const float mean = sum / (float)g.K;
+            float sq = 0.f;
+            for (int c = lane; c < g.K; c += 64) {
+                const float t = xr[c] - mean;
+                sq += t * t;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+            const float rstd = 1.0f / sqrtf(sq / (float)g.K + 1e-5f);
+            for (int c = lane; c < g.K; c += 64) xr[c] = (xr[c] - mean) * rstd * g.ln_gamma[c] + g.ln_beta[c];
+        }
+        __syncthreads();
+    }
 
     constexpr int RPW = 4;  // output features per wave per pass
     const int n_groups = (g.N + RPW - 1) / RPW;
@@ -213,6 +235,11 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
                 if (g.flags & kGemmGelu) v = gelu_erf(v);
                 if (g.flags & kGemmResidual) v += g.R[(long)m * g.ldr + n];
                 g.C[(long)m * g.ldc + n] = v;
+                if (g.kcache && n >= g.kv_d) {
+                    const long at = ((long)m * g.kv_ctx + *g.kv_pos) * g.kv_d;
+                    if (n < 2 * g.kv_d) g.kcache[at + n - g.kv_d] = v;
+                    else g.vcache[at + n - 2 * g.kv_d] = v;
+                }
             }
         }
     }

@@ -63,31 +63,41 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return r;
 }
 
-// one workgroup per beam row: log_softmax(x)[i] = (x_i - max) - log(sum exp(x - max)); top-k by
-// k rounds of (value, lowest index) arg-max.
-__global__ __launch_bounds__(kSelThreads) void logsoftmax_topk_kernel(const float* __restrict__ logits,
-                                                                      int n_vocab, int k,
-                                                                      float* __restrict__ top_vals,
-                                                                      int* __restrict__ top_ids) {
+// log_softmax(x)[i] = (x_i - max) - log(sum exp(x - max)) and top-k, in two stages so the 51864-wide
+// row is swept by kSelBlocks workgroups at once: stage 1 leaves per-slice (max, sum exp(x - max_slice),
+// k best (value, index)); stage 2 folds the slices.  Ties resolve to the lowest index in both stages.
+constexpr int kSelBlocks = 64;
+struct SelPartial {
+    float mx, sum;
+    float v[kMaxTopK];
+    int i[kMaxTopK];
+};
+
+__global__ __launch_bounds__(256) void topk_stage1_kernel(const float* __restrict__ logits, int n_vocab, int k,
+                                                          SelPartial* __restrict__ parts) {
     __shared__ float red[16];
-    __shared__ float cand_v[16];
-    __shared__ int cand_i[16];
+    __shared__ float cand_v[4];
+    __shared__ int cand_i[4];
     __shared__ int taken[kMaxTopK];
     const int tid = threadIdx.x;
-    const float* x = logits + (long)blockIdx.x * n_vocab;
-
+    const int row = blockIdx.y;
+    const int per = (n_vocab + kSelBlocks - 1) / kSelBlocks;
+    const int lo = blockIdx.x * per;
+    const int hi = min(n_vocab, lo + per);
+    const float* x = logits + (long)row * n_vocab;
     float mx = -INFINITY;
-    for (int i = tid; i < n_vocab; i += kSelThreads) mx = fmaxf(mx, x[i]);
+    for (int i = lo + tid; i < hi; i += 256) mx = fmaxf(mx, x[i]);
     mx = block_max(mx, red);
     float sum = 0.f;
-    for (int i = tid; i < n_vocab; i += kSelThreads) sum += expf(x[i] - mx);
+    if (mx > -INFINITY)
+        for (int i = lo + tid; i < hi; i += 256) sum += expf(x[i] - mx);
     sum = block_sum(sum, red);
-    const float lse = logf(sum);
-
+    SelPartial* out = parts + (long)row * kSelBlocks + blockIdx.x;
+    if (tid == 0) { out->mx = mx; out->sum = sum; }
     for (int round = 0; round < k; ++round) {
         float bv = -INFINITY;
         int bi = 0x7fffffff;
-        for (int i = tid; i < n_vocab; i += kSelThreads) {
+        for (int i = lo + tid; i < hi; i += 256) {
             bool skip = false;
             for (int t = 0; t < round; ++t) skip |= (taken[t] == i);
             const float v = x[i];
@@ -103,24 +113,70 @@ __global__ __launch_bounds__(kSelThreads) void logsoftmax_topk_kernel(const floa
         if ((tid & 63) == 0) { cand_v[tid >> 6] = bv; cand_i[tid >> 6] = bi; }
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < kSelThreads / 64; ++w)
+            for (int w = 1; w < 4; ++w)
                 if (cand_v[w] > bv || (cand_v[w] == bv && cand_i[w] < bi)) { bv = cand_v[w]; bi = cand_i[w]; }
             taken[round] = bi;
-            top_ids[blockIdx.x * k + round] = bi;
-            top_vals[blockIdx.x * k + round] = (bv - mx) - lse;
+            out->v[round] = bv;
+            out->i[round] = bi;
         }
         __syncthreads();
     }
 }
 
-void launch_logsoftmax_topk(const LaunchCtx& ctx, const float* logits, int n_vocab, int n_rows, int k,
-                            float* top_vals, int* top_ids) {
-    if (k < 1 || k > kMaxTopK) throw std::invalid_argument("top-k: k must be in [1, 8]");
-    KernelScope ks(ctx, "sel_logsoftmax_topk");
-    hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(n_rows), dim3(kSelThreads), 0, ctx.stream, logits, n_vocab, k,
-                       top_vals, top_ids);
-    WLK_HIP(hipGetLastError());
+__global__ __launch_bounds__(64) void topk_stage2_kernel(const SelPartial* __restrict__ parts, int k,
+                                                         float* __restrict__ top_vals, int* __restrict__ top_ids) {
+    const int lane = threadIdx.x;   // one lane per slice
+    const int row = blockIdx.x;
+    const SelPartial p = parts[(long)row * kSelBlocks + lane];
+    float mx = p.mx;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float sum = p.mx > -INFINITY ? p.sum * expf(p.mx - mx) : 0.f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float lse = logf(sum);
+    int head = 0;                   // next unconsumed candidate of this slice (its list is sorted)
+    for (int round = 0; round < k; ++round) {
+        float bv = head < k ? p.v[0] : -INFINITY;
+        int bi = head < k ? p.i[0] : 0x7fffffff;
+#pragma unroll
+        for (int t = 1; t < kMaxTopK; ++t)
+            if (t == head && t < k) { bv = p.v[t]; bi = p.i[t]; }
+        if (head >= k) { bv = -INFINITY; bi = 0x7fffffff; }
+        float wv = bv;
+        int wi = bi;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(wv, off, 64);
+            const int oi = __shfl_xor(wi, off, 64);
+            if (ov > wv || (ov == wv && oi < wi)) { wv = ov; wi = oi; }
+        }
+        if (wi == bi && bi != 0x7fffffff) ++head;
+        if (lane == 0) {
+            top_ids[row * k + round] = wi;
+            top_vals[row * k + round] = (wv - mx) - lse;
+        }
+    }
 }
+
+void launch_logsoftmax_topk(const LaunchCtx& ctx, const float* logits, int n_vocab, int n_rows, int k,
+                            float* top_vals, int* top_ids, void* scratch) {
+    if (k < 1 || k > kMaxTopK) throw std::invalid_argument("top-k: k must be in [1, 8]");
+    SelPartial* parts = static_cast<SelPartial*>(scratch);
+    {
+        KernelScope ks(ctx, "sel_topk_stage1", 0.0, 4.0 * 3.0 * n_rows * (double)n_vocab);
+        hipLaunchKernelGGL(topk_stage1_kernel, dim3(kSelBlocks, n_rows), dim3(256), 0, ctx.stream, logits, n_vocab, k,
+                           parts);
+        WLK_HIP(hipGetLastError());
+    }
+    {
+        KernelScope ks(ctx, "sel_topk_stage2");
+        hipLaunchKernelGGL(topk_stage2_kernel, dim3(n_rows), dim3(64), 0, ctx.stream, parts, k, top_vals, top_ids);
+        WLK_HIP(hipGetLastError());
+    }
+}
+
+size_t topk_scratch_bytes(int n_rows) { return sizeof(SelPartial) * kSelBlocks * (size_t)n_rows; }
 
 __global__ __launch_bounds__(kSelThreads) void token_prob_kernel(const float* __restrict__ logits, int n_vocab,
                                                                  int token, float* __restrict__ probs) {
