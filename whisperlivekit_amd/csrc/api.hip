@@ -248,6 +248,7 @@ struct wlk_session {
     int ring_rows = 0;
     float *z = nullptr, *attn_last = nullptr;
     float* qk_debug = nullptr;  // [L][max_rows][H][T]
+    float* xsplit = nullptr;    // scratch of the split cross-attention (decode steps)
 
     // select scratch (device) + pinned host staging
     int *adj_row = nullptr, *adj_ids = nullptr, *src_rows = nullptr;
@@ -500,6 +501,7 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         s->d_offset = dev_alloc<int>(4);
         s->ring_rows = (int)ctx + kAlignWindow;
         if (m->n_align > 0) s->ring = dev_alloc<float>((size_t)m->n_align * beam * s->ring_rows * T);
+        s->xsplit = dev_alloc<float>(cross_split_scratch_floats(8, D.n_text_head, (int)T));
         s->z = dev_alloc<float>((size_t)beam * std::max(m->n_align, 1) * T);
         s->attn_last = dev_alloc_zero<float>((size_t)beam * T, st);
         s->adj_row = dev_alloc<int>(wlk_session::kAdjCap);
@@ -525,7 +527,7 @@ int wlk_session_destroy(wlk_session* s) {
     float* fl[] = {s->audio[0], s->audio[1], s->logmel, s->frame_max, s->mel_t, s->x1p, s->ex, s->eh, s->eqkv,
                    s->eatt, s->emlp, s->enc_out, s->cross_kv, s->dx, s->dh, s->dqkv, s->datt, s->dq, s->dmlp,
                    s->kcache[0], s->kcache[1], s->vcache[0], s->vcache[1], s->hsel, s->logits_last, s->logits_sot,
-                   s->ring, s->z, s->attn_last, s->qk_debug, s->adj_deltas, s->top_vals, s->probs};
+                   s->ring, s->z, s->attn_last, s->qk_debug, s->xsplit, s->adj_deltas, s->top_vals, s->probs};
     for (float* p : fl)
         if (p) (void)hipFree(p);
     int* il[] = {s->d_offset, s->tokens_dev, s->ring_row, s->beam_of_row, s->adj_row, s->adj_ids, s->src_rows, s->top_ids, s->frames};
@@ -798,7 +800,15 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
             ca.ring_rows = s->ring_rows;
             ca.n_beam = s->beam;
             ca.qk_debug = s->debug ? s->qk_debug + (size_t)i * s->max_rows * H * T : nullptr;
-            launch_decoder_cross_attention(c, ca);
+            if (R <= 8 && !s->debug) {
+                float* sc = s->xsplit;
+                float* pm = sc + (size_t)8 * H * T;
+                float* pl = pm + (size_t)8 * H * 8;
+                float* po = pl + (size_t)8 * H * 8;
+                launch_decoder_cross_attention_split(c, ca, sc, pm, pl, po);
+            } else {
+                launch_decoder_cross_attention(c, ca);
+            }
         }
         GemmArgs xo;
         xo.A = s->datt; xo.lda = d; xo.W = L.xoutw; xo.bias = L.xoutb; xo.C = s->dx; xo.ldc = d; xo.M = R; xo.N = d;

@@ -144,11 +144,11 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
             }
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             const float m_new = fmaxf(m_run, mt);
-            const float alpha = expf(m_run - m_new);
+            const float alpha = __expf(m_run - m_new);
             float rs = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = expf(s[r] - m_new);
+                s[r] = __expf(s[r] - m_new);   // v_exp_f32: ~1 ulp, keeps the VALU share small next to the MFMAs
                 rs += s[r];
             }
             rs += __shfl_xor(rs, 32, 64);

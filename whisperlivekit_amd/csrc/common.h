@@ -155,6 +155,11 @@ struct CrossAttnArgs {
     float* qk_debug;       // [rows][n_head][T] or nullptr
 };
 void launch_decoder_cross_attention(const LaunchCtx& ctx, const CrossAttnArgs& a);
+// decode steps: keys split over several workgroups per (row, head) + merge; scratch layout is
+// [scores rows*H*T | pm rows*H*S | pl rows*H*S | po rows*H*S*64] (cross_split_scratch_floats)
+void launch_decoder_cross_attention_split(const LaunchCtx& ctx, const CrossAttnArgs& a, float* scores, float* pm,
+                                          float* pl, float* po);
+size_t cross_split_scratch_floats(int rows, int n_head, int T);
 void launch_kv_gather(const LaunchCtx& ctx, const float* src, float* dst, const int* source_rows, int n_rows,
                       int len, int d, int ctx_len, int n_layer);
 

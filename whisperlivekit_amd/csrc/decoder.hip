@@ -257,6 +257,157 @@ void launch_decoder_cross_attention(const LaunchCtx& ctx, const CrossAttnArgs& a
     WLK_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------
+// Cross-attention for decode STEPS (<= 8 query rows).  A step has only rows x heads = 8 independent
+// softmaxes, far too few workgroups to pull 6 MB of K/V per layer out of HBM / Infinity Cache at
+// speed (every kernel starts with a cold L2 on this part).  So the 1500 keys of each (row, head) are
+// split over kCrossSplit workgroups: each loads its ~188 keys with ALL its K rows in flight at once
+// (12 x 1 KiB per wave), leaves raw scores, a local max, a local exp-sum and a local weighted V sum;
+// cross_merge_kernel folds the slices and, for alignment heads, writes softmax = exp(s - M) / L of
+// the full row into the alignment window.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCrossSplit = 8;
+constexpr int kCrossUnroll = 12;   // key-row loads in flight per wave: covers ceil(1500/8)=188 keys / 16
+
+__global__ __launch_bounds__(256) void cross_split_kernel(CrossAttnArgs a, float* __restrict__ scores,
+                                                          float* __restrict__ pm, float* __restrict__ pl,
+                                                          float* __restrict__ po) {
+    __shared__ __attribute__((aligned(16))) float qs[64];
+    __shared__ float sc[kCrossUnroll * 16];
+    __shared__ float red[8];
+    __shared__ __attribute__((aligned(16))) float part[16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x, head = blockIdx.y, ks = blockIdx.z;
+    const int sub = lane & 15, kq = lane >> 4;
+    const int chunk = (a.T + kCrossSplit - 1) / kCrossSplit;
+    const int k_lo = ks * chunk, k_hi = min(a.T, k_lo + chunk);
+    if (tid < 64) qs[tid] = a.q[(long)row * a.d + head * 64 + tid];
+    __syncthreads();
+    const float4 q4 = reinterpret_cast<const float4*>(qs)[sub];
+    const float* kb = a.k + head * 64 + sub * 4;
+    const float* vb = a.v + head * 64 + sub * 4;
+    float* srow = scores + ((long)row * a.n_head + head) * a.T;
+
+    float4 kk[kCrossUnroll];
+#pragma unroll
+    for (int u = 0; u < kCrossUnroll; ++u) {
+        const int j = k_lo + wave * 4 + 16 * u + kq;
+        const bool ok = j < k_hi;
+        const float4 t = *reinterpret_cast<const float4*>(kb + (long)(ok ? j : k_lo) * a.ldkv);
+        kk[u] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < kCrossUnroll; ++u) {
+        const int j = k_lo + wave * 4 + 16 * u + kq;
+        float acc = 0.f;
+        acc = fmaf(q4.x, kk[u].x, acc);
+        acc = fmaf(q4.y, kk[u].y, acc);
+        acc = fmaf(q4.z, kk[u].z, acc);
+        acc = fmaf(q4.w, kk[u].w, acc);
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        acc += __shfl_xor(acc, 8, 64);
+        if (j < k_hi) {
+            if (sub == 0) { sc[j - k_lo] = acc; srow[j] = acc; }
+            mx = fmaxf(mx, acc);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < k_hi - k_lo; j += 256) {
+        const float e = expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
+
+    float4 vv[kCrossUnroll];
+#pragma unroll
+    for (int u = 0; u < kCrossUnroll; ++u) {
+        const int j = k_lo + wave * 4 + 16 * u + kq;
+        vv[u] = *reinterpret_cast<const float4*>(vb + (long)(j < k_hi ? j : k_lo) * a.ldkv);
+    }
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < kCrossUnroll; ++u) {
+        const int j = k_lo + wave * 4 + 16 * u + kq;
+        const float w = j < k_hi ? sc[j - k_lo] : 0.f;
+        o.x = fmaf(w, vv[u].x, o.x);
+        o.y = fmaf(w, vv[u].y, o.y);
+        o.z = fmaf(w, vv[u].z, o.z);
+        o.w = fmaf(w, vv[u].w, o.w);
+    }
+    reinterpret_cast<float4*>(part)[(wave * 4 + kq) * 16 + sub] = o;
+    __syncthreads();
+    const long slot = ((long)row * a.n_head + head) * kCrossSplit + ks;
+    if (tid < 64) {
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc += part[s * 64 + tid];
+        po[slot * 64 + tid] = acc;
+    }
+    if (tid == 0) { pm[slot] = mx; pl[slot] = sum; }
+}
+
+__global__ __launch_bounds__(256) void cross_merge_kernel(CrossAttnArgs a, const float* __restrict__ scores,
+                                                          const float* __restrict__ pm, const float* __restrict__ pl,
+                                                          const float* __restrict__ po) {
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x, head = blockIdx.y;
+    const long base = ((long)row * a.n_head + head) * kCrossSplit;
+    float M = pm[base];
+#pragma unroll
+    for (int s = 1; s < kCrossSplit; ++s) M = fmaxf(M, pm[base + s]);
+    float L = 0.f;
+    float f[kCrossSplit];
+#pragma unroll
+    for (int s = 0; s < kCrossSplit; ++s) {
+        f[s] = expf(pm[base + s] - M);
+        L += pl[base + s] * f[s];
+    }
+    if (tid < 64) {
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < kCrossSplit; ++s) acc += po[(base + s) * 64 + tid] * f[s];
+        a.out[(long)row * a.d + head * 64 + tid] = acc / L;
+    }
+    const int rank = a.head_rank ? a.head_rank[head] : -1;
+    if (rank >= 0) {
+        float* dst = a.ring + (((long)rank * a.n_beam + a.beam_of_row[row]) * a.ring_rows + a.ring_row[row]) * a.T;
+        const float* srow = scores + ((long)row * a.n_head + head) * a.T;
+        for (int j = tid; j < a.T; j += 256) dst[j] = expf(srow[j] - M) / L;
+    }
+}
+
+void launch_decoder_cross_attention_split(const LaunchCtx& ctx, const CrossAttnArgs& a, float* scores, float* pm,
+                                          float* pl, float* po) {
+    if ((a.T + kCrossSplit - 1) / kCrossSplit > kCrossUnroll * 16) throw std::invalid_argument("cross-attention: T too large");
+    {
+        KernelScope ks(ctx, "dec_cross_split", 4.0 * a.rows * (double)a.T * a.d, 4.0 * 2.0 * a.rows * (double)a.T * a.d);
+        hipLaunchKernelGGL(cross_split_kernel, dim3(a.rows, a.n_head, kCrossSplit), dim3(256), 0, ctx.stream, a, scores,
+                           pm, pl, po);
+        WLK_HIP(hipGetLastError());
+    }
+    {
+        KernelScope ks(ctx, "dec_cross_merge");
+        hipLaunchKernelGGL(cross_merge_kernel, dim3(a.rows, a.n_head), dim3(256), 0, ctx.stream, a, scores, pm, pl, po);
+        WLK_HIP(hipGetLastError());
+    }
+}
+size_t cross_split_scratch_floats(int rows, int n_head, int T) {
+    return (size_t)rows * n_head * ((size_t)T + kCrossSplit * (2 + 64));
+}
+
 // beam reorder of the self-attention caches: dst[l][b] = src[l][source_rows[b]]
 __global__ __launch_bounds__(256) void kv_gather_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                         const int* __restrict__ source_rows, int n_rows, int len,

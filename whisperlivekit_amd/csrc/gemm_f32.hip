@@ -24,79 +24,89 @@ namespace wlk {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = BK + 4;
+constexpr int BK = 32, LDS_LD = BK + 4;
 
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-__device__ __forceinline__ float4 load4_guard(const float* p, bool ok) {
-    return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-}
+// One operand-tile slice held in registers between its global load and its LDS store.
+template <int NA, int NW>
+struct Stage {
+    float4 a[NA], w[NW];
+};
 
-__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g) {
+// BM x BN workgroup tile, one 32x32 MFMA tile per wave ((BM/32)*(BN/32) waves).  Global -> register
+// -> LDS staging runs TWO k-tiles ahead of the MFMA stream: the loads of tile kt+2 are issued before
+// the math on tile kt, and are only waited for one full iteration later, so a cold-L2 / Infinity-Cache
+// round trip (every kernel starts with an invalidated L2 on this multi-XCD part) is covered even when
+// a CU holds a single workgroup - the common case for the 1500-row encoder GEMMs (192..768 tiles on
+// 256 CUs).  Guards are branch-free (clamped address + select) so the loads stay unpredicated.
+template <int BM, int BN>
+__global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel(GemmArgs g) {
+    constexpr int NT = 64 * (BM / 32) * (BN / 32);
+    constexpr int NA = BM * 8 / NT, NW = BN * 8 / NT;
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Ws[2][BN * LDS_LD];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / (BN / 32), wc = wave % (BN / 32);
     const int m0 = blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
 
-    // staging map: 512 float4 per operand tile, two per thread
-    int st_row[2], st_c4[2];
+    const float* a_ptr[NA];
+    const float* w_ptr[NW];
+    bool a_ok[NA], w_ok[NW];
+    int a_lds[NA], w_lds[NW], a_c[NA], w_c[NW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int idx = tid + 256 * i;
-        st_row[i] = idx >> 3;
-        st_c4[i] = idx & 7;
+    for (int i = 0; i < NA; ++i) {
+        const int idx = tid + NT * i, row = idx >> 3, c4 = idx & 7;
+        a_ok[i] = (m0 + row) < g.M;
+        a_ptr[i] = g.A + (long)(a_ok[i] ? m0 + row : 0) * g.lda + c4 * 4;
+        a_lds[i] = row * LDS_LD + c4 * 4;
+        a_c[i] = c4 * 4;
     }
-    const float* a_ptr[2];
-    const float* w_ptr[2];
-    bool a_ok[2], w_ok[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        a_ok[i] = (m0 + st_row[i]) < g.M;
-        w_ok[i] = (n0 + st_row[i]) < g.N;
-        a_ptr[i] = g.A + (long)(m0 + st_row[i]) * g.lda + st_c4[i] * 4;
-        w_ptr[i] = g.W + (long)(n0 + st_row[i]) * g.K + st_c4[i] * 4;
+    for (int i = 0; i < NW; ++i) {
+        const int idx = tid + NT * i, row = idx >> 3, c4 = idx & 7;
+        w_ok[i] = (n0 + row) < g.N;
+        w_ptr[i] = g.W + (long)(w_ok[i] ? n0 + row : 0) * g.K + c4 * 4;
+        w_lds[i] = row * LDS_LD + c4 * 4;
+        w_c[i] = c4 * 4;
     }
+    const int nk = (g.K + BK - 1) / BK;
+    const int k_last = g.K - 4;  // K % 4 == 0: last float4 column that is in range
+
+    auto fetch = [&](Stage<NA, NW>& st, int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const bool ok = a_ok[i] && (k0 + a_c[i]) <= k_last;
+            const float4 v = *reinterpret_cast<const float4*>(a_ptr[i] + (ok ? k0 : -a_c[i]));
+            st.a[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const bool ok = w_ok[i] && (k0 + w_c[i]) <= k_last;
+            const float4 v = *reinterpret_cast<const float4*>(w_ptr[i] + (ok ? k0 : -w_c[i]));
+            st.w[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](const Stage<NA, NW>& st, int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<float4*>(&As[buf][a_lds[i]]) = st.a[i];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) *reinterpret_cast<float4*>(&Ws[buf][w_lds[i]]) = st.w[i];
+    };
 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-
-    const int nk = (g.K + BK - 1) / BK;
-    float4 ra[2], rw[2];
-    auto fetch = [&](int kt) {
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bool kin = (k0 + st_c4[i] * 4) < g.K;  // K % 4 == 0 is required by the launcher
-            ra[i] = load4_guard(a_ptr[i] + k0, a_ok[i] && kin);
-            rw[i] = load4_guard(w_ptr[i] + k0, w_ok[i] && kin);
-        }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<float4*>(&As[buf][st_row[i] * LDS_LD + st_c4[i] * 4]) = ra[i];
-            *reinterpret_cast<float4*>(&Ws[buf][st_row[i] * LDS_LD + st_c4[i] * 4]) = rw[i];
-        }
-    };
-
-    fetch(0);
-    stash(0);
-    __syncthreads();
-
     const int a_off = (wr * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
     const int w_off = (wc * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
-
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) fetch(kt + 1);
+    auto mma = [&](int buf) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][a_off + s * 8]);
@@ -106,9 +116,24 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
         }
-        if (kt + 1 < nk) stash(buf ^ 1);
+    };
+
+    Stage<NA, NW> s0, s1;
+    fetch(s0, 0);
+    if (nk > 1) fetch(s1, 1);
+    stash(s0, 0);
+    __syncthreads();
+    // iteration kt: math on LDS buffer kt&1; tile kt+1 is in registers (s1 on even kt, s0 on odd kt)
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 2 < nk) fetch(s0, kt + 2);
+        mma(0);
+        if (kt + 1 < nk) stash(s1, 1);
         __syncthreads();
-        buf ^= 1;
+        if (kt + 1 >= nk) break;
+        if (kt + 3 < nk) fetch(s1, kt + 3);
+        mma(1);
+        if (kt + 2 < nk) stash(s0, 0);
+        __syncthreads();
     }
 
     // epilogue: acc[r] is C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31] of the wave tile
@@ -133,9 +158,15 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g) {
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (g.M <= 0 || g.N <= 0) return;
     if (g.K % 4 != 0 || g.lda % 4 != 0) throw std::invalid_argument("gemm: K and lda must be multiples of 4");
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
     KernelScope ks(ctx, tag, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
-    hipLaunchKernelGGL(gemm_nt_f32_kernel, grid, dim3(256), 0, ctx.stream, g);
+    const long tiles64 = (long)((g.N + 63) / 64) * ((g.M + 63) / 64);
+    if (tiles64 >= 256) {
+        dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
+        hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64>), grid, dim3(256), 0, ctx.stream, g);
+    } else {  // few tiles: halve the tile height so that more CUs get a workgroup
+        dim3 grid((g.N + 63) / 64, (g.M + 31) / 32);
+        hipLaunchKernelGGL((gemm_nt_f32_kernel<32, 64>), grid, dim3(128), 0, ctx.stream, g);
+    }
     WLK_HIP(hipGetLastError());
 }
 
@@ -146,7 +177,7 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
 // sums are folded with DPP-free xor shuffles.  HBM-bound by construction: K*4 bytes per output
 // feature against 2*M*K flops.
 // -------------------------------------------------------------------------------------------------
-template <int MR>
+template <int MR, int RPW>
 __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [MR][K]
     const int tid = threadIdx.x;
@@ -183,7 +214,6 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    constexpr int RPW = 4;  // output features per wave per pass
     const int n_groups = (g.N + RPW - 1) / RPW;
     for (int grp = blockIdx.x * 4 + wave; grp < n_groups; grp += gridDim.x * 4) {
         const int n_base = grp * RPW;
@@ -249,17 +279,30 @@ void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (g.M <= 0 || g.N <= 0) return;
     if (!gemv_applicable(g.M, g.K) || g.lda % 4 != 0) throw std::invalid_argument("gemv: unsupported shape");
     const int mr = gemv_row_bucket(g.M);
-    const int n_groups = (g.N + 3) / 4;
+    // output features per wave per pass: few for narrow layers (more workgroups in flight), more for
+    // the 51864-wide vocabulary projection (amortises the shuffle folds)
+    const int rpw = g.N >= 16384 ? 4 : (g.N >= 2048 ? 2 : 1);
+    const int n_groups = (g.N + rpw - 1) / rpw;
     int blocks = (n_groups + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     const size_t lds = (size_t)mr * g.K * sizeof(float);
     KernelScope ks(ctx, tag, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+#define WLK_GEMV(MRv, RPWv) \
+    hipLaunchKernelGGL((gemv_f32_kernel<MRv, RPWv>), dim3(blocks), dim3(256), lds, ctx.stream, g)
+#define WLK_GEMV_R(MRv)                      \
+    do {                                     \
+        if (rpw == 4) WLK_GEMV(MRv, 4);      \
+        else if (rpw == 2) WLK_GEMV(MRv, 2); \
+        else WLK_GEMV(MRv, 1);               \
+    } while (0)
     switch (mr) {
-        case 1: hipLaunchKernelGGL(gemv_f32_kernel<1>, dim3(blocks), dim3(256), lds, ctx.stream, g); break;
-        case 2: hipLaunchKernelGGL(gemv_f32_kernel<2>, dim3(blocks), dim3(256), lds, ctx.stream, g); break;
-        case 4: hipLaunchKernelGGL(gemv_f32_kernel<4>, dim3(blocks), dim3(256), lds, ctx.stream, g); break;
-        default: hipLaunchKernelGGL(gemv_f32_kernel<8>, dim3(blocks), dim3(256), lds, ctx.stream, g); break;
+        case 1: WLK_GEMV_R(1); break;
+        case 2: WLK_GEMV_R(2); break;
+        case 4: WLK_GEMV_R(4); break;
+        default: WLK_GEMV_R(8); break;
     }
+#undef WLK_GEMV_R
+#undef WLK_GEMV
     WLK_HIP(hipGetLastError());
 }
 
