@@ -23,6 +23,7 @@ namespace wlk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32, LDS_LD = BK + 4;
 
@@ -56,42 +57,45 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
     const int m0 = blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
 
-    const float* a_ptr[NA];
-    const float* w_ptr[NW];
-    bool a_ok[NA], w_ok[NW];
+    // Operand tiles are fetched with buffer loads: the hardware bounds check returns 0 for any
+    // offset past the descriptor's size, so row / K tails need no branches and the compiler can
+    // count outstanding loads exactly (counted vmcnt keeps the second prefetch stage in flight).
+    constexpr unsigned kOob = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.A), 0, (int)((((long)g.M - 1) * g.lda + g.K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.W), 0, (int)((long)g.N * g.K * 4), 0x00020000);
+    unsigned a_byte[NA], w_byte[NW];
     int a_lds[NA], w_lds[NW], a_c[NA], w_c[NW];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int idx = tid + NT * i, row = idx >> 3, c4 = idx & 7;
-        a_ok[i] = (m0 + row) < g.M;
-        a_ptr[i] = g.A + (long)(a_ok[i] ? m0 + row : 0) * g.lda + c4 * 4;
+        a_byte[i] = (m0 + row) < g.M ? (unsigned)(((long)(m0 + row) * g.lda + c4 * 4) * 4) : kOob;
         a_lds[i] = row * LDS_LD + c4 * 4;
         a_c[i] = c4 * 4;
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
         const int idx = tid + NT * i, row = idx >> 3, c4 = idx & 7;
-        w_ok[i] = (n0 + row) < g.N;
-        w_ptr[i] = g.W + (long)(w_ok[i] ? n0 + row : 0) * g.K + c4 * 4;
+        w_byte[i] = (n0 + row) < g.N ? (unsigned)(((long)(n0 + row) * g.K + c4 * 4) * 4) : kOob;
         w_lds[i] = row * LDS_LD + c4 * 4;
         w_c[i] = c4 * 4;
     }
     const int nk = (g.K + BK - 1) / BK;
-    const int k_last = g.K - 4;  // K % 4 == 0: last float4 column that is in range
 
     auto fetch = [&](Stage<NA, NW>& st, int kt) {
         const int k0 = kt * BK;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const bool ok = a_ok[i] && (k0 + a_c[i]) <= k_last;
-            const float4 v = *reinterpret_cast<const float4*>(a_ptr[i] + (ok ? k0 : -a_c[i]));
-            st.a[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned off = (k0 + a_c[i]) < g.K ? a_byte[i] + (unsigned)k0 * 4u : kOob;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)off, 0, 0);
+            st.a[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            const bool ok = w_ok[i] && (k0 + w_c[i]) <= k_last;
-            const float4 v = *reinterpret_cast<const float4*>(w_ptr[i] + (ok ? k0 : -w_c[i]));
-            st.w[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned off = (k0 + w_c[i]) < g.K ? w_byte[i] + (unsigned)k0 * 4u : kOob;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)off, 0, 0);
+            st.w[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
     };
     auto stash = [&](const Stage<NA, NW>& st, int buf) {
@@ -118,39 +122,55 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
         }
     };
 
+    // Straight-line software pipeline, two k-tiles per trip, no conditionals inside: tiles past the end
+    // of K are fetched out of bounds (-> zeros, contributing nothing), so the load count in flight is a
+    // compile-time constant and hipcc emits counted vmcnt waits instead of vmcnt(0).
     Stage<NA, NW> s0, s1;
     fetch(s0, 0);
-    if (nk > 1) fetch(s1, 1);
+    fetch(s1, 1);
     stash(s0, 0);
     __syncthreads();
-    // iteration kt: math on LDS buffer kt&1; tile kt+1 is in registers (s1 on even kt, s0 on odd kt)
-    for (int kt = 0; kt < nk; kt += 2) {
-        if (kt + 2 < nk) fetch(s0, kt + 2);
-        mma(0);
-        if (kt + 1 < nk) stash(s1, 1);
+    const int nk2 = (nk + 1) & ~1;
+    for (int kt = 0; kt < nk2; kt += 2) {
+        fetch(s0, kt + 2);
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch loads ahead of the MFMA block
+        mma(0);            // tile kt
+        stash(s1, 1);      // tile kt+1 (loaded one full trip ago)
         __syncthreads();
-        if (kt + 1 >= nk) break;
-        if (kt + 3 < nk) fetch(s1, kt + 3);
-        mma(1);
-        if (kt + 2 < nk) stash(s0, 0);
+        fetch(s1, kt + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1);            // tile kt+1
+        stash(s0, 0);      // tile kt+2
         __syncthreads();
     }
 
-    // epilogue: acc[r] is C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31] of the wave tile
+    // epilogue: acc[r] is C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31] of the wave tile.
+    // The 16 residual reads are issued together (one latency, not sixteen) before any store.
     const int col = n0 + wc * 32 + (lane & 31);
     if (col < g.N) {
         const float b = g.bias ? g.bias[col] : 0.f;
         const bool do_scale = (g.flags & kGemmScaleCols) && col < g.scale_cols;
+        const int row_base = m0 + wr * 32 + 4 * (lane >> 5);
+        float res[16];
+        if (g.flags & kGemmResidual) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + (r & 3) + 8 * (r >> 2);
+                res[r] = g.R[(long)min(row, g.M - 1) * g.ldr + col];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) res[r] = 0.f;
+        }
+        const bool gelu = (g.flags & kGemmGelu) != 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row < g.M) {
-                float v = acc[r] + b;
-                if (do_scale) v *= g.scale;
-                if (g.flags & kGemmGelu) v = gelu_erf(v);
-                if (g.flags & kGemmResidual) v += g.R[(long)row * g.ldr + col];
-                g.C[(long)row * g.ldc + col] = v;
-            }
+            const int row = row_base + (r & 3) + 8 * (r >> 2);
+            float v = acc[r] + b;
+            if (do_scale) v *= g.scale;
+            if (gelu) v = gelu_erf(v);
+            v += res[r];
+            if (row < g.M) g.C[(long)row * g.ldc + col] = v;
         }
     }
 }
@@ -158,9 +178,11 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (g.M <= 0 || g.N <= 0) return;
     if (g.K % 4 != 0 || g.lda % 4 != 0) throw std::invalid_argument("gemm: K and lda must be multiples of 4");
+    if ((((long)g.M - 1) * g.lda + g.K) * 4 >= (1L << 31) || (long)g.N * g.K * 4 >= (1L << 31))
+        throw std::invalid_argument("gemm: operand larger than 2 GiB");
     KernelScope ks(ctx, tag, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
     const long tiles64 = (long)((g.N + 63) / 64) * ((g.M + 63) / 64);
-    if (tiles64 >= 256) {
+    if (tiles64 >= 64) {   // measured: the 32x64 variant only pays below ~64 tiles (more L2->LDS traffic per flop)
         dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
         hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64>), grid, dim3(256), 0, ctx.stream, g);
     } else {  // few tiles: halve the tile height so that more CUs get a workgroup
@@ -184,6 +206,18 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int K4 = g.K >> 2;
+    // the first weight chunk of this wave's first output group does not depend on the activations:
+    // issue it BEFORE the x staging round trip so the two memory latencies overlap instead of adding up
+    const int n_groups = (g.N + RPW - 1) / RPW;
+    const int grp0 = blockIdx.x * 4 + wave;
+    float4 wpre[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int n = min(grp0 * RPW + r, g.N - 1);
+        const bool ok = grp0 < n_groups && lane < K4;
+        const float4 t = *reinterpret_cast<const float4*>(g.W + (long)(ok ? n : 0) * g.K + (ok ? lane : 0) * 4);
+        wpre[r] = t;
+    }
     for (int i = tid; i < MR * K4; i += 256) {
         const int m = i / K4, c = i - m * K4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -214,30 +248,44 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    const int n_groups = (g.N + RPW - 1) / RPW;
-    for (int grp = blockIdx.x * 4 + wave; grp < n_groups; grp += gridDim.x * 4) {
+    for (int grp = grp0; grp < n_groups; grp += gridDim.x * 4) {
         const int n_base = grp * RPW;
         float acc[RPW][MR];
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
 #pragma unroll
             for (int m = 0; m < MR; ++m) acc[r][m] = 0.f;
-        for (int c = lane; c < K4; c += 64) {
-            float4 w[RPW];
+        // K is walked in batches of 4 lane-strided float4 chunks: all loads of a batch are issued
+        // before the first FMA so that several KiB per wave are in flight (weights come from HBM / MALL)
+        constexpr int UB = 4;
+        for (int c0 = lane; c0 < K4; c0 += 64 * UB) {
+            float4 w[UB][RPW];
 #pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const int n = min(n_base + r, g.N - 1);
-                w[r] = *reinterpret_cast<const float4*>(g.W + (long)n * g.K + c * 4);
-            }
-#pragma unroll
-            for (int m = 0; m < MR; ++m) {
-                const float4 x = reinterpret_cast<const float4*>(xs)[m * K4 + c];
+            for (int u = 0; u < UB; ++u) {
+                const int c = c0 + 64 * u;
+                const bool ok = c < K4;
 #pragma unroll
                 for (int r = 0; r < RPW; ++r) {
-                    acc[r][m] = fmaf(w[r].x, x.x, acc[r][m]);
-                    acc[r][m] = fmaf(w[r].y, x.y, acc[r][m]);
-                    acc[r][m] = fmaf(w[r].z, x.z, acc[r][m]);
-                    acc[r][m] = fmaf(w[r].w, x.w, acc[r][m]);
+                    const int n = min(n_base + r, g.N - 1);
+                    if (u == 0 && grp == grp0 && c0 == lane) w[u][r] = wpre[r];
+                    else w[u][r] = *reinterpret_cast<const float4*>(g.W + (long)n * g.K + (ok ? c : 0) * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int c = c0 + 64 * u;
+                if (c < K4) {
+#pragma unroll
+                    for (int m = 0; m < MR; ++m) {
+                        const float4 x = reinterpret_cast<const float4*>(xs)[m * K4 + c];
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r) {
+                            acc[r][m] = fmaf(w[u][r].x, x.x, acc[r][m]);
+                            acc[r][m] = fmaf(w[u][r].y, x.y, acc[r][m]);
+                            acc[r][m] = fmaf(w[u][r].z, x.z, acc[r][m]);
+                            acc[r][m] = fmaf(w[u][r].w, x.w, acc[r][m]);
+                        }
+                    }
                 }
             }
         }
