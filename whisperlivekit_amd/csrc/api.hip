@@ -949,9 +949,9 @@ int wlk_select(wlk_session* s, const int32_t* adj_row, const int32_t* adj_ids, c
             WLK_HIP(hipMemcpyAsync(s->adj_row, st, n_adj * 4, hipMemcpyHostToDevice, s->stream));
             WLK_HIP(hipMemcpyAsync(s->adj_ids, st + n_adj * 4, n_adj * 4, hipMemcpyHostToDevice, s->stream));
             WLK_HIP(hipMemcpyAsync(s->adj_deltas, st + n_adj * 8, n_adj * 4, hipMemcpyHostToDevice, s->stream));
-            launch_apply_adjust(c, s->logits_last, V, B, s->adj_row, s->adj_ids, s->adj_deltas, n_adj);
         }
-        launch_logsoftmax_topk(c, s->logits_last, V, B, k, s->top_vals, s->top_ids, s->topk_scratch);
+        launch_logsoftmax_topk(c, s->logits_last, V, B, k, s->top_vals, s->top_ids, s->topk_scratch, s->adj_row,
+                               s->adj_ids, s->adj_deltas, n_adj);
 
         AlignArgs a;
         a.ring = s->ring; a.n_align = m->n_align; a.n_beam = B; a.ring_rows = s->ring_rows; a.T = D.n_audio_ctx;

@@ -166,8 +166,10 @@ void launch_kv_gather(const LaunchCtx& ctx, const float* src, float* dst, const 
 // ---- select.hip -----------------------------------------------------------------------------
 void launch_apply_adjust(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, const int* adj_row,
                          const int* adj_ids, const float* adj_deltas, int n_adj);
-void launch_logsoftmax_topk(const LaunchCtx& ctx, const float* logits, int n_vocab, int n_rows, int k,
-                            float* top_vals, int* top_ids, void* scratch);
+// adjustments (may be n_adj = 0) are applied to the logits in place before the reduction
+void launch_logsoftmax_topk(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, int k,
+                            float* top_vals, int* top_ids, void* scratch, const int* adj_row, const int* adj_ids,
+                            const float* adj_deltas, int n_adj);
 size_t topk_scratch_bytes(int n_rows);
 void launch_token_prob(const LaunchCtx& ctx, const float* logits, int n_vocab, int n_rows, int token, float* probs);
 struct AlignArgs {

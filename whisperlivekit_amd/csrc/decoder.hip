@@ -55,59 +55,110 @@ void launch_kv_append(const LaunchCtx& ctx, const float* qkv, float* kc, float* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Self-attention, one wave per (query row, head).  Causal: row p of the fed block sees cache
-// positions 0..offset+p (model.py:164-166 adds mask[:n_ctx,:n_ctx]; with a cache and one fed
-// token that mask is the single 0, i.e. everything cached is visible).
+// Self-attention over the growing KV cache, one 256-thread workgroup per (query row, head).
+// Causal: row p of the fed block sees cache positions 0..offset+p (model.py:164-166 adds
+// mask[:n_ctx,:n_ctx]; with a cache and one fed token that mask is the single 0, i.e. everything
+// cached is visible).  Same data mapping as the cross-attention kernels below: a 16-lane group reads
+// one 256-byte key/value row, a wave covers 4 rows per instruction, 8 instructions are in flight
+// before the first dot product is folded.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void decoder_self_attention_kernel(const float* __restrict__ qkv,
-                                                                    const float* __restrict__ kc,
-                                                                    const float* __restrict__ vc,
-                                                                    float* __restrict__ out, int n_tok,
-                                                                    const int* __restrict__ offset_p, int d,
-                                                                    int ctx_len) {
-    __shared__ float qs[64];
+__global__ __launch_bounds__(256) void decoder_self_attention_kernel(const float* __restrict__ qkv,
+                                                                     const float* __restrict__ kc,
+                                                                     const float* __restrict__ vc,
+                                                                     float* __restrict__ out, int n_tok,
+                                                                     const int* __restrict__ offset_p, int d,
+                                                                     int ctx_len) {
+    __shared__ __attribute__((aligned(16))) float qs[64];
     __shared__ float sc[448 + 64];
-    const int lane = threadIdx.x;
+    __shared__ float red[8];
+    __shared__ __attribute__((aligned(16))) float part[16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane & 15, kq = lane >> 4;
     const int offset = *offset_p;
     const int row = blockIdx.x;
     const int head = blockIdx.y;
     const int b = row / n_tok, p = row - b * n_tok;
     const int n_keys = offset + p + 1;
-    qs[lane] = qkv[(long)row * 3 * d + head * 64 + lane];
+    if (tid < 64) qs[tid] = qkv[(long)row * 3 * d + head * 64 + tid];
     __syncthreads();
-    const float* kb = kc + (long)b * ctx_len * d + head * 64;
-    const float* vb = vc + (long)b * ctx_len * d + head * 64;
+    const float4 q4 = reinterpret_cast<const float4*>(qs)[sub];
+    const float* kb = kc + (long)b * ctx_len * d + head * 64 + sub * 4;
+    const float* vb = vc + (long)b * ctx_len * d + head * 64 + sub * 4;
 
     float mx = -INFINITY;
-    for (int j = lane; j < n_keys; j += 64) {
-        const float4* kr = reinterpret_cast<const float4*>(kb + (long)j * d);
-        float acc = 0.f;
+    for (int base = wave * 4; base < n_keys; base += 16 * 8) {
+        float4 kk[8];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const float4 k4 = kr[c];
-            acc = fmaf(qs[c * 4 + 0], k4.x, acc);
-            acc = fmaf(qs[c * 4 + 1], k4.y, acc);
-            acc = fmaf(qs[c * 4 + 2], k4.z, acc);
-            acc = fmaf(qs[c * 4 + 3], k4.w, acc);
+        for (int u = 0; u < 8; ++u) {
+            const int j = base + 16 * u + kq;
+            const bool ok = j < n_keys;
+            const float4 t = *reinterpret_cast<const float4*>(kb + (long)(ok ? j : 0) * d);
+            kk[u] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        sc[j] = acc;
-        mx = fmaxf(mx, acc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = base + 16 * u + kq;
+            float acc = 0.f;
+            acc = fmaf(q4.x, kk[u].x, acc);
+            acc = fmaf(q4.y, kk[u].y, acc);
+            acc = fmaf(q4.z, kk[u].z, acc);
+            acc = fmaf(q4.w, kk[u].w, acc);
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            acc += __shfl_xor(acc, 8, 64);
+            if (j < n_keys) {
+                if (sub == 0) sc[j] = acc;
+                mx = fmaxf(mx, acc);
+            }
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sum = 0.f;
-    for (int j = lane; j < n_keys; j += 64) {
+    for (int j = tid; j < n_keys; j += 256) {
         const float e = expf(sc[j] - mx);
         sc[j] = e;
         sum += e;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
-    for (int j = lane; j < n_keys; j += 64) sc[j] = sc[j] / sum;
+    if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
-    float acc = 0.f;
-    for (int j = 0; j < n_keys; ++j) acc = fmaf(sc[j], vb[(long)j * d + lane], acc);
-    out[(long)row * d + head * 64 + lane] = acc;
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    for (int j = tid; j < n_keys; j += 256) sc[j] = sc[j] / sum;
+    __syncthreads();
+
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = wave * 4; base < n_keys; base += 16 * 8) {
+        float4 vv[8];
+        float ww[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = base + 16 * u + kq;
+            const bool ok = j < n_keys;
+            vv[u] = *reinterpret_cast<const float4*>(vb + (long)(ok ? j : 0) * d);
+            ww[u] = ok ? sc[j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            o.x = fmaf(ww[u], vv[u].x, o.x);
+            o.y = fmaf(ww[u], vv[u].y, o.y);
+            o.z = fmaf(ww[u], vv[u].z, o.z);
+            o.w = fmaf(ww[u], vv[u].w, o.w);
+        }
+    }
+    reinterpret_cast<float4*>(part)[(wave * 4 + kq) * 16 + sub] = o;
+    __syncthreads();
+    if (tid < 64) {
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc += part[s * 64 + tid];
+        out[(long)row * d + head * 64 + tid] = acc;
+    }
 }
 
 void launch_decoder_self_attention(const LaunchCtx& ctx, const float* qkv, const float* kc, const float* vc,
@@ -115,7 +166,7 @@ void launch_decoder_self_attention(const LaunchCtx& ctx, const float* qkv, const
                                    int ctx_len) {
     if (ctx_len > 448 + 64) throw std::invalid_argument("self-attention: context too long");
     KernelScope ks(ctx, "dec_self_attention");
-    hipLaunchKernelGGL(decoder_self_attention_kernel, dim3(n_rows * n_tok, n_head), dim3(64), 0, ctx.stream, qkv,
+    hipLaunchKernelGGL(decoder_self_attention_kernel, dim3(n_rows * n_tok, n_head), dim3(256), 0, ctx.stream, qkv,
                        kc, vc, out, n_tok, offset, d, ctx_len);
     WLK_HIP(hipGetLastError());
 }

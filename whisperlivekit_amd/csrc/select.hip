@@ -73,8 +73,10 @@ struct SelPartial {
     int i[kMaxTopK];
 };
 
-__global__ __launch_bounds__(256) void topk_stage1_kernel(const float* __restrict__ logits, int n_vocab, int k,
-                                                          SelPartial* __restrict__ parts) {
+__global__ __launch_bounds__(256) void topk_stage1_kernel(float* __restrict__ logits, int n_vocab, int k,
+                                                          SelPartial* __restrict__ parts, const int* __restrict__ adj_row,
+                                                          const int* __restrict__ adj_ids,
+                                                          const float* __restrict__ adj_deltas, int n_adj) {
     __shared__ float red[16];
     __shared__ float cand_v[4];
     __shared__ int cand_i[4];
@@ -84,7 +86,15 @@ __global__ __launch_bounds__(256) void topk_stage1_kernel(const float* __restric
     const int per = (n_vocab + kSelBlocks - 1) / kSelBlocks;
     const int lo = blockIdx.x * per;
     const int hi = min(n_vocab, lo + per);
-    const float* x = logits + (long)row * n_vocab;
+    float* x = logits + (long)row * n_vocab;
+    // logit adjustments that fall into this slice are applied here (each slice is owned by one
+    // workgroup, so a workgroup barrier is all the ordering that is needed); ids are unique per row
+    for (int i = tid; i < n_adj; i += 256) {
+        const int id = adj_ids[i];
+        const int r = adj_row[i];
+        if (id >= lo && id < hi && (r < 0 || r == row)) x[id] += adj_deltas[i];
+    }
+    __syncthreads();
     float mx = -INFINITY;
     for (int i = lo + tid; i < hi; i += 256) mx = fmaxf(mx, x[i]);
     mx = block_max(mx, red);
@@ -159,14 +169,15 @@ __global__ __launch_bounds__(64) void topk_stage2_kernel(const SelPartial* __res
     }
 }
 
-void launch_logsoftmax_topk(const LaunchCtx& ctx, const float* logits, int n_vocab, int n_rows, int k,
-                            float* top_vals, int* top_ids, void* scratch) {
+void launch_logsoftmax_topk(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, int k,
+                            float* top_vals, int* top_ids, void* scratch, const int* adj_row, const int* adj_ids,
+                            const float* adj_deltas, int n_adj) {
     if (k < 1 || k > kMaxTopK) throw std::invalid_argument("top-k: k must be in [1, 8]");
     SelPartial* parts = static_cast<SelPartial*>(scratch);
     {
         KernelScope ks(ctx, "sel_topk_stage1", 0.0, 4.0 * 3.0 * n_rows * (double)n_vocab);
         hipLaunchKernelGGL(topk_stage1_kernel, dim3(kSelBlocks, n_rows), dim3(256), 0, ctx.stream, logits, n_vocab, k,
-                           parts);
+                           parts, adj_row, adj_ids, adj_deltas, n_adj);
         WLK_HIP(hipGetLastError());
     }
     {
@@ -288,10 +299,93 @@ __global__ __launch_bounds__(256) void align_argmax_kernel(AlignArgs a) {
     if (tid == 0) a.frames[b] = besti[0] == 0x7fffffff ? 0 : besti[0];
 }
 
+// Both steps in one launch (one workgroup of 1024 threads per beam row, z-scores staged in LDS):
+// decode steps are a chain of dependent launches, so a launch saved is ~5 us saved.
+__global__ __launch_bounds__(1024) void align_fused_kernel(AlignArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float zs[];   // [n_align][T]
+    __shared__ float bestv[1024];
+    __shared__ int besti[1024];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int n = a.prefill_rows + a.n_single;
+    for (int i = tid; i < a.n_align * a.T; i += 1024) {
+        const int al = i / a.T, f = i - al * a.T;
+        const float* base = a.ring + ((long)(al * a.n_beam + b) * a.ring_rows) * a.T + f;
+        double sum = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < a.prefill_rows; ++r) sum += (double)base[(long)r * a.T];
+#pragma unroll 8
+        for (int r = 0; r < a.n_single; ++r) sum += (double)base[(long)(a.single_base + r) * a.T];
+        const double mean = sum / n;
+        double sq = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < a.prefill_rows; ++r) {
+            const double t = (double)base[(long)r * a.T] - mean;
+            sq += t * t;
+        }
+#pragma unroll 8
+        for (int r = 0; r < a.n_single; ++r) {
+            const double t = (double)base[(long)(a.single_base + r) * a.T] - mean;
+            sq += t * t;
+        }
+        const float stdv = (float)sqrt(sq / n);
+        zs[i] = (base[(long)a.newest_row * a.T] - (float)mean) / (stdv + 1e-8f);
+    }
+    __syncthreads();
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int f = tid; f < a.T; f += 1024) {
+        float acc = 0.f;
+        for (int al = 0; al < a.n_align; ++al) {
+            const float* z = zs + al * a.T;
+            float v[7];
+#pragma unroll
+            for (int o = -3; o <= 3; ++o) {
+                int idx = f + o;
+                if (idx < 0) idx = -idx;
+                if (idx >= a.T) idx = 2 * (a.T - 1) - idx;
+                v[o + 3] = z[idx];
+            }
+            acc += a.T > 3 ? median7(v[0], v[1], v[2], v[3], v[4], v[5], v[6]) : z[f];
+        }
+        const float m = acc / (float)a.n_align;
+        a.attn_last[(long)b * a.T + f] = m;
+        if (f < a.content_len && (m > bv || (m == bv && f < bi))) { bv = m; bi = f; }
+    }
+    bestv[tid] = bv;
+    besti[tid] = bi;
+    __syncthreads();
+    for (int s = 512; s >= 1; s >>= 1) {
+        if (tid < s) {
+            const float ov = bestv[tid + s];
+            const int oi = besti[tid + s];
+            if (ov > bestv[tid] || (ov == bestv[tid] && oi < besti[tid])) { bestv[tid] = ov; besti[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) a.frames[b] = besti[0] == 0x7fffffff ? 0 : besti[0];
+}
+
 void launch_alignatt(const LaunchCtx& ctx, const AlignArgs& a) {
     if (a.n_align <= 0) {
         WLK_HIP(hipMemsetAsync(a.frames, 0, sizeof(int) * a.n_beam, ctx.stream));
         WLK_HIP(hipMemsetAsync(a.attn_last, 0, sizeof(float) * a.n_beam * a.T, ctx.stream));
+        return;
+    }
+    const size_t lds = (size_t)a.n_align * a.T * sizeof(float);
+    if (lds + 8192 <= 160 * 1024) {
+        static bool attr_set[64] = {};
+        int dev = 0;
+        WLK_HIP(hipGetDevice(&dev));
+        if (dev < 64 && !attr_set[dev]) {
+            WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(align_fused_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_set[dev] = true;
+        }
+        const int n = a.prefill_rows + a.n_single;
+        KernelScope ks(ctx, "align_fused", 0.0, 4.0 * 2.0 * n * (double)a.n_align * a.T * a.n_beam);
+        hipLaunchKernelGGL(align_fused_kernel, dim3(a.n_beam), dim3(1024), lds, ctx.stream, a);
+        WLK_HIP(hipGetLastError());
         return;
     }
     {
