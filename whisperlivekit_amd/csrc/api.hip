@@ -243,7 +243,8 @@ struct wlk_session {
     int last_rows = 0, last_ntok = 0;
     float *hsel = nullptr, *logits_last = nullptr, *logits_sot = nullptr;
     bool have_sot = false;
-    int *ring_row = nullptr, *beam_of_row = nullptr, *d_offset = nullptr;
+    int* step_in = nullptr;      // [tokens max_rows | ring_row max_rows | beam_of_row max_rows | offset]: ONE H2D per decode
+    int *ring_row = nullptr, *beam_of_row = nullptr, *d_offset = nullptr;   // views into step_in
     float* ring = nullptr;
     int ring_rows = 0;
     float *z = nullptr, *attn_last = nullptr;
@@ -251,8 +252,7 @@ struct wlk_session {
     float* xsplit = nullptr;    // scratch of the split cross-attention (decode steps)
 
     // select scratch (device) + pinned host staging
-    int *adj_row = nullptr, *adj_ids = nullptr, *src_rows = nullptr;
-    float* adj_deltas = nullptr;
+    int *adj_row = nullptr, *src_rows = nullptr;   // adj_row: packed [rows | ids | deltas] of the current call
     float* top_vals = nullptr;
     void* topk_scratch = nullptr;
     int *top_ids = nullptr, *frames = nullptr;
@@ -483,7 +483,8 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
 
         s->max_rows = beam * (int)ctx;
         const size_t R = s->max_rows;
-        s->tokens_dev = dev_alloc<int>(R);
+        s->step_in = dev_alloc<int>(3 * R + 4);
+        s->tokens_dev = s->step_in;
         s->dx = dev_alloc<float>(R * d);
         s->dh = dev_alloc<float>(R * d);
         s->dqkv = dev_alloc<float>(R * 3 * d);
@@ -496,22 +497,20 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         s->hsel = dev_alloc<float>((size_t)2 * beam * d);
         s->logits_last = dev_alloc<float>((size_t)beam * V);
         s->logits_sot = dev_alloc<float>((size_t)beam * V);
-        s->ring_row = dev_alloc<int>(R);
-        s->beam_of_row = dev_alloc<int>(R);
-        s->d_offset = dev_alloc<int>(4);
+        s->ring_row = s->step_in + R;
+        s->beam_of_row = s->step_in + 2 * R;
+        s->d_offset = s->step_in + 3 * R;
         s->ring_rows = (int)ctx + kAlignWindow;
         if (m->n_align > 0) s->ring = dev_alloc<float>((size_t)m->n_align * beam * s->ring_rows * T);
         s->xsplit = dev_alloc<float>(cross_split_scratch_floats(8, D.n_text_head, (int)T));
         s->z = dev_alloc<float>((size_t)beam * std::max(m->n_align, 1) * T);
         s->attn_last = dev_alloc_zero<float>((size_t)beam * T, st);
-        s->adj_row = dev_alloc<int>(wlk_session::kAdjCap);
-        s->adj_ids = dev_alloc<int>(wlk_session::kAdjCap);
-        s->adj_deltas = dev_alloc<float>(wlk_session::kAdjCap);
+        s->adj_row = dev_alloc<int>(3 * wlk_session::kAdjCap);   // [rows n | ids n | deltas n] packed per call
         s->src_rows = dev_alloc<int>(8);
-        s->top_vals = dev_alloc<float>((size_t)beam * 8);
+        s->top_vals = dev_alloc<float>((size_t)beam * 17);       // [log-probs B*8 | ids B*8 | frames B]: ONE D2H
+        s->top_ids = reinterpret_cast<int*>(s->top_vals) + (size_t)beam * 8;
+        s->frames = s->top_ids + (size_t)beam * 8;
         WLK_HIP(hipMalloc(&s->topk_scratch, topk_scratch_bytes(beam)));
-        s->top_ids = dev_alloc<int>((size_t)beam * 8);
-        s->frames = dev_alloc<int>(beam);
         s->probs = dev_alloc<float>(beam);
         WLK_HIP(hipHostMalloc(&s->pinned, wlk_session::kPinnedBytes, hipHostMallocDefault));
         WLK_HIP(hipStreamSynchronize(st));
@@ -527,10 +526,10 @@ int wlk_session_destroy(wlk_session* s) {
     float* fl[] = {s->audio[0], s->audio[1], s->logmel, s->frame_max, s->mel_t, s->x1p, s->ex, s->eh, s->eqkv,
                    s->eatt, s->emlp, s->enc_out, s->cross_kv, s->dx, s->dh, s->dqkv, s->datt, s->dq, s->dmlp,
                    s->kcache[0], s->kcache[1], s->vcache[0], s->vcache[1], s->hsel, s->logits_last, s->logits_sot,
-                   s->ring, s->z, s->attn_last, s->qk_debug, s->xsplit, s->adj_deltas, s->top_vals, s->probs};
+                   s->ring, s->z, s->attn_last, s->qk_debug, s->xsplit, s->top_vals, s->probs};
     for (float* p : fl)
         if (p) (void)hipFree(p);
-    int* il[] = {s->d_offset, s->tokens_dev, s->ring_row, s->beam_of_row, s->adj_row, s->adj_ids, s->src_rows, s->top_ids, s->frames};
+    int* il[] = {s->step_in, s->adj_row, s->src_rows};
     for (int* p : il)
         if (p) (void)hipFree(p);
     for (auto& e : s->step_exec)
@@ -727,11 +726,9 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
     const int ctx_len = D.n_text_ctx;
     const int R = n_rows * n_tok;
     const int d = D.n_text_state, T = D.n_audio_ctx, H = D.n_text_head, V = D.n_vocab;
-    const int* stage = static_cast<const int*>(s->pinned);
-    WLK_HIP(hipMemcpyAsync(s->tokens_dev, stage, R * sizeof(int), hipMemcpyHostToDevice, s->stream));
-    WLK_HIP(hipMemcpyAsync(s->ring_row, stage + R, R * sizeof(int), hipMemcpyHostToDevice, s->stream));
-    WLK_HIP(hipMemcpyAsync(s->beam_of_row, stage + 2 * R, R * sizeof(int), hipMemcpyHostToDevice, s->stream));
-    WLK_HIP(hipMemcpyAsync(s->d_offset, stage + 3 * R, sizeof(int), hipMemcpyHostToDevice, s->stream));
+    // one host->device copy: [tokens | alignment-window row | beam of row | cache offset]
+    WLK_HIP(hipMemcpyAsync(s->step_in, s->pinned, (size_t)(3 * s->max_rows + 1) * sizeof(int), hipMemcpyHostToDevice,
+                           s->stream));
     // decode steps (<= 8 rows): LayerNorm and the KV-cache append are fused into the weight-streaming
     // GEMV launches; prefill keeps them as separate kernels in front of the MFMA GEMMs
     const bool fused = gemv_applicable(R, d) && n_tok == 1;
@@ -860,21 +857,22 @@ int wlk_decode(wlk_session* s, const int64_t* tokens, int n_rows, int n_tok, int
         const int ctx_len = D.n_text_ctx;
         if (offset + n_tok > ctx_len) return fail(WLK_ERR_CAPACITY, "text context exceeded");
         const int R = n_rows * n_tok;
-        if ((size_t)(R * 3 + 4) * sizeof(int) > wlk_session::kPinnedBytes) return fail(WLK_ERR_CAPACITY, "too many rows");
+        if ((size_t)(s->max_rows * 3 + 4) * sizeof(int) > 65536) return fail(WLK_ERR_CAPACITY, "too many rows");
 
         // staging block (pinned): tokens as int32 | alignment-window row of each query row | beam of row | offset
         WLK_HIP(hipStreamSynchronize(s->stream));  // the previous call's copies out of this block are done
         int* stage = static_cast<int*>(s->pinned);
         const int slot_row = first ? 0 : ctx_len + ((s->n_steps - 1) % kAlignWindow);
+        const int MR = s->max_rows;
         for (int b = 0; b < n_rows; ++b)
             for (int p = 0; p < n_tok; ++p) {
                 const int64_t t = tokens[(size_t)b * n_tok + p];
                 if (t < 0 || t >= D.n_vocab) return fail(WLK_ERR_ARG, "token id out of range");
                 stage[b * n_tok + p] = (int)t;
-                stage[R + b * n_tok + p] = first ? p : slot_row;
-                stage[2 * R + b * n_tok + p] = b;
+                stage[MR + b * n_tok + p] = first ? p : slot_row;
+                stage[2 * MR + b * n_tok + p] = b;
             }
-        stage[3 * R] = offset;
+        stage[3 * MR] = offset;
 
         const bool graphable = !first && n_tok == 1 && gemv_applicable(R, D.n_text_state) && !s->debug &&
                                !s->prof_on && s->use_graph;
@@ -940,18 +938,20 @@ int wlk_select(wlk_session* s, const int32_t* adj_row, const int32_t* adj_ids, c
         WLK_HIP(hipSetDevice(m->device));
         const LaunchCtx c = s->ctx();
         const int B = s->beam, V = D.n_vocab;
+        int* adj_rows_d = s->adj_row;
+        int* adj_ids_d = s->adj_row + n_adj;
+        float* adj_deltas_d = reinterpret_cast<float*>(s->adj_row + 2 * n_adj);
         if (n_adj > 0) {
-            WLK_HIP(hipStreamSynchronize(s->stream));
-            char* st = static_cast<char*>(s->pinned);
+            // the adjustment block has its own pinned region (offset 128 KiB) so it never races with the
+            // decode staging block that a still-running graph replay may be reading
+            char* st = static_cast<char*>(s->pinned) + 131072;
             std::memcpy(st, adj_row, n_adj * sizeof(int));
             std::memcpy(st + n_adj * 4, adj_ids, n_adj * sizeof(int));
             std::memcpy(st + n_adj * 8, adj_deltas, n_adj * sizeof(float));
-            WLK_HIP(hipMemcpyAsync(s->adj_row, st, n_adj * 4, hipMemcpyHostToDevice, s->stream));
-            WLK_HIP(hipMemcpyAsync(s->adj_ids, st + n_adj * 4, n_adj * 4, hipMemcpyHostToDevice, s->stream));
-            WLK_HIP(hipMemcpyAsync(s->adj_deltas, st + n_adj * 8, n_adj * 4, hipMemcpyHostToDevice, s->stream));
+            WLK_HIP(hipMemcpyAsync(s->adj_row, st, (size_t)n_adj * 12, hipMemcpyHostToDevice, s->stream));
         }
-        launch_logsoftmax_topk(c, s->logits_last, V, B, k, s->top_vals, s->top_ids, s->topk_scratch, s->adj_row,
-                               s->adj_ids, s->adj_deltas, n_adj);
+        launch_logsoftmax_topk(c, s->logits_last, V, B, k, s->top_vals, s->top_ids, s->topk_scratch, adj_rows_d,
+                               adj_ids_d, adj_deltas_d, n_adj);
 
         AlignArgs a;
         a.ring = s->ring; a.n_align = m->n_align; a.n_beam = B; a.ring_rows = s->ring_rows; a.T = D.n_audio_ctx;
@@ -963,15 +963,15 @@ int wlk_select(wlk_session* s, const int32_t* adj_row, const int32_t* adj_ids, c
         a.z = s->z; a.attn_last = s->attn_last; a.frames = s->frames;
         launch_alignatt(c, a);
 
-        // one readback: [top_vals B*k | top_ids B*k | frames B]
+        // one readback of the packed result block [log-probs B*8 | ids B*8 | frames B]
         char* out = static_cast<char*>(s->pinned) + 65536;
-        WLK_HIP(hipMemcpyAsync(out, s->top_vals, B * k * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-        WLK_HIP(hipMemcpyAsync(out + 1024, s->top_ids, B * k * sizeof(int), hipMemcpyDeviceToHost, s->stream));
-        WLK_HIP(hipMemcpyAsync(out + 2048, s->frames, B * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        WLK_HIP(hipMemcpyAsync(out, s->top_vals, (size_t)B * 17 * 4, hipMemcpyDeviceToHost, s->stream));
         WLK_HIP(hipStreamSynchronize(s->stream));
-        std::memcpy(top_logprobs_host, out, B * k * sizeof(float));
-        std::memcpy(top_ids_host, out + 1024, B * k * sizeof(int));
-        std::memcpy(frames_host, out + 2048, B * sizeof(int));
+        for (int b = 0; b < B; ++b) {
+            std::memcpy(top_logprobs_host + (size_t)b * k, out + (size_t)b * k * 4, k * sizeof(float));
+            std::memcpy(top_ids_host + (size_t)b * k, out + (size_t)B * 32 + (size_t)b * k * 4, k * sizeof(int));
+        }
+        std::memcpy(frames_host, out + (size_t)B * 64, B * sizeof(int));
         return WLK_OK;
     });
 }

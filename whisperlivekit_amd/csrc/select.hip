@@ -218,28 +218,37 @@ void launch_token_prob(const LaunchCtx& ctx, const float* logits, int n_vocab, i
 // (torch.std_mean(unbiased=False) accumulates in double on CPU), then the z-score of the newest row.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void align_zscore_kernel(AlignArgs a) {
-    const int f = blockIdx.x * 256 + threadIdx.x;
+    // 64 frame columns x 4 row groups per workgroup: the window rows (up to 448 + 15) are walked by
+    // four threads per column in parallel and folded through LDS - the loop is latency-bound, so
+    // parallel rows matter more than anything else here
+    __shared__ double red[4][64];
+    const int fx = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int f = blockIdx.x * 64 + fx;
     const int al = blockIdx.y, b = blockIdx.z;
-    if (f >= a.T) return;
-    const float* base = a.ring + ((long)(al * a.n_beam + b) * a.ring_rows) * a.T + f;
+    const bool ok = f < a.T;
+    const float* base = a.ring + ((long)(al * a.n_beam + b) * a.ring_rows) * a.T + (ok ? f : 0);
     const int n = a.prefill_rows + a.n_single;
+    auto row_of = [&](int i) { return i < a.prefill_rows ? i : a.single_base + (i - a.prefill_rows); };
     double sum = 0.0;
-    for (int r = 0; r < a.prefill_rows; ++r) sum += (double)base[(long)r * a.T];
-    for (int r = 0; r < a.n_single; ++r) sum += (double)base[(long)(a.single_base + r) * a.T];
-    const double mean = sum / n;
+#pragma unroll 4
+    for (int i = rg; i < n; i += 4) sum += (double)base[(long)row_of(i) * a.T];
+    red[rg][fx] = sum;
+    __syncthreads();
+    const double mean = (red[0][fx] + red[1][fx] + red[2][fx] + red[3][fx]) / n;
+    __syncthreads();
     double sq = 0.0;
-    for (int r = 0; r < a.prefill_rows; ++r) {
-        const double t = (double)base[(long)r * a.T] - mean;
+#pragma unroll 4
+    for (int i = rg; i < n; i += 4) {
+        const double t = (double)base[(long)row_of(i) * a.T] - mean;
         sq += t * t;
     }
-    for (int r = 0; r < a.n_single; ++r) {
-        const double t = (double)base[(long)(a.single_base + r) * a.T] - mean;
-        sq += t * t;
+    red[rg][fx] = sq;
+    __syncthreads();
+    if (rg == 0 && ok) {
+        const float stdv = (float)sqrt((red[0][fx] + red[1][fx] + red[2][fx] + red[3][fx]) / n);
+        const float w = base[(long)a.newest_row * a.T];
+        a.z[((long)b * a.n_align + al) * a.T + f] = (w - (float)mean) / (stdv + 1e-8f);
     }
-    const float stdv = (float)sqrt(sq / n);
-    const float meanf = (float)mean;
-    const float w = base[(long)a.newest_row * a.T];
-    a.z[((long)b * a.n_align + al) * a.T + f] = (w - meanf) / (stdv + 1e-8f);
 }
 
 __device__ __forceinline__ float median7(float v0, float v1, float v2, float v3, float v4, float v5, float v6) {
@@ -299,38 +308,16 @@ __global__ __launch_bounds__(256) void align_argmax_kernel(AlignArgs a) {
     if (tid == 0) a.frames[b] = besti[0] == 0x7fffffff ? 0 : besti[0];
 }
 
-// Both steps in one launch (one workgroup of 1024 threads per beam row, z-scores staged in LDS):
-// decode steps are a chain of dependent launches, so a launch saved is ~5 us saved.
-__global__ __launch_bounds__(1024) void align_fused_kernel(AlignArgs a) {
+// Step 2 variant for the common case (z of all alignment heads fits LDS): 1024 threads stage z with
+// coalesced loads once, then medians / head mean / arg-max run out of LDS.
+__global__ __launch_bounds__(1024) void align_argmax_lds_kernel(AlignArgs a) {
     extern __shared__ __attribute__((aligned(16))) float zs[];   // [n_align][T]
     __shared__ float bestv[1024];
     __shared__ int besti[1024];
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
-    const int n = a.prefill_rows + a.n_single;
-    for (int i = tid; i < a.n_align * a.T; i += 1024) {
-        const int al = i / a.T, f = i - al * a.T;
-        const float* base = a.ring + ((long)(al * a.n_beam + b) * a.ring_rows) * a.T + f;
-        double sum = 0.0;
-#pragma unroll 8
-        for (int r = 0; r < a.prefill_rows; ++r) sum += (double)base[(long)r * a.T];
-#pragma unroll 8
-        for (int r = 0; r < a.n_single; ++r) sum += (double)base[(long)(a.single_base + r) * a.T];
-        const double mean = sum / n;
-        double sq = 0.0;
-#pragma unroll 8
-        for (int r = 0; r < a.prefill_rows; ++r) {
-            const double t = (double)base[(long)r * a.T] - mean;
-            sq += t * t;
-        }
-#pragma unroll 8
-        for (int r = 0; r < a.n_single; ++r) {
-            const double t = (double)base[(long)(a.single_base + r) * a.T] - mean;
-            sq += t * t;
-        }
-        const float stdv = (float)sqrt(sq / n);
-        zs[i] = (base[(long)a.newest_row * a.T] - (float)mean) / (stdv + 1e-8f);
-    }
+    const float* zb = a.z + (long)b * a.n_align * a.T;
+    for (int i = tid; i < a.n_align * a.T; i += 1024) zs[i] = zb[i];
     __syncthreads();
     float bv = -INFINITY;
     int bi = 0x7fffffff;
@@ -372,33 +359,29 @@ void launch_alignatt(const LaunchCtx& ctx, const AlignArgs& a) {
         WLK_HIP(hipMemsetAsync(a.attn_last, 0, sizeof(float) * a.n_beam * a.T, ctx.stream));
         return;
     }
+    {
+        const int n = a.prefill_rows + a.n_single;
+        KernelScope ks(ctx, "align_zscore", 0.0, 4.0 * 2.0 * n * (double)a.n_align * a.T * a.n_beam);
+        hipLaunchKernelGGL(align_zscore_kernel, dim3((a.T + 63) / 64, a.n_align, a.n_beam), dim3(256), 0,
+                           ctx.stream, a);
+        WLK_HIP(hipGetLastError());
+    }
     const size_t lds = (size_t)a.n_align * a.T * sizeof(float);
-    if (lds + 8192 <= 160 * 1024) {
+    KernelScope ks(ctx, "align_argmax");
+    if (lds + 8192 + 1024 <= 150 * 1024) {
         static bool attr_set[64] = {};
         int dev = 0;
         WLK_HIP(hipGetDevice(&dev));
         if (dev < 64 && !attr_set[dev]) {
-            WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(align_fused_kernel),
+            WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(align_argmax_lds_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             attr_set[dev] = true;
         }
-        const int n = a.prefill_rows + a.n_single;
-        KernelScope ks(ctx, "align_fused", 0.0, 4.0 * 2.0 * n * (double)a.n_align * a.T * a.n_beam);
-        hipLaunchKernelGGL(align_fused_kernel, dim3(a.n_beam), dim3(1024), lds, ctx.stream, a);
-        WLK_HIP(hipGetLastError());
-        return;
-    }
-    {
-        KernelScope ks(ctx, "align_zscore");
-        hipLaunchKernelGGL(align_zscore_kernel, dim3((a.T + 255) / 256, a.n_align, a.n_beam), dim3(256), 0,
-                           ctx.stream, a);
-        WLK_HIP(hipGetLastError());
-    }
-    {
-        KernelScope ks(ctx, "align_argmax");
+        hipLaunchKernelGGL(align_argmax_lds_kernel, dim3(a.n_beam), dim3(1024), lds, ctx.stream, a);
+    } else {
         hipLaunchKernelGGL(align_argmax_kernel, dim3(a.n_beam), dim3(256), 0, ctx.stream, a);
-        WLK_HIP(hipGetLastError());
     }
+    WLK_HIP(hipGetLastError());
 }
 
 }  // namespace wlk
