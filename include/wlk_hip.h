@@ -140,6 +140,9 @@ const char* wlk_diag_last_error(void);
 int wlk_diag_linear(const float* a, int64_t lda, int64_t a_floats, const float* w, const float* bias,
                     const float* r, int64_t ldr, int m, int n, int k, int flags, float scale, int scale_cols,
                     int force_gemv, float* c);
+/* c[m,n] = LayerNorm(a[m,k]; gamma, beta, eps 1e-5) . w[n,k]^T + bias  (the fused pre-LN projections) */
+int wlk_diag_linear_ln(const float* a, const float* w, const float* bias, const float* gamma, const float* beta,
+                       int m, int n, int k, int force_gemv, float* c);
 int wlk_diag_layernorm(const float* x, const float* gamma, const float* beta, int rows, int d, float* y);
 /* qkv [t, 3d] with q and k pre-scaled -> softmax(q k^T) v per 64-wide head, out [t, d] */
 int wlk_diag_encoder_attention(const float* qkv, int t, int d, int n_head, float* out);

@@ -105,6 +105,24 @@ def test_gemv_matches_torch(lib, M, N, K):
     assert err <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("M,N,K,gemv", [(1500, 1536, 512, 0), (61, 512, 512, 0), (33, 2048, 384, 0), (1, 1536, 512, 1),
+                                        (3, 512, 128, 1), (8, 2048, 512, 1)])
+def test_fused_layernorm_linear_matches_torch(lib, M, N, K, gemv):
+    rng = np.random.default_rng(6)
+    a = (rng.standard_normal((M, K)) * 2 + 0.5).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias, gamma, beta = (rng.standard_normal(n).astype(np.float32) for n in (N, K, K))
+    c = np.empty((M, N), np.float32)
+    assert lib.wlk_diag_linear_ln(vp(a), vp(w), vp(bias), vp(gamma), vp(beta), M, N, K, gemv, vp(c)) == 0, \
+        lib.wlk_diag_last_error()
+    h = torch.nn.functional.layer_norm(torch.from_numpy(a).double(), (K,), torch.from_numpy(gamma).double(),
+                                       torch.from_numpy(beta).double())
+    ref = h @ torch.from_numpy(w).double().T + torch.from_numpy(bias).double()
+    err = float((torch.from_numpy(c).double() - ref).abs().max())
+    report(f"ln_linear_{M}x{N}x{K}_{'gemv' if gemv else 'gemm'}", max_abs_err=err)
+    assert err <= 3e-5 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("rows,d", [(1500, 512), (7, 128), (3, 384), (1, 1280)])
 def test_layernorm_matches_torch(lib, rows, d):
     rng = np.random.default_rng(3)

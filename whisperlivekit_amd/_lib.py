@@ -62,6 +62,7 @@ def _declare(lib: C.CDLL) -> None:
         "wlk_diag_last_error": (C.c_char_p, []),
         "wlk_diag_linear": (cint, [p, C.c_int64, C.c_int64, p, p, p, C.c_int64, cint, cint, cint, cint, C.c_float,
                                    cint, cint, p]),
+        "wlk_diag_linear_ln": (cint, [p, p, p, p, p, cint, cint, cint, cint, p]),
         "wlk_diag_layernorm": (cint, [p, p, p, cint, cint, p]),
         "wlk_diag_encoder_attention": (cint, [p, cint, cint, cint, p]),
     }
@@ -78,7 +79,7 @@ EXPORTED_SYMBOLS = (
     "wlk_session_destroy", "wlk_session_set_debug", "wlk_audio_append", "wlk_audio_append_zeros",
     "wlk_audio_drop_front", "wlk_audio_clear", "wlk_audio_len", "wlk_encode", "wlk_decode",
     "wlk_no_speech_prob", "wlk_select", "wlk_kv_reorder", "wlk_sync", "wlk_export", "wlk_prof_begin",
-    "wlk_prof_end", "wlk_diag_last_error", "wlk_diag_linear", "wlk_diag_layernorm", "wlk_diag_encoder_attention",
+    "wlk_prof_end", "wlk_diag_last_error", "wlk_diag_linear", "wlk_diag_linear_ln", "wlk_diag_layernorm", "wlk_diag_encoder_attention",
 )
 
 

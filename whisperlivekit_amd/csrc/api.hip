@@ -250,6 +250,8 @@ struct wlk_session {
     float *z = nullptr, *attn_last = nullptr;
     float* qk_debug = nullptr;  // [L][max_rows][H][T]
     float* xsplit = nullptr;    // scratch of the split cross-attention (decode steps)
+    float* fsplit = nullptr;    // scratch of the key-split flash attention (decoder prefill)
+    static constexpr int kFlashSplits = 6;
 
     // select scratch (device) + pinned host staging
     int *adj_row = nullptr, *src_rows = nullptr;   // adj_row: packed [rows | ids | deltas] of the current call
@@ -503,6 +505,7 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         s->ring_rows = (int)ctx + kAlignWindow;
         if (m->n_align > 0) s->ring = dev_alloc<float>((size_t)m->n_align * beam * s->ring_rows * T);
         s->xsplit = dev_alloc<float>(cross_split_scratch_floats(8, D.n_text_head, (int)T));
+        s->fsplit = dev_alloc<float>(flash_split_scratch_floats(s->max_rows, D.n_text_head, wlk_session::kFlashSplits));
         s->z = dev_alloc<float>((size_t)beam * std::max(m->n_align, 1) * T);
         s->attn_last = dev_alloc_zero<float>((size_t)beam * T, st);
         s->adj_row = dev_alloc<int>(3 * wlk_session::kAdjCap);   // [rows n | ids n | deltas n] packed per call
@@ -526,7 +529,7 @@ int wlk_session_destroy(wlk_session* s) {
     float* fl[] = {s->audio[0], s->audio[1], s->logmel, s->frame_max, s->mel_t, s->x1p, s->ex, s->eh, s->eqkv,
                    s->eatt, s->emlp, s->enc_out, s->cross_kv, s->dx, s->dh, s->dqkv, s->datt, s->dq, s->dmlp,
                    s->kcache[0], s->kcache[1], s->vcache[0], s->vcache[1], s->hsel, s->logits_last, s->logits_sot,
-                   s->ring, s->z, s->attn_last, s->qk_debug, s->xsplit, s->top_vals, s->probs};
+                   s->ring, s->z, s->attn_last, s->qk_debug, s->xsplit, s->fsplit, s->top_vals, s->probs};
     for (float* p : fl)
         if (p) (void)hipFree(p);
     int* il[] = {s->step_in, s->adj_row, s->src_rows};
@@ -628,19 +631,14 @@ int wlk_audio_len(wlk_session* s, int* n) {
 }
 
 // ---- encode ---------------------------------------------------------------------------------
-static void transformer_mlp(const LaunchCtx& c, const LayerW& L, float* x, float* h, float* mlp, int rows, int d,
-                            const char* t_ln, const char* t_fc1, const char* t_fc2, bool fuse_ln = false) {
+// pre-LN MLP block: x += fc2(gelu(fc1(LN(x)))); the LayerNorm is folded into the fc1 launch (GEMM: per-row
+// statistics in the workgroup prologue; GEMV: in the LDS staging of the activation rows)
+static void transformer_mlp(const LaunchCtx& c, const LayerW& L, float* x, float* mlp, int rows, int d,
+                            const char* t_fc1, const char* t_fc2) {
     GemmArgs g;
-    g.lda = d; g.W = L.fc1w; g.bias = L.fc1b; g.C = mlp; g.ldc = 4 * d; g.M = rows; g.N = 4 * d; g.K = d;
-    g.flags = kGemmGelu;
-    if (fuse_ln) {
-        g.A = x; g.ln_gamma = L.ln2w; g.ln_beta = L.ln2b;
-        launch_gemv(c, g, "dec_ln2_fc1");
-    } else {
-        launch_layernorm(c, x, d, L.ln2w, L.ln2b, h, d, rows, d, t_ln);
-        g.A = h;
-        launch_linear(c, g, t_fc1);
-    }
+    g.A = x; g.lda = d; g.W = L.fc1w; g.bias = L.fc1b; g.C = mlp; g.ldc = 4 * d; g.M = rows; g.N = 4 * d; g.K = d;
+    g.flags = kGemmGelu; g.ln_gamma = L.ln2w; g.ln_beta = L.ln2b;
+    launch_linear(c, g, t_fc1);
     GemmArgs g2;
     g2.A = mlp; g2.lda = 4 * d; g2.W = L.fc2w; g2.bias = L.fc2b; g2.C = x; g2.ldc = d; g2.M = rows; g2.N = d;
     g2.K = 4 * d; g2.flags = kGemmResidual; g2.R = x; g2.ldr = d;
@@ -686,17 +684,16 @@ int wlk_encode(wlk_session* s, int32_t* content_mel_len) {
         const float scale = std::pow((float)kHeadDim, -0.25f);
         for (int i = 0; i < D.n_audio_layer; ++i) {
             const LayerW& L = m->enc_layers[i];
-            launch_layernorm(c, s->ex, d, L.ln1w, L.ln1b, s->eh, d, T, d, "enc_ln1");
             GemmArgs g;
-            g.A = s->eh; g.lda = d; g.W = L.qkvw; g.bias = L.qkvb; g.C = s->eqkv; g.ldc = 3 * d; g.M = T; g.N = 3 * d;
+            g.A = s->ex; g.lda = d; g.ln_gamma = L.ln1w; g.ln_beta = L.ln1b; g.W = L.qkvw; g.bias = L.qkvb; g.C = s->eqkv; g.ldc = 3 * d; g.M = T; g.N = 3 * d;
             g.K = d; g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = 2 * d;
-            launch_gemm(c, g, "enc_qkv");
+            launch_gemm(c, g, "enc_ln1_qkv");
             launch_encoder_attention(c, s->eqkv, s->eatt, T, d, D.n_audio_head);
             GemmArgs o;
             o.A = s->eatt; o.lda = d; o.W = L.outw; o.bias = L.outb; o.C = s->ex; o.ldc = d; o.M = T; o.N = d; o.K = d;
             o.flags = kGemmResidual; o.R = s->ex; o.ldr = d;
             launch_gemm(c, o, "enc_out");
-            transformer_mlp(c, L, s->ex, s->eh, s->emlp, T, d, "enc_ln2", "enc_fc1", "enc_fc2");
+            transformer_mlp(c, L, s->ex, s->emlp, T, d, "enc_ln2_fc1", "enc_fc2");
         }
         launch_layernorm(c, s->ex, d, m->w("enc.ln_post.w"), m->w("enc.ln_post.b"), s->enc_out, d, T, d, "enc_ln_post");
         for (int i = 0; i < D.n_text_layer; ++i) {  // cross-attention K (scaled) and V of every decoder layer
@@ -748,9 +745,8 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
             g.kcache = kc; g.vcache = vc; g.kv_pos = s->d_offset; g.kv_d = d; g.kv_ctx = ctx_len;
             launch_gemv(c, g, "dec_ln1_qkv_kv");
         } else {
-            launch_layernorm(c, s->dx, d, L.ln1w, L.ln1b, s->dh, d, R, d, "dec_ln1");
-            g.A = s->dh;
-            launch_linear(c, g, "dec_qkv");
+            g.A = s->dx; g.ln_gamma = L.ln1w; g.ln_beta = L.ln1b;
+            launch_linear(c, g, "dec_ln1_qkv");
             launch_kv_append(c, s->dqkv, kc, vc, n_rows, n_tok, s->d_offset, d, ctx_len);
         }
         launch_decoder_self_attention(c, s->dqkv, kc, vc, s->datt, n_rows, n_tok, s->d_offset, d, H, ctx_len);
@@ -766,9 +762,8 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
             q.A = s->dx; q.ln_gamma = L.lnxw; q.ln_beta = L.lnxb;
             launch_gemv(c, q, "dec_lnx_xq");
         } else {
-            launch_layernorm(c, s->dx, d, L.lnxw, L.lnxb, s->dh, d, R, d, "dec_lnx");
-            q.A = s->dh;
-            launch_linear(c, q, "dec_xq");
+            q.A = s->dx; q.ln_gamma = L.lnxw; q.ln_beta = L.lnxb;
+            launch_linear(c, q, "dec_lnx_xq");
         }
         const int* ranks_l = m->n_align > 0 ? m->head_rank + (size_t)i * H : nullptr;
         if (R > 8 && !s->debug) {
@@ -779,6 +774,12 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
             fa.out = s->datt; fa.ldo = d; fa.Tq = R; fa.Tk = T; fa.n_head = H;
             fa.head_rank = ranks_l; fa.ring = s->ring; fa.ring_row = s->ring_row;
             fa.beam_of_row = s->beam_of_row; fa.ring_rows = s->ring_rows; fa.n_beam = s->beam;
+            if (((R + 31) / 32) * H < 256) {   // few query tiles: spread the 1500 keys over more workgroups
+                fa.k_splits = wlk_session::kFlashSplits;
+                fa.part_o = s->fsplit;
+                fa.part_m = fa.part_o + (size_t)s->max_rows * H * fa.k_splits * 64;
+                fa.part_l = fa.part_m + (size_t)s->max_rows * H * fa.k_splits;
+            }
             launch_prefill_cross_attention(c, fa);
             launch_ring_softmax(c, s->ring, s->ring_row, s->beam_of_row, m->layer_ranks + (size_t)i * H,
                                 m->layer_rank_count[i], R, s->ring_rows, s->beam, T);
@@ -811,7 +812,7 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
         xo.A = s->datt; xo.lda = d; xo.W = L.xoutw; xo.bias = L.xoutb; xo.C = s->dx; xo.ldc = d; xo.M = R; xo.N = d;
         xo.K = d; xo.flags = kGemmResidual; xo.R = s->dx; xo.ldr = d;
         launch_linear(c, xo, "dec_xout");
-        transformer_mlp(c, L, s->dx, s->dh, s->dmlp, R, d, "dec_ln2", "dec_fc1", "dec_fc2", fused);
+        transformer_mlp(c, L, s->dx, s->dmlp, R, d, "dec_ln2_fc1", "dec_fc2");
     }
     // final LayerNorm + vocabulary projection only for the rows the policy reads
     GemmArgs lg;

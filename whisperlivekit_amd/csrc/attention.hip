@@ -44,7 +44,10 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int head = blockIdx.x % n_head;       // head == XCD for 8 heads: K/V of a head stay in one L2
-    const int q0 = (blockIdx.x / n_head) * QT;
+    const int q_tiles = (a.Tq + QT - 1) / QT;
+    const int qt_idx = (blockIdx.x / n_head) % q_tiles;
+    const int ks = blockIdx.x / (n_head * q_tiles);   // key split index (0 when a.k_splits == 1)
+    const int q0 = qt_idx * QT;
     const long ld = a.ldkv;
     const int half = lane >> 5;
     const int lq = lane & 31;
@@ -101,12 +104,16 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
         }
     };
 
-    const int n_iter = (T + NWAVE * KT - 1) / (NWAVE * KT);
-    fetch(0);
+    // key range of this workgroup: iterations [it_lo, it_hi) of 128 keys each
+    const int n_iter_all = (T + NWAVE * KT - 1) / (NWAVE * KT);
+    const int it_per = (n_iter_all + a.k_splits - 1) / a.k_splits;
+    const int it_lo = ks * it_per;
+    const int n_iter = min(n_iter_all, it_lo + it_per);
+    fetch(it_lo);
     const float* Kw = Ks + wave * (KT * K_LD) + lq * K_LD + half * 4;
     const float* Vw = Vs + wave * (KT * 64) + lq;
 
-    for (int it = 0; it < n_iter; ++it) {
+    for (int it = it_lo; it < n_iter; ++it) {
         __syncthreads();  // previous iteration's LDS reads are done
         stash();
         __syncthreads();
@@ -200,9 +207,31 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
                 L += e * Ls[w * QT + q];
                 acc += e * Os[(w * QT + q) * O_LD + dd];
             }
-            if (qrow < a.Tq) a.out[(long)qrow * a.ldo + head * 64 + dd] = acc / L;
+            if (a.k_splits == 1) {
+                if (qrow < a.Tq) a.out[(long)qrow * a.ldo + head * 64 + dd] = acc / L;
+            } else if (qrow < a.Tq) {
+                // partial state of this key range: unnormalised O (relative to M), M and L
+                const long slot = ((long)qrow * n_head + head) * a.k_splits + ks;
+                a.part_o[slot * 64 + dd] = acc;
+                if (dd == 0) { a.part_m[slot] = M; a.part_l[slot] = L; }
+            }
         }
     }
+}
+
+// folds the k_splits partial softmax states of every (query row, head): out = sum_s e^{m_s-M} O_s / sum_s e^{m_s-M} l_s
+__global__ __launch_bounds__(64) void flash_merge_kernel(FlashArgs a) {
+    const int row = blockIdx.x, head = blockIdx.y, dd = threadIdx.x;
+    const long base = ((long)row * a.n_head + head) * a.k_splits;
+    float M = -INFINITY;
+    for (int s = 0; s < a.k_splits; ++s) M = fmaxf(M, a.part_m[base + s]);
+    float L = 0.f, acc = 0.f;
+    for (int s = 0; s < a.k_splits; ++s) {
+        const float f = expf(a.part_m[base + s] - M);
+        L += a.part_l[base + s] * f;
+        acc += a.part_o[(base + s) * 64 + dd] * f;
+    }
+    a.out[(long)row * a.ldo + head * 64 + dd] = acc / L;
 }
 
 static void launch_flash(const LaunchCtx& ctx, const FlashArgs& a, const char* tag) {
@@ -220,8 +249,16 @@ static void launch_flash(const LaunchCtx& ctx, const FlashArgs& a, const char* t
     // QK^T and PV: 2 * Tq*Tk*64 MACs per head each; reads q,k,v once, writes out
     KernelScope ks(ctx, tag, 4.0 * a.Tq * (double)a.Tk * 64.0 * a.n_head,
                    4.0 * 64.0 * a.n_head * (2.0 * a.Tq + 2.0 * a.Tk));
-    hipLaunchKernelGGL(flash_attention_kernel, dim3(q_tiles * a.n_head), dim3(256), lds, ctx.stream, a);
+    hipLaunchKernelGGL(flash_attention_kernel, dim3(q_tiles * a.n_head * a.k_splits), dim3(256), lds, ctx.stream, a);
     WLK_HIP(hipGetLastError());
+    if (a.k_splits > 1) {
+        hipLaunchKernelGGL(flash_merge_kernel, dim3(a.Tq, a.n_head), dim3(64), 0, ctx.stream, a);
+        WLK_HIP(hipGetLastError());
+    }
+}
+
+size_t flash_split_scratch_floats(int rows, int n_head, int k_splits) {
+    return (size_t)rows * n_head * k_splits * (64 + 2);
 }
 
 void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out, int T, int d, int n_head) {

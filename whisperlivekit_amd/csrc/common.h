@@ -125,7 +125,14 @@ struct FlashArgs {
     const int* ring_row = nullptr;               // [Tq]
     const int* beam_of_row = nullptr;            // [Tq]
     int ring_rows = 0, n_beam = 1;
+    // key-range split (few query tiles, e.g. decoder prefill): k_splits workgroups per (q tile, head) leave
+    // partial softmax states in part_o/m/l [rows][n_head][k_splits][64|1|1]; a merge kernel folds them
+    int k_splits = 1;
+    float* part_o = nullptr;
+    float* part_m = nullptr;
+    float* part_l = nullptr;
 };
+size_t flash_split_scratch_floats(int rows, int n_head, int k_splits);
 // encoder self-attention over qkv[T][3d] (q and k pre-scaled), out[T][d]
 void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out, int T, int d, int n_head);
 void launch_prefill_cross_attention(const LaunchCtx& ctx, const FlashArgs& a);

@@ -50,6 +50,21 @@ int wlk_diag_linear(const float* a, int64_t lda, int64_t a_floats, const float* 
     });
 }
 
+int wlk_diag_linear_ln(const float* a, const float* w, const float* bias, const float* gamma, const float* beta, int m,
+                       int n, int k, int force_gemv, float* c) {
+    return run([&]() {
+        DevBuf A((size_t)m * k, a), W((size_t)n * k, w), B(n, bias), G(k, gamma), Bt(k, beta), Cc((size_t)m * n);
+        GemmArgs g;
+        g.A = A.p; g.lda = k; g.W = W.p; g.bias = B.p; g.C = Cc.p; g.ldc = n; g.M = m; g.N = n; g.K = k;
+        g.ln_gamma = G.p; g.ln_beta = Bt.p;
+        LaunchCtx ctx;
+        if (force_gemv) launch_gemv(ctx, g, "diag_gemv_ln");
+        else launch_gemm(ctx, g, "diag_gemm_ln");
+        WLK_HIP(hipDeviceSynchronize());
+        WLK_HIP(hipMemcpy(c, Cc.p, (size_t)m * n * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+
 int wlk_diag_layernorm(const float* x, const float* gamma, const float* beta, int rows, int d, float* y) {
     return run([&]() {
         DevBuf X((size_t)rows * d, x), G(d, gamma), Bt(d, beta), Y((size_t)rows * d);
