@@ -36,8 +36,8 @@ PEAK_HBM_GBPS = 8000.0
 
 # launch tag -> kernel function (what rocprofv3 --stats reports)
 KERNEL_OF_TAG = {
-    "enc_conv1": "gemm_nt_f32_kernel", "enc_conv2": "gemm_nt_f32_kernel", "enc_ln1_qkv": "gemm_nt_f32_kernel",
-    "enc_out": "gemm_nt_f32_kernel", "enc_ln2_fc1": "gemm_nt_f32_kernel", "enc_fc2": "gemm_nt_f32_kernel",
+    "enc_conv1": "gemm_nt_f32_kernel", "enc_conv2": "gemm_nt_f32_kernel", "enc_qkv": "gemm_nt_f32_kernel",
+    "enc_out": "gemm_nt_f32_kernel", "enc_fc1": "gemm_nt_f32_kernel", "enc_fc2": "gemm_nt_f32_kernel",
     "dec_cross_kv": "gemm_nt_f32_kernel", "enc_attention": "flash_attention_kernel",
     "dec_cross_attention": "decoder_cross_attention_kernel",
     "dec_cross_attention_prefill": "flash_attention_kernel",

@@ -140,7 +140,8 @@ const char* wlk_diag_last_error(void);
 int wlk_diag_linear(const float* a, int64_t lda, int64_t a_floats, const float* w, const float* bias,
                     const float* r, int64_t ldr, int m, int n, int k, int flags, float scale, int scale_cols,
                     int force_gemv, float* c);
-/* c[m,n] = LayerNorm(a[m,k]; gamma, beta, eps 1e-5) . w[n,k]^T + bias  (the fused pre-LN projections) */
+/* c[m,n] = LayerNorm(a[m,k]; gamma, beta, eps 1e-5) . w[n,k]^T + bias, m <= 8: the fused pre-LN projections
+ * of the decode-step (weight-streaming) path */
 int wlk_diag_linear_ln(const float* a, const float* w, const float* bias, const float* gamma, const float* beta,
                        int m, int n, int k, int force_gemv, float* c);
 int wlk_diag_layernorm(const float* x, const float* gamma, const float* beta, int rows, int d, float* y);

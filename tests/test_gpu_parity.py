@@ -105,8 +105,7 @@ def test_gemv_matches_torch(lib, M, N, K):
     assert err <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("M,N,K,gemv", [(1500, 1536, 512, 0), (61, 512, 512, 0), (33, 2048, 384, 0), (1, 1536, 512, 1),
-                                        (3, 512, 128, 1), (8, 2048, 512, 1)])
+@pytest.mark.parametrize("M,N,K,gemv", [(1, 1536, 512, 1), (3, 512, 128, 1), (8, 2048, 512, 1), (2, 51864, 384, 1)])
 def test_fused_layernorm_linear_matches_torch(lib, M, N, K, gemv):
     rng = np.random.default_rng(6)
     a = (rng.standard_normal((M, K)) * 2 + 0.5).astype(np.float32)
@@ -342,12 +341,17 @@ def test_stream_matches_reference_golden(case):
         proc.close()
 
 
-def test_stream_without_hipgraph_matches_too(monkeypatch):
-    """Same golden stream with graph replay disabled (WLK_NO_GRAPH=1): the eager launch sequence and
-    the captured one must be the same arithmetic."""
-    monkeypatch.setenv("WLK_NO_GRAPH", "1")
-    g, proc, got = replay_stream("micro_12s", make_hip_processor)
-    try:
-        assert check_stream_against_golden(g, proc.trace, got, tol=1e-3, allow_ties=True) is None
-    finally:
+def test_hipgraph_replay_equals_eager_launches(monkeypatch):
+    """The captured decode-step graph and the eager launch sequence are the same arithmetic: identical
+    tokens, frames and log-prob sums, bit for bit, over a whole stream."""
+    def run():
+        g, proc, got = replay_stream("micro_12s", make_hip_processor)
+        trace = [(r["content_mel_len"], [(s.get("token"), s.get("frame"), s.get("sum_logprob")) for s in r["steps"]])
+                 for r in proc.trace]
+        words = [[(t.start, t.end, t.text) for t in toks] for _, toks, _ in got]
         proc.close()
+        return trace, words
+    with_graph = run()
+    monkeypatch.setenv("WLK_NO_GRAPH", "1")
+    eager = run()
+    assert with_graph == eager

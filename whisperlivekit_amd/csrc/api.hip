@@ -631,14 +631,22 @@ int wlk_audio_len(wlk_session* s, int* n) {
 }
 
 // ---- encode ---------------------------------------------------------------------------------
-// pre-LN MLP block: x += fc2(gelu(fc1(LN(x)))); the LayerNorm is folded into the fc1 launch (GEMM: per-row
-// statistics in the workgroup prologue; GEMV: in the LDS staging of the activation rows)
-static void transformer_mlp(const LaunchCtx& c, const LayerW& L, float* x, float* mlp, int rows, int d,
-                            const char* t_fc1, const char* t_fc2) {
+// pre-LN MLP block: x += fc2(gelu(fc1(LN(x)))).  For decode steps (GEMV path) the LayerNorm is folded into the
+// fc1 launch; for many rows it is its own kernel (folding it into the MFMA GEMM's tile staging was measured
+// slower: every workgroup re-derives the row statistics)
+static void transformer_mlp(const LaunchCtx& c, const LayerW& L, float* x, float* h, float* mlp, int rows, int d,
+                            const char* t_ln, const char* t_fc1, const char* t_fc2) {
     GemmArgs g;
-    g.A = x; g.lda = d; g.W = L.fc1w; g.bias = L.fc1b; g.C = mlp; g.ldc = 4 * d; g.M = rows; g.N = 4 * d; g.K = d;
-    g.flags = kGemmGelu; g.ln_gamma = L.ln2w; g.ln_beta = L.ln2b;
-    launch_linear(c, g, t_fc1);
+    g.lda = d; g.W = L.fc1w; g.bias = L.fc1b; g.C = mlp; g.ldc = 4 * d; g.M = rows; g.N = 4 * d; g.K = d;
+    g.flags = kGemmGelu;
+    if (gemv_applicable(rows, d)) {
+        g.A = x; g.ln_gamma = L.ln2w; g.ln_beta = L.ln2b;
+        launch_gemv(c, g, "dec_ln2_fc1");
+    } else {
+        launch_layernorm(c, x, d, L.ln2w, L.ln2b, h, d, rows, d, t_ln);
+        g.A = h;
+        launch_gemm(c, g, t_fc1);
+    }
     GemmArgs g2;
     g2.A = mlp; g2.lda = 4 * d; g2.W = L.fc2w; g2.bias = L.fc2b; g2.C = x; g2.ldc = d; g2.M = rows; g2.N = d;
     g2.K = 4 * d; g2.flags = kGemmResidual; g2.R = x; g2.ldr = d;
@@ -684,16 +692,17 @@ int wlk_encode(wlk_session* s, int32_t* content_mel_len) {
         const float scale = std::pow((float)kHeadDim, -0.25f);
         for (int i = 0; i < D.n_audio_layer; ++i) {
             const LayerW& L = m->enc_layers[i];
+            launch_layernorm(c, s->ex, d, L.ln1w, L.ln1b, s->eh, d, T, d, "enc_ln1");
             GemmArgs g;
-            g.A = s->ex; g.lda = d; g.ln_gamma = L.ln1w; g.ln_beta = L.ln1b; g.W = L.qkvw; g.bias = L.qkvb; g.C = s->eqkv; g.ldc = 3 * d; g.M = T; g.N = 3 * d;
+            g.A = s->eh; g.lda = d; g.W = L.qkvw; g.bias = L.qkvb; g.C = s->eqkv; g.ldc = 3 * d; g.M = T; g.N = 3 * d;
             g.K = d; g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = 2 * d;
-            launch_gemm(c, g, "enc_ln1_qkv");
+            launch_gemm(c, g, "enc_qkv");
             launch_encoder_attention(c, s->eqkv, s->eatt, T, d, D.n_audio_head);
             GemmArgs o;
             o.A = s->eatt; o.lda = d; o.W = L.outw; o.bias = L.outb; o.C = s->ex; o.ldc = d; o.M = T; o.N = d; o.K = d;
             o.flags = kGemmResidual; o.R = s->ex; o.ldr = d;
             launch_gemm(c, o, "enc_out");
-            transformer_mlp(c, L, s->ex, s->emlp, T, d, "enc_ln2_fc1", "enc_fc2");
+            transformer_mlp(c, L, s->ex, s->eh, s->emlp, T, d, "enc_ln2", "enc_fc1", "enc_fc2");
         }
         launch_layernorm(c, s->ex, d, m->w("enc.ln_post.w"), m->w("enc.ln_post.b"), s->enc_out, d, T, d, "enc_ln_post");
         for (int i = 0; i < D.n_text_layer; ++i) {  // cross-attention K (scaled) and V of every decoder layer
@@ -745,8 +754,9 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
             g.kcache = kc; g.vcache = vc; g.kv_pos = s->d_offset; g.kv_d = d; g.kv_ctx = ctx_len;
             launch_gemv(c, g, "dec_ln1_qkv_kv");
         } else {
-            g.A = s->dx; g.ln_gamma = L.ln1w; g.ln_beta = L.ln1b;
-            launch_linear(c, g, "dec_ln1_qkv");
+            launch_layernorm(c, s->dx, d, L.ln1w, L.ln1b, s->dh, d, R, d, "dec_ln1");
+            g.A = s->dh;
+            launch_linear(c, g, "dec_qkv");
             launch_kv_append(c, s->dqkv, kc, vc, n_rows, n_tok, s->d_offset, d, ctx_len);
         }
         launch_decoder_self_attention(c, s->dqkv, kc, vc, s->datt, n_rows, n_tok, s->d_offset, d, H, ctx_len);
@@ -762,8 +772,9 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
             q.A = s->dx; q.ln_gamma = L.lnxw; q.ln_beta = L.lnxb;
             launch_gemv(c, q, "dec_lnx_xq");
         } else {
-            q.A = s->dx; q.ln_gamma = L.lnxw; q.ln_beta = L.lnxb;
-            launch_linear(c, q, "dec_lnx_xq");
+            launch_layernorm(c, s->dx, d, L.lnxw, L.lnxb, s->dh, d, R, d, "dec_lnx");
+            q.A = s->dh;
+            launch_linear(c, q, "dec_xq");
         }
         const int* ranks_l = m->n_align > 0 ? m->head_rank + (size_t)i * H : nullptr;
         if (R > 8 && !s->debug) {
@@ -812,7 +823,7 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
         xo.A = s->datt; xo.lda = d; xo.W = L.xoutw; xo.bias = L.xoutb; xo.C = s->dx; xo.ldc = d; xo.M = R; xo.N = d;
         xo.K = d; xo.flags = kGemmResidual; xo.R = s->dx; xo.ldr = d;
         launch_linear(c, xo, "dec_xout");
-        transformer_mlp(c, L, s->dx, s->dmlp, R, d, "dec_ln2_fc1", "dec_fc2");
+        transformer_mlp(c, L, s->dx, s->dh, s->dmlp, R, d, "dec_ln2", "dec_fc1", "dec_fc2");
     }
     // final LayerNorm + vocabulary projection only for the rows the policy reads
     GemmArgs lg;

@@ -58,8 +58,8 @@ int wlk_diag_linear_ln(const float* a, const float* w, const float* bias, const 
         g.A = A.p; g.lda = k; g.W = W.p; g.bias = B.p; g.C = Cc.p; g.ldc = n; g.M = m; g.N = n; g.K = k;
         g.ln_gamma = G.p; g.ln_beta = Bt.p;
         LaunchCtx ctx;
-        if (force_gemv) launch_gemv(ctx, g, "diag_gemv_ln");
-        else launch_gemm(ctx, g, "diag_gemm_ln");
+        (void)force_gemv;   // only the weight-streaming path fuses the LayerNorm
+        launch_gemv(ctx, g, "diag_gemv_ln");
         WLK_HIP(hipDeviceSynchronize());
         WLK_HIP(hipMemcpy(c, Cc.p, (size_t)m * n * sizeof(float), hipMemcpyDeviceToHost));
     });

@@ -101,46 +101,6 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
     }
     const int nk = (g.K + BK - 1) / BK;
 
-    // Optional fused pre-LayerNorm of the A rows (whisper/model.py:39-41, eps 1e-5): every workgroup first
-    // derives mean / rstd of its BM rows (K == row width; the rows are L2-resident, 4 lanes per row), and
-    // the normalisation is applied when a tile goes from registers to LDS.
-    __shared__ float ln_mean[BM], ln_rstd[BM];
-    if (g.ln_gamma) {
-        for (int r = tid >> 2; r < BM; r += NT >> 2) {
-            const int row = m0 + r;
-            const int q = tid & 3;
-            const float* xr = g.A + (long)min(row, g.M - 1) * g.lda;
-            float sum = 0.f;
-            for (int c = q * 4; c < g.K; c += 16) {
-                const float4 v = *reinterpret_cast<const float4*>(xr + c);
-                sum += (v.x + v.y) + (v.z + v.w);
-            }
-            sum += __shfl_xor(sum, 1, 64);
-            sum += __shfl_xor(sum, 2, 64);
-            const float mean = sum / (float)g.K;
-            float sq = 0.f;
-            for (int c = q * 4; c < g.K; c += 16) {
-                const float4 v = *reinterpret_cast<const float4*>(xr + c);
-                const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
-                sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-            }
-            sq += __shfl_xor(sq, 1, 64);
-            sq += __shfl_xor(sq, 2, 64);
-            if (q == 0) {
-                ln_mean[r] = mean;
-                ln_rstd[r] = 1.0f / sqrtf(sq / (float)g.K + 1e-5f);
-            }
-        }
-        __syncthreads();
-    }
-    float a_mean[NA], a_rstd[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int row = (tid + NT * i) >> 3;
-        a_mean[i] = g.ln_gamma ? ln_mean[row] : 0.f;
-        a_rstd[i] = g.ln_gamma ? ln_rstd[row] : 1.f;
-    }
-
     auto fetch = [&](Stage<NA, NW>& st, int kt) {
         const int k0 = kt * BK;
 #pragma unroll
@@ -156,21 +116,9 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
             st.w[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
     };
-    auto stash = [&](const Stage<NA, NW>& st, int buf, int kt) {
+    auto stash = [&](const Stage<NA, NW>& st, int buf) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            float4 v = st.a[i];
-            if (g.ln_gamma) {
-                const int k = min(kt * BK + a_c[i], g.K - 4);
-                const float4 gm = *reinterpret_cast<const float4*>(g.ln_gamma + k);
-                const float4 bt = *reinterpret_cast<const float4*>(g.ln_beta + k);
-                v.x = (v.x - a_mean[i]) * a_rstd[i] * gm.x + bt.x;
-                v.y = (v.y - a_mean[i]) * a_rstd[i] * gm.y + bt.y;
-                v.z = (v.z - a_mean[i]) * a_rstd[i] * gm.z + bt.z;
-                v.w = (v.w - a_mean[i]) * a_rstd[i] * gm.w + bt.w;
-            }
-            *reinterpret_cast<float4*>(&As[buf][a_lds[i]]) = v;
-        }
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<float4*>(&As[buf][a_lds[i]]) = st.a[i];
 #pragma unroll
         for (int i = 0; i < NW; ++i) *reinterpret_cast<float4*>(&Ws[buf][w_lds[i]]) = st.w[i];
     };
@@ -198,19 +146,19 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
     Stage<NA, NW> s0, s1;
     fetch(s0, 0);
     fetch(s1, 1);
-    stash(s0, 0, 0);
+    stash(s0, 0);
     __syncthreads();
     const int nk2 = (nk + 1) & ~1;
     for (int kt = 0; kt < nk2; kt += 2) {
         fetch(s0, kt + 2);
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch loads ahead of the MFMA block
         mma(0);            // tile kt
-        stash(s1, 1, kt + 1);      // tile kt+1 (loaded one full trip ago)
+        stash(s1, 1);      // tile kt+1 (loaded one full trip ago)
         __syncthreads();
         fetch(s1, kt + 3);
         __builtin_amdgcn_sched_barrier(0);
         mma(1);            // tile kt+1
-        stash(s0, 0, kt + 2);      // tile kt+2
+        stash(s0, 0);      // tile kt+2
         __syncthreads();
     }
 
@@ -248,7 +196,6 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (g.M <= 0 || g.N <= 0) return;
     if (g.K % 4 != 0 || g.lda % 4 != 0) throw std::invalid_argument("gemm: K and lda must be multiples of 4");
-    if (g.ln_gamma && g.lda < g.K) throw std::invalid_argument("gemm: fused LayerNorm needs whole rows (lda >= K)");
     if ((((long)g.M - 1) * g.lda + g.K) * 4 >= (1L << 31) || (long)g.N * g.K * 4 >= (1L << 31))
         throw std::invalid_argument("gemm: operand larger than 2 GiB");
     KernelScope ks(ctx, tag, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
