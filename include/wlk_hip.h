@@ -133,6 +133,18 @@ int wlk_prof_begin(wlk_session* s);
 int wlk_prof_end(wlk_session* s, int cap, const char** names, float* total_ms, int32_t* launches,
                  double* flops, double* bytes, int32_t* n_out);
 
+/* ---- a12 front end: log-mel features of the streaming Sortformer diarizer ----------------------
+ * Replaces NeMo's AudioToMelSpectrogramPreprocessor.get_features as called at
+ * whisperlivekit/diarization/sortformer_backend.py:181-188,273-275 (window 25 ms, stride 10 ms, n_fft 512,
+ * 128 mel bins, normalize "NA", pre-emphasis 0.97, log(x + 2^-24)).  filters: [n_mels, n_fft/2+1];
+ * window: [win_length] (symmetric hann).  Output is time-major [n_frames, n_mels], n_frames = n/hop + 1. */
+typedef struct wlk_melspec wlk_melspec;
+int wlk_melspec_create(int device, int n_fft, int win_length, int hop, int n_mels, const float* filters,
+                       const float* window, float preemph, float log_guard, int max_samples, wlk_melspec** out);
+int wlk_melspec_run(wlk_melspec* m, const float* pcm_host, int n, float* out_host, int capacity_frames,
+                    int* n_frames);
+int wlk_melspec_destroy(wlk_melspec* m);
+
 /* ---- diagnostics: one kernel on host data (used by the GPU parity tests only) ---------------- */
 const char* wlk_diag_last_error(void);
 /* c[m,n] = epilogue(a[m,k](row stride lda, a_floats floats in total) . w[n,k]^T + bias); flags:

@@ -355,3 +355,59 @@ def test_hipgraph_replay_equals_eager_launches(monkeypatch):
     monkeypatch.setenv("WLK_NO_GRAPH", "1")
     eager = run()
     assert with_graph == eager
+
+
+def test_diarization_melspec_against_oracle():
+    """a12 front end: 128-bin log-mel of 1 s chunks (NeMo FilterbankFeatures config) vs the torch restatement."""
+    from oracle.sortformer_oracle import nemo_log_mel
+    from whisperlivekit_amd.diarization import HipMelSpectrogram
+    mel = HipMelSpectrogram()
+    filters = np.array(mel_filterbank(128, 16000, 512))
+    worst = 0.0
+    for seed, n in ((0, 16000), (1, 16000), (2, 12345), (3, 400)):
+        pcm = synth.to_pcm16_roundtrip(synth.speech_like(1.0, seed))[:n]
+        got = mel(pcm)
+        ref = nemo_log_mel(pcm, filters)
+        assert got.shape == ref.shape == (n // 160 + 1, 128)
+        worst = max(worst, float(np.abs(got - ref).max()))
+    silence = mel(np.zeros(16000, np.float32))
+    report("diar_melspec", max_abs_err=worst, silence_value=float(silence[5, 5]))
+    mel.close()
+    assert worst <= 1e-3
+    assert np.allclose(silence, np.log(np.float32(2.0 ** -24)), atol=1e-5)
+
+
+def test_large_v3_shapes_smoke():
+    """Config 3 (large-v3: d=1280, 20 heads, 32+32 layers, 128 mels, 51866 tokens) with a 2-layer stand-in
+    of the same widths: exercises the 128-mel conv1, the 1280-wide GEMM/GEMV/LayerNorm paths and the
+    5120-wide MLP against the oracle."""
+    from oracle import whisper_oracle as wo
+    from whisperlivekit_amd.dims import ModelDims
+    from whisperlivekit_amd.engine import HipWhisperModel
+    dims = ModelDims(128, 1500, 1280, 20, 2, 51866, 448, 1280, 20, 2)
+    sd = synth.synth_state_dict(dims, 9)
+    model = HipWhisperModel.from_state_dict(dims, sd, [(1, 3), (1, 17)])
+    sess = model.new_session()
+    audio = synth.to_pcm16_roundtrip(synth.speech_like(3.0, 4))
+    sess.append(audio)
+    cml = sess.encode()
+    sdt = wo.to_torch_state_dict(sd)
+    with torch.no_grad():
+        mel, rcml = wo.encoder_input_from_audio(torch.from_numpy(audio), torch.from_numpy(np.array(mel_filterbank(128))))
+        enc = wo.encoder_forward(sdt, dims, mel)
+    e_enc = float(np.abs(sess.export("enc").reshape(1500, 1280) - enc[0].numpy()).max())
+    toks = np.array([[50258, 50259, 50360, 50364, 1000, 2000, 3000, 4000, 5000, 6000]])
+    cache = wo.DecoderCache(dims.n_text_layer)
+    worst = 0.0
+    for step in range(3):
+        feed = toks if step == 0 else toks[:, -1:]
+        sess.decode(feed, first=(step == 0), sot_index=0)
+        with torch.no_grad():
+            logits, _ = wo.decoder_forward(sdt, dims, torch.from_numpy(feed), enc, cache)
+        got = sess.export("logits_last").reshape(-1)
+        worst = max(worst, float(np.abs(got - logits[0, -1].numpy()).max()))
+        toks = np.concatenate([toks, [[int(got.argmax())]]], axis=1)
+        assert int(got.argmax()) == int(logits[0, -1].argmax())
+    report("large_v3_widths", enc_err=e_enc, logits_err=worst)
+    sess.close(); model.close()
+    assert cml == rcml and e_enc <= 1e-3 and worst <= 1e-3

@@ -59,6 +59,9 @@ def _declare(lib: C.CDLL) -> None:
         "wlk_export": (cint, [p, C.c_char_p, p, u64, C.POINTER(u64)]),
         "wlk_prof_begin": (cint, [p]),
         "wlk_prof_end": (cint, [p, cint, C.POINTER(C.c_char_p), p, p, p, p, C.POINTER(i32)]),
+        "wlk_melspec_create": (cint, [cint, cint, cint, cint, cint, p, p, C.c_float, C.c_float, cint, C.POINTER(p)]),
+        "wlk_melspec_run": (cint, [p, p, cint, p, cint, C.POINTER(cint)]),
+        "wlk_melspec_destroy": (cint, [p]),
         "wlk_diag_last_error": (C.c_char_p, []),
         "wlk_diag_linear": (cint, [p, C.c_int64, C.c_int64, p, p, p, C.c_int64, cint, cint, cint, cint, C.c_float,
                                    cint, cint, p]),
@@ -79,7 +82,7 @@ EXPORTED_SYMBOLS = (
     "wlk_session_destroy", "wlk_session_set_debug", "wlk_audio_append", "wlk_audio_append_zeros",
     "wlk_audio_drop_front", "wlk_audio_clear", "wlk_audio_len", "wlk_encode", "wlk_decode",
     "wlk_no_speech_prob", "wlk_select", "wlk_kv_reorder", "wlk_sync", "wlk_export", "wlk_prof_begin",
-    "wlk_prof_end", "wlk_diag_last_error", "wlk_diag_linear", "wlk_diag_linear_ln", "wlk_diag_layernorm", "wlk_diag_encoder_attention",
+    "wlk_prof_end", "wlk_melspec_create", "wlk_melspec_run", "wlk_melspec_destroy", "wlk_diag_last_error", "wlk_diag_linear", "wlk_diag_linear_ln", "wlk_diag_layernorm", "wlk_diag_encoder_attention",
 )
 
 

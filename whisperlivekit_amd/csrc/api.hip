@@ -1103,6 +1103,92 @@ int wlk_export(wlk_session* s, const char* what, float* host, uint64_t capacity,
     });
 }
 
+// ---- diarization front end: stand-alone log-mel extractor --------------------------------------
+struct wlk_melspec {
+    int device = 0, n_fft = 0, win_length = 0, hop = 0, n_mels = 0, cap = 0;
+    float preemph = 0.f, log_guard = 0.f;
+    float *window = nullptr, *filters = nullptr, *audio = nullptr, *out = nullptr;
+    double* twiddle = nullptr;
+    int *lo = nullptr, *hi = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+int wlk_melspec_create(int device, int n_fft, int win_length, int hop, int n_mels, const float* filters,
+                       const float* window, float preemph, float log_guard, int max_samples, wlk_melspec** out) {
+    if (!filters || !window || !out) return fail(WLK_ERR_ARG, "NULL argument");
+    if (n_fft < 16 || n_fft > 512 || win_length < 1 || win_length > n_fft || hop < 1 || n_mels < 1 || n_mels > 256 ||
+        max_samples < n_fft)
+        return fail(WLK_ERR_ARG, "unsupported mel-spectrogram configuration");
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(device));
+        auto m = std::make_unique<wlk_melspec>();
+        m->device = device; m->n_fft = n_fft; m->win_length = win_length; m->hop = hop; m->n_mels = n_mels;
+        m->preemph = preemph; m->log_guard = log_guard; m->cap = max_samples;
+        const int nf = n_fft / 2 + 1;
+        WLK_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+        m->window = dev_alloc<float>(win_length);
+        m->filters = dev_alloc<float>((size_t)n_mels * nf);
+        m->twiddle = dev_alloc<double>(n_fft);
+        m->lo = dev_alloc<int>(n_mels);
+        m->hi = dev_alloc<int>(n_mels);
+        m->audio = dev_alloc<float>(max_samples);
+        m->out = dev_alloc<float>((size_t)(max_samples / hop + 2) * n_mels);
+        std::vector<double> tw(n_fft);
+        for (int i = 0; i < n_fft; ++i) tw[i] = std::cos(2.0 * M_PI * (double)i / (double)n_fft);
+        std::vector<int> lo(n_mels), hi(n_mels);
+        for (int i = 0; i < n_mels; ++i) {
+            int a = nf, b = 0;
+            for (int k = 0; k < nf; ++k)
+                if (filters[(size_t)i * nf + k] != 0.f) { a = std::min(a, k); b = k + 1; }
+            if (b == 0) a = 0;
+            lo[i] = a; hi[i] = b;
+        }
+        WLK_HIP(hipMemcpy(m->window, window, win_length * sizeof(float), hipMemcpyHostToDevice));
+        WLK_HIP(hipMemcpy(m->filters, filters, (size_t)n_mels * nf * sizeof(float), hipMemcpyHostToDevice));
+        WLK_HIP(hipMemcpy(m->twiddle, tw.data(), n_fft * sizeof(double), hipMemcpyHostToDevice));
+        WLK_HIP(hipMemcpy(m->lo, lo.data(), n_mels * sizeof(int), hipMemcpyHostToDevice));
+        WLK_HIP(hipMemcpy(m->hi, hi.data(), n_mels * sizeof(int), hipMemcpyHostToDevice));
+        *out = m.release();
+        return WLK_OK;
+    });
+}
+
+int wlk_melspec_run(wlk_melspec* m, const float* pcm_host, int n, float* out_host, int capacity_frames, int* n_frames) {
+    if (!m || !pcm_host || !out_host || !n_frames) return fail(WLK_ERR_ARG, "NULL argument");
+    if (n < 1 || n > m->cap) return fail(WLK_ERR_CAPACITY, "chunk does not fit the extractor's buffer");
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(m->device));
+        // FilterbankFeatures.get_seq_len with centre padding: floor((n + 2*(n_fft/2) - n_fft) / hop) + 1
+        const int frames = n / m->hop + 1;
+        *n_frames = frames;
+        if (frames > capacity_frames) return fail(WLK_ERR_CAPACITY, "output buffer too small");
+        WLK_HIP(hipMemcpyAsync(m->audio, pcm_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice, m->stream));
+        MelSpecArgs a;
+        a.audio = m->audio; a.n_samples = n; a.window = m->window; a.twiddle = m->twiddle; a.filters = m->filters;
+        a.filt_lo = m->lo; a.filt_hi = m->hi; a.out = m->out; a.n_fft = m->n_fft; a.win_length = m->win_length;
+        a.hop = m->hop; a.n_mels = m->n_mels; a.preemph = m->preemph; a.log_guard = m->log_guard;
+        LaunchCtx c{m->stream, nullptr};
+        launch_melspec(c, a, frames);
+        WLK_HIP(hipMemcpyAsync(out_host, m->out, (size_t)frames * m->n_mels * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        WLK_HIP(hipStreamSynchronize(m->stream));
+        return WLK_OK;
+    });
+}
+
+int wlk_melspec_destroy(wlk_melspec* m) {
+    if (!m) return WLK_OK;
+    (void)hipSetDevice(m->device);
+    float* fl[] = {m->window, m->filters, m->audio, m->out};
+    for (float* p : fl)
+        if (p) (void)hipFree(p);
+    if (m->twiddle) (void)hipFree(m->twiddle);
+    if (m->lo) (void)hipFree(m->lo);
+    if (m->hi) (void)hipFree(m->hi);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+    return WLK_OK;
+}
+
 // ---- profiling ------------------------------------------------------------------------------
 int wlk_prof_begin(wlk_session* s) {
     if (!s) return fail(WLK_ERR_ARG, "session is NULL");

@@ -112,6 +112,21 @@ struct MelArgs {
 };
 void launch_mel(const LaunchCtx& ctx, const MelArgs& a);
 
+// ---- melspec.hip (diarization front end) ---------------------------------------------------------
+struct MelSpecArgs {
+    const float* audio;     // device
+    int n_samples;
+    const float* window;    // [win_length]
+    const double* twiddle;  // [n_fft] cos(2*pi*i/n_fft), fp64
+    const float* filters;   // [n_mels][n_fft/2+1]
+    const int* filt_lo;
+    const int* filt_hi;
+    float* out;             // [n_frames][n_mels], time-major
+    int n_fft, win_length, hop, n_mels;
+    float preemph, log_guard;
+};
+void launch_melspec(const LaunchCtx& ctx, const MelSpecArgs& a, int n_frames);
+
 // ---- attention.hip --------------------------------------------------------------------------
 // flash-style fp32-MFMA attention: q rows [Tq] against k/v rows [Tk], 64-wide heads, no mask
 struct FlashArgs {
