@@ -145,10 +145,50 @@ int wlk_melspec_run(wlk_melspec* m, const float* pcm_host, int n, float* out_hos
                     int* n_frames);
 int wlk_melspec_destroy(wlk_melspec* m);
 
+/* ---- a12 network: the streaming Sortformer diarizer ------------------------------------------------
+ * Replaces what the reference gets from NeMo's SortformerEncLabelModel at
+ * whisperlivekit/diarization/sortformer_backend.py:108-131 (load, streaming configuration) and :293-300
+ * (forward_streaming_step): ConvSubsampling(dw_striding, x8) -> 17 Conformer blocks (relative-position
+ * attention) -> Linear -> 18 post-LN Transformer blocks -> sigmoid speaker head.  NeMo is a third-party
+ * dependency that is not in the reference tree: packed tensor names/layout are defined by wlk_sf_tensor_name /
+ * wlk_sf_tensor_lookup, the host shim (whisperlivekit_amd/sortformer.py) maps NeMo state-dict names onto them.
+ * The streaming speaker-cache / FIFO bookkeeping (SortformerModules.streaming_update_async) is host logic. */
+typedef struct wlk_sortformer wlk_sortformer;
+typedef struct wlk_sf_dims {
+    int32_t n_mels;        /* 128 */
+    int32_t sub_channels;  /* 256: conv channels of the sub-sampling stem */
+    int32_t fc_d_model, fc_layers, fc_heads, fc_ff, conv_kernel;   /* 512, 17, 8, 2048, 9 */
+    int32_t tf_d_model, tf_layers, tf_heads, tf_inner;             /* 192, 18, 8, 768 */
+    int32_t n_spk;         /* 4 */
+    int32_t max_frames;    /* longest [spkcache | fifo | chunk] sequence, <= 512 */
+    int32_t max_feat_frames; /* longest feature chunk handed to wlk_sf_step */
+    float xscale;          /* sqrt(fc_d_model) when the encoder was trained with xscaling, else 1 */
+} wlk_sf_dims;
+int wlk_sf_arena_floats(const wlk_sf_dims* dims, uint64_t* n_floats);
+int wlk_sf_tensor_lookup(const wlk_sf_dims* dims, const char* packed_name, uint64_t* offset_floats, uint64_t* numel);
+int wlk_sf_tensor_name(const wlk_sf_dims* dims, int index, const char** name);
+int wlk_sf_create(const wlk_sf_dims* dims, int device, wlk_sortformer** out);
+int wlk_sf_upload(wlk_sortformer* m, const char* packed_name, const float* host, uint64_t numel);
+/* precomputes linear_pos(pos_emb) of every Conformer block for max_frames (input independent) */
+int wlk_sf_finalize(wlk_sortformer* m);
+/* One streaming step (the device part of forward_streaming_step): feats_host [n_feat, n_mels] time-major log-mel
+ * -> pre_encode -> chunk embeddings [n_chunk, fc_d_model] (returned in chunk_embs_host, n_chunk in *n_chunk);
+ * ctx_embs_host [n_ctx, fc_d_model] = the caller's valid speaker-cache rows followed by its valid FIFO rows;
+ * the network runs over [ctx | chunk] and preds_host receives [n_ctx + n_chunk, n_spk] sigmoid activities.
+ * n_feat == 0 runs the network over ctx only; n_ctx == 0 over the chunk only.  Thread-safe (one step at a time
+ * per model; sessions keep their state on the host). */
+int wlk_sf_step(wlk_sortformer* m, const float* feats_host, int n_feat, const float* ctx_embs_host, int n_ctx,
+                float* chunk_embs_host, int chunk_capacity_rows, int* n_chunk, float* preds_host,
+                int preds_capacity_rows);
+/* parity/debug export of the last step: "fc_out" [T, fc_d_model] (Conformer output), "tf_out" [T, tf_d_model] */
+int wlk_sf_export(wlk_sortformer* m, const char* what, float* host, uint64_t capacity, uint64_t* n_written);
+int wlk_sf_destroy(wlk_sortformer* m);
+
 /* ---- diagnostics: one kernel on host data (used by the GPU parity tests only) ---------------- */
 const char* wlk_diag_last_error(void);
 /* c[m,n] = epilogue(a[m,k](row stride lda, a_floats floats in total) . w[n,k]^T + bias); flags:
- * 1 = exact-erf GELU, 2 = add r[m, ldr] after the activation, 4 = scale columns < scale_cols */
+ * 1 = exact-erf GELU, 2 = add r[m, ldr] after the activation, 4 = scale columns < scale_cols,
+ * 8 = ReLU, 16 = Swish */
 int wlk_diag_linear(const float* a, int64_t lda, int64_t a_floats, const float* w, const float* bias,
                     const float* r, int64_t ldr, int m, int n, int k, int flags, float scale, int scale_cols,
                     int force_gemv, float* c);

@@ -1,0 +1,142 @@
+"""a12 on the GPU: the Sortformer network through the C ABI (wlk_sf_*) against the torch-CPU restatement in
+oracle/sortformer_oracle.py on the same seeded weights and inputs.  PARITY UNPINNED with respect to NeMo itself
+(no NeMo / checkpoint offline) - what is checked here is HIP path == oracle, fp32 tolerance stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sortformer_oracle as so
+from whisperlivekit_amd import _lib
+from whisperlivekit_amd import sortformer as sf
+from whisperlivekit_amd.diarization import HipSortformerDiarizationOnline
+from whisperlivekit_amd.synth import speech_like
+
+pytestmark = pytest.mark.gpu
+
+
+def as_torch(sd):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+
+
+def oracle_dims(d):
+    return so.SortformerDims(n_mels=d.n_mels, fc_d_model=d.fc_d_model, fc_layers=d.fc_layers, fc_heads=d.fc_heads,
+                             conv_kernel=d.conv_kernel, sub_channels=d.sub_channels, tf_d_model=d.tf_d_model,
+                             tf_layers=d.tf_layers, tf_heads=d.tf_heads, tf_inner=d.tf_inner, n_spk=d.n_spk)
+
+
+def logmel_like(rng, n):
+    return (rng.standard_normal((n, 128)) * 2.5 - 9.0).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def shallow():
+    dims = sf.SortformerDims(fc_layers=2, tf_layers=2)
+    sd = sf.synth_sortformer_state_dict(dims, 11)
+    m = sf.HipSortformerModel(dims, sd)
+    yield dims, as_torch(sd), m
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def full():
+    dims = sf.SortformerDims()
+    sd = sf.synth_sortformer_state_dict(dims, 12)
+    m = sf.HipSortformerModel(dims, sd)
+    yield dims, as_torch(sd), m
+    m.close()
+
+
+@pytest.mark.parametrize("n_feat", [200, 101, 9, 8])
+def test_subsampling_stem_matches_oracle(shallow, n_feat):
+    """ConvSubsampling (conv0, 2 x depthwise+pointwise, Linear over (freq, channel)); tolerance 1e-4 relative to the
+    embedding scale (K = 4096 fp32 accumulation in a different order than torch's)."""
+    dims, tsd, m = shallow
+    feats = logmel_like(np.random.default_rng(n_feat), n_feat)
+    chunk, preds = m.step(feats, None)
+    ref = so.pre_encode(tsd, oracle_dims(dims), torch.from_numpy(feats)).numpy()
+    sub = lambda n: (n - 1) // 2 + 1
+    assert chunk.shape == ref.shape == (sub(sub(sub(n_feat))), 512)
+    assert np.abs(chunk - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    assert preds.shape == (ref.shape[0], 4) and np.all((preds >= 0) & (preds <= 1))
+
+
+@pytest.mark.parametrize("n_ctx,n_feat", [(300, 200), (0, 200), (1, 0), (37, 0), (376, 200)])
+def test_network_matches_oracle_two_blocks(shallow, n_ctx, n_feat):
+    """2 Conformer + 2 Transformer blocks at full width: Conformer output, Transformer output and activities.
+    Tolerances: 2e-4 absolute on LayerNorm-ed activations (O(1)), 1e-4 on the sigmoid outputs."""
+    dims, tsd, m = shallow
+    rng = np.random.default_rng(100 + n_ctx)
+    ctx = (rng.standard_normal((n_ctx, 512)) * 0.3).astype(np.float32) if n_ctx else None
+    feats = logmel_like(rng, n_feat) if n_feat else None
+    chunk, preds = m.step(feats, ctx)
+    od = oracle_dims(dims)
+    parts = ([torch.from_numpy(ctx)] if n_ctx else []) + ([so.pre_encode(tsd, od, torch.from_numpy(feats))] if n_feat else [])
+    embs = torch.cat(parts, 0)
+    T = embs.shape[0]
+    x = embs * math.sqrt(512)
+    pos = so.rel_positional_encoding(T, 512)
+    for i in range(dims.fc_layers):
+        x = so.conformer_layer(tsd, f"encoder.layers.{i}.", od, x, pos)
+    fc = m.export("fc_out")
+    assert fc.shape == (T, 512)
+    assert np.abs(fc - x.numpy()).max() <= 2e-4
+    ref = so.forward_embeddings(tsd, od, embs).numpy()
+    assert preds.shape == ref.shape
+    assert np.abs(preds - ref).max() <= 1e-4
+    assert ref.std() > 0.01
+
+
+def test_capacity_and_argument_errors(shallow):
+    dims, _, m = shallow
+    with pytest.raises(_lib.WlkError):
+        m.step(logmel_like(np.random.default_rng(0), m.max_feat_frames + 1), None)
+    with pytest.raises(_lib.WlkError):
+        m.step(None, np.zeros((m.max_frames + 1, 512), np.float32))
+    with pytest.raises(_lib.WlkError):
+        m.step(None, None)
+
+
+def test_full_depth_streaming_session_teacher_forced(full):
+    """The whole a12 pass: 1 s chunks of audio -> HIP log-mel -> 17 + 18 blocks -> speaker-cache update -> segments,
+    18 chunks (FIFO overflow at chunk ~9, first cache compression at ~15).  Every step's activities are compared
+    with the oracle run on the SAME context (the HIP session's own speaker cache / FIFO: teacher forcing, so that a
+    frame-selection flip cannot cascade); tolerance 2e-3 absolute on sigmoid outputs after 35 blocks."""
+    dims, tsd, m = full
+    od = oracle_dims(dims)
+    steps = []
+    orig = m.step
+
+    def recording_step(feats, ctx):
+        chunk, preds = orig(feats, ctx)
+        steps.append((feats.copy(), None if ctx is None else ctx.copy(), chunk.copy(), preds.copy()))
+        return chunk, preds
+
+    m.step = recording_step
+    try:
+        online = HipSortformerDiarizationOnline(m)
+        audio = speech_like(18.0, seed=5)
+        segs = []
+        for i in range(0, len(audio), 8000):
+            online.insert_audio_chunk(audio[i: i + 8000])
+            segs += online.diarize_sync()
+    finally:
+        m.step = orig
+    assert len(steps) == 18
+    st = online.streaming_state
+    assert st.spkcache_len == 188 and 0 < st.fifo_len <= 188
+    worst = 0.0
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    for k, (feats, ctx, chunk, preds) in enumerate(steps):
+        assert feats.shape == ((101, 128) if k == 0 else (200, 128))
+        emb_c = so.pre_encode(tsd, od, torch.from_numpy(feats))
+        assert np.abs(chunk - emb_c.numpy()).max() <= 1e-4 * max(1.0, float(emb_c.abs().max()))
+        embs = torch.cat(([torch.from_numpy(ctx)] if ctx is not None else []) + [torch.from_numpy(chunk)], 0)
+        ref = so.forward_embeddings(tsd, od, embs).numpy()
+        worst = max(worst, float(np.abs(preds - ref).max()))
+    assert worst <= 2e-3, worst
+    assert online.total_preds.shape == (12 + 17 * 23, 4)
+    assert segs and all(s.end >= s.start for s in segs)
+    assert abs(segs[-1].end - 18.0) < 0.05 and segs[0].start == 0.0
+    assert all(abs(a.end - b.start) < 1e-6 for a, b in zip(segs, segs[1:]))

@@ -22,6 +22,14 @@ class Dims(C.Structure):
         "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer")]
 
 
+class SfDims(C.Structure):
+    """wlk_sf_dims (include/wlk_hip.h)"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_mels", "sub_channels", "fc_d_model", "fc_layers", "fc_heads", "fc_ff", "conv_kernel",
+        "tf_d_model", "tf_layers", "tf_heads", "tf_inner", "n_spk", "max_frames", "max_feat_frames")] + [
+        ("xscale", C.c_float)]
+
+
 def lib_path() -> str:
     return os.environ.get("WLK_HIP_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME))
 
@@ -62,6 +70,15 @@ def _declare(lib: C.CDLL) -> None:
         "wlk_melspec_create": (cint, [cint, cint, cint, cint, cint, p, p, C.c_float, C.c_float, cint, C.POINTER(p)]),
         "wlk_melspec_run": (cint, [p, p, cint, p, cint, C.POINTER(cint)]),
         "wlk_melspec_destroy": (cint, [p]),
+        "wlk_sf_arena_floats": (cint, [C.POINTER(SfDims), C.POINTER(u64)]),
+        "wlk_sf_tensor_lookup": (cint, [C.POINTER(SfDims), C.c_char_p, C.POINTER(u64), C.POINTER(u64)]),
+        "wlk_sf_tensor_name": (cint, [C.POINTER(SfDims), cint, C.POINTER(C.c_char_p)]),
+        "wlk_sf_create": (cint, [C.POINTER(SfDims), cint, C.POINTER(p)]),
+        "wlk_sf_upload": (cint, [p, C.c_char_p, p, u64]),
+        "wlk_sf_finalize": (cint, [p]),
+        "wlk_sf_step": (cint, [p, p, cint, p, cint, p, cint, C.POINTER(cint), p, cint]),
+        "wlk_sf_export": (cint, [p, C.c_char_p, p, u64, C.POINTER(u64)]),
+        "wlk_sf_destroy": (cint, [p]),
         "wlk_diag_last_error": (C.c_char_p, []),
         "wlk_diag_linear": (cint, [p, C.c_int64, C.c_int64, p, p, p, C.c_int64, cint, cint, cint, cint, C.c_float,
                                    cint, cint, p]),
@@ -82,7 +99,11 @@ EXPORTED_SYMBOLS = (
     "wlk_session_destroy", "wlk_session_set_debug", "wlk_audio_append", "wlk_audio_append_zeros",
     "wlk_audio_drop_front", "wlk_audio_clear", "wlk_audio_len", "wlk_encode", "wlk_decode",
     "wlk_no_speech_prob", "wlk_select", "wlk_kv_reorder", "wlk_sync", "wlk_export", "wlk_prof_begin",
-    "wlk_prof_end", "wlk_melspec_create", "wlk_melspec_run", "wlk_melspec_destroy", "wlk_diag_last_error", "wlk_diag_linear", "wlk_diag_linear_ln", "wlk_diag_layernorm", "wlk_diag_encoder_attention",
+    "wlk_prof_end", "wlk_melspec_create", "wlk_melspec_run", "wlk_melspec_destroy",
+    "wlk_sf_arena_floats", "wlk_sf_tensor_lookup", "wlk_sf_tensor_name", "wlk_sf_create", "wlk_sf_upload",
+    "wlk_sf_finalize", "wlk_sf_step", "wlk_sf_export", "wlk_sf_destroy",
+    "wlk_diag_last_error", "wlk_diag_linear", "wlk_diag_linear_ln", "wlk_diag_layernorm",
+    "wlk_diag_encoder_attention",
 )
 
 

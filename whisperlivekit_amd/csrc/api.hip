@@ -19,6 +19,7 @@ namespace wlk {
 // error plumbing
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
 
 template <typename F>
 static int guarded(F&& f) {

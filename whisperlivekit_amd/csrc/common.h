@@ -28,6 +28,9 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
 }
 #define WLK_HIP(expr) ::wlk::hip_check((expr), #expr, __FILE__, __LINE__)
 
+// message returned by wlk_last_error() on the calling thread (api.hip owns the storage)
+void set_last_error(const std::string& msg);
+
 // optional per-kernel HIP-event timing (wlk_prof_begin/end)
 struct Profiler;
 struct LaunchCtx {
@@ -54,6 +57,8 @@ enum GemmFlags : int {
     kGemmGelu = 1,      // exact-erf GELU after bias
     kGemmResidual = 2,  // += R[m*ldr + n] (after GELU); R may alias C
     kGemmScaleCols = 4, // columns n < scale_cols are multiplied by `scale` (after bias)
+    kGemmRelu = 8,      // max(x, 0) after bias            (Sortformer sub-sampling / transformer FFN)
+    kGemmSwish = 16,    // x * sigmoid(x) after bias       (Conformer feed-forward)
 };
 struct GemmArgs {
     const float* A = nullptr;
@@ -184,6 +189,36 @@ void launch_decoder_cross_attention_split(const LaunchCtx& ctx, const CrossAttnA
 size_t cross_split_scratch_floats(int rows, int n_head, int T);
 void launch_kv_gather(const LaunchCtx& ctx, const float* src, float* dst, const int* source_rows, int n_rows,
                       int len, int d, int ctx_len, int n_layer);
+
+// ---- sortformer.hip (a12: streaming Sortformer diarizer network) -----------------------------------
+// sub-sampling stem, channels-last: feats [T][F] -> conv0 (1->C, 3x3 s2 p1, ReLU) -> [T1][F1][C]
+void launch_sf_conv0(const LaunchCtx& ctx, const float* in, const float* w, const float* b, float* out, int T, int F,
+                     int C);
+// depthwise 3x3 s2 p1 over [Ti][Fi][C] -> [To][Fo][C]; w tap-major [9][C]
+void launch_sf_dwconv2d(const LaunchCtx& ctx, const float* in, const float* w, const float* b, float* out, int Ti,
+                        int Fi, int C);
+inline int sf_sub_len(int n) { return (n - 1) / 2 + 1; }   // floor((n + 2 - 3) / 2) + 1
+void launch_sf_scale_copy(const LaunchCtx& ctx, const float* src, float* dst, long n, float scale);
+struct SfAttnArgs {
+    const float* q = nullptr; const float* k = nullptr; const float* v = nullptr;
+    long ldq = 0, ldk = 0, ldv = 0;
+    float* out = nullptr; long ldo = 0;
+    int T = 0, n_head = 0, dh = 0;
+    float scale = 1.f;                 // applied to (ac + bd)
+    // relative-position term (Conformer RelPositionMultiHeadAttention): score += (q + v_bias) . pos[pos_row0 - i + j]
+    const float* pos = nullptr; long ldp = 0; int pos_row0 = 0;
+    const float* bias_u = nullptr; const float* bias_v = nullptr;
+};
+constexpr int kSfMaxFrames = 512;      // attention rows the score buffer in LDS is sized for
+void launch_sf_attention(const LaunchCtx& ctx, const SfAttnArgs& a);
+// Conformer convolution module core: GLU over [T][2d] -> depthwise conv1d (k taps, same padding) -> BatchNorm (eval)
+// -> Swish -> [T][d]; w tap-major [k][d]
+void launch_sf_glu_dwconv(const LaunchCtx& ctx, const float* in, const float* w, const float* b, const float* bn_mean,
+                          const float* bn_invstd, const float* bn_w, const float* bn_b, float* out, int T, int d,
+                          int taps);
+// relu -> Linear(d,d)+relu -> Linear(d,n_spk) -> sigmoid
+void launch_sf_head(const LaunchCtx& ctx, const float* x, const float* w1, const float* b1, const float* w2,
+                    const float* b2, float* out, int T, int d, int n_spk);
 
 // ---- select.hip -----------------------------------------------------------------------------
 void launch_apply_adjust(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, const int* adj_row,

@@ -181,12 +181,15 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
             for (int r = 0; r < 16; ++r) res[r] = 0.f;
         }
         const bool gelu = (g.flags & kGemmGelu) != 0;
+        const bool relu = (g.flags & kGemmRelu) != 0, swish = (g.flags & kGemmSwish) != 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row_base + (r & 3) + 8 * (r >> 2);
             float v = acc[r] + b;
             if (do_scale) v *= g.scale;
             if (gelu) v = gelu_erf(v);
+            if (relu) v = fmaxf(v, 0.f);
+            if (swish) v = v / (1.0f + expf(-v));
             v += res[r];
             if (row < g.M) g.C[(long)row * g.ldc + col] = v;
         }
@@ -332,6 +335,8 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
                 if (g.bias) v += g.bias[n];
                 if ((g.flags & kGemmScaleCols) && n < g.scale_cols) v *= g.scale;
                 if (g.flags & kGemmGelu) v = gelu_erf(v);
+                if (g.flags & kGemmRelu) v = fmaxf(v, 0.f);
+                if (g.flags & kGemmSwish) v = v / (1.0f + expf(-v));
                 if (g.flags & kGemmResidual) v += g.R[(long)m * g.ldr + n];
                 g.C[(long)m * g.ldc + n] = v;
                 if (g.kcache && n >= g.kv_d) {

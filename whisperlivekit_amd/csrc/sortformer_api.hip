@@ -1,0 +1,430 @@
+// C ABI of the streaming Sortformer diarizer network (include/wlk_hip.h, "a12 network"): packed weight arena,
+// workspace, and the launch sequence of one streaming step.  Kernels: sortformer.hip, gemm_f32.hip, layernorm.hip.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/wlk_hip.h"
+#include "common.h"
+
+namespace wlk {
+
+static int sf_fail(int code, const std::string& msg) {
+    set_last_error(msg);
+    return code;
+}
+template <typename F>
+static int sf_guarded(F&& f) {
+    try {
+        return f();
+    } catch (const HipError& e) {
+        return sf_fail(WLK_ERR_HIP, e.what());
+    } catch (const std::invalid_argument& e) {
+        return sf_fail(WLK_ERR_ARG, e.what());
+    } catch (const std::exception& e) {
+        return sf_fail(WLK_ERR_STATE, e.what());
+    }
+}
+
+struct SfSlot {
+    std::string name;
+    uint64_t offset, numel;
+};
+
+static int sf_freq_out(const wlk_sf_dims& D) { return sf_sub_len(sf_sub_len(sf_sub_len(D.n_mels))); }
+
+static std::vector<SfSlot> sf_layout(const wlk_sf_dims& D, uint64_t* total) {
+    std::vector<SfSlot> v;
+    uint64_t off = 0;
+    auto add = [&](const std::string& n, uint64_t numel) {
+        v.push_back({n, off, numel});
+        off += (numel + 63) / 64 * 64;
+    };
+    const uint64_t C = D.sub_channels, d = D.fc_d_model, ff = D.fc_ff, dt = D.tf_d_model, in = D.tf_inner;
+    add("pre.conv0.w", C * 9); add("pre.conv0.b", C);
+    for (int i = 1; i <= 2; ++i) {
+        const std::string s = std::to_string(i);
+        add("pre.dw" + s + ".w", 9 * C); add("pre.dw" + s + ".b", C);
+        add("pre.pw" + s + ".w", C * C); add("pre.pw" + s + ".b", C);
+    }
+    add("pre.out.w", d * C * sf_freq_out(D)); add("pre.out.b", d);
+    add("pos.table", (uint64_t)(2 * D.max_frames - 1) * d);
+    for (int i = 0; i < D.fc_layers; ++i) {
+        const std::string p = "fc." + std::to_string(i) + ".";
+        add(p + "ln_ff1.w", d); add(p + "ln_ff1.b", d);
+        add(p + "ff1a.w", ff * d); add(p + "ff1a.b", ff);
+        add(p + "ff1b.w", d * ff); add(p + "ff1b.b", d);
+        add(p + "ln_att.w", d); add(p + "ln_att.b", d);
+        add(p + "qkv.w", 3 * d * d); add(p + "qkv.b", 3 * d);
+        add(p + "pos.w", d * d);
+        add(p + "bias_u", d); add(p + "bias_v", d);
+        add(p + "out.w", d * d); add(p + "out.b", d);
+        add(p + "ln_conv.w", d); add(p + "ln_conv.b", d);
+        add(p + "pw1.w", 2 * d * d); add(p + "pw1.b", 2 * d);
+        add(p + "dw.w", (uint64_t)D.conv_kernel * d); add(p + "dw.b", d);
+        add(p + "bn.mean", d); add(p + "bn.invstd", d); add(p + "bn.w", d); add(p + "bn.b", d);
+        add(p + "pw2.w", d * d); add(p + "pw2.b", d);
+        add(p + "ln_ff2.w", d); add(p + "ln_ff2.b", d);
+        add(p + "ff2a.w", ff * d); add(p + "ff2a.b", ff);
+        add(p + "ff2b.w", d * ff); add(p + "ff2b.b", d);
+        add(p + "ln_out.w", d); add(p + "ln_out.b", d);
+    }
+    add("proj.w", dt * d); add("proj.b", dt);
+    for (int i = 0; i < D.tf_layers; ++i) {
+        const std::string p = "tf." + std::to_string(i) + ".";
+        add(p + "qkv.w", 3 * dt * dt); add(p + "qkv.b", 3 * dt);
+        add(p + "out.w", dt * dt); add(p + "out.b", dt);
+        add(p + "ln1.w", dt); add(p + "ln1.b", dt);
+        add(p + "in.w", in * dt); add(p + "in.b", in);
+        add(p + "outd.w", dt * in); add(p + "outd.b", dt);
+        add(p + "ln2.w", dt); add(p + "ln2.b", dt);
+    }
+    add("head.h.w", dt * dt); add("head.h.b", dt);
+    add("head.s.w", (uint64_t)D.n_spk * dt); add("head.s.b", D.n_spk);
+    if (total) *total = off;
+    return v;
+}
+
+static int sf_check_dims(const wlk_sf_dims* d) {
+    if (!d) return sf_fail(WLK_ERR_ARG, "dims is NULL");
+    if (d->n_mels < 8 || d->sub_channels < 4 || d->sub_channels % 4 || d->fc_layers < 0 || d->tf_layers < 0 ||
+        d->fc_heads < 1 || d->tf_heads < 1 || d->n_spk < 1 || d->n_spk > 64)
+        return sf_fail(WLK_ERR_ARG, "bad Sortformer dimensions");
+    if (d->fc_d_model % d->fc_heads || d->tf_d_model % d->tf_heads) return sf_fail(WLK_ERR_ARG, "width not divisible by heads");
+    const int dh = d->fc_d_model / d->fc_heads, dht = d->tf_d_model / d->tf_heads;
+    if (dh % 4 || dh > 64 || dht % 4 || dht > 64) return sf_fail(WLK_ERR_ARG, "head width must be a multiple of 4, <= 64");
+    if (d->fc_d_model % 4 || d->fc_ff % 4 || d->tf_d_model % 4 || d->tf_inner % 4 || d->fc_d_model > 1536 || d->tf_d_model > 1536)
+        return sf_fail(WLK_ERR_ARG, "layer widths must be multiples of 4 (<= 1536 for the model widths)");
+    if (d->conv_kernel < 1 || d->conv_kernel % 2 == 0) return sf_fail(WLK_ERR_ARG, "conv_kernel must be odd");
+    if (d->max_frames < 8 || d->max_frames > kSfMaxFrames) return sf_fail(WLK_ERR_ARG, "max_frames out of range");
+    if (d->max_feat_frames < 8 || d->max_feat_frames > 8 * kSfMaxFrames) return sf_fail(WLK_ERR_ARG, "max_feat_frames out of range");
+    return WLK_OK;
+}
+
+struct SfFcLayer {
+    const float *ln_ff1_w, *ln_ff1_b, *ff1a_w, *ff1a_b, *ff1b_w, *ff1b_b, *ln_att_w, *ln_att_b, *qkv_w, *qkv_b, *pos_w,
+        *bias_u, *bias_v, *out_w, *out_b, *ln_conv_w, *ln_conv_b, *pw1_w, *pw1_b, *dw_w, *dw_b, *bn_mean, *bn_invstd,
+        *bn_w, *bn_b, *pw2_w, *pw2_b, *ln_ff2_w, *ln_ff2_b, *ff2a_w, *ff2a_b, *ff2b_w, *ff2b_b, *ln_out_w, *ln_out_b;
+};
+struct SfTfLayer {
+    const float *qkv_w, *qkv_b, *out_w, *out_b, *ln1_w, *ln1_b, *in_w, *in_b, *outd_w, *outd_b, *ln2_w, *ln2_b;
+};
+
+}  // namespace wlk
+
+using namespace wlk;
+
+struct wlk_sortformer {
+    wlk_sf_dims D{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    float* arena = nullptr;
+    uint64_t arena_floats = 0;
+    std::vector<SfSlot> layout;
+    std::map<std::string, const SfSlot*> index;
+    bool finalized = false;
+    std::mutex mu;
+    std::vector<SfFcLayer> fc;
+    std::vector<SfTfLayer> tf;
+    // workspace
+    float *feats = nullptr, *ca = nullptr, *cb = nullptr, *emb_raw = nullptr, *x = nullptr, *xn = nullptr, *wide = nullptr,
+          *qkv = nullptr, *att = nullptr, *pos_full = nullptr, *tx = nullptr, *ty = nullptr, *tqkv = nullptr, *tatt = nullptr,
+          *th = nullptr, *preds = nullptr;
+    int last_T = 0;
+    std::vector<float*> owned;
+    const float* P(const std::string& n) const {
+        auto it = index.find(n);
+        if (it == index.end()) throw std::invalid_argument("unknown packed tensor " + n);
+        return arena + it->second->offset;
+    }
+};
+
+namespace wlk {
+static float* sf_alloc(wlk_sortformer* m, size_t n) {
+    float* p = nullptr;
+    WLK_HIP(hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(float)));
+    m->owned.push_back(p);
+    return p;
+}
+
+static void sf_linear(const LaunchCtx& c, const float* A, long lda, const float* W, const float* b, float* C, long ldc,
+                      int M, int N, int K, int flags, const float* R, long ldr, const char* tag, float scale = 1.f,
+                      int scale_cols = 0) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.bias = b; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.flags = flags; g.R = R; g.ldr = ldr; g.scale = scale; g.scale_cols = scale_cols;
+    launch_linear(c, g, tag);
+}
+
+// the network over m->emb_raw[0:T] -> m->preds[0:T]
+static void sf_network(wlk_sortformer* m, const LaunchCtx& c, int T) {
+    const wlk_sf_dims& D = m->D;
+    const int d = D.fc_d_model, ff = D.fc_ff, dh = d / D.fc_heads, L = D.max_frames;
+    launch_sf_scale_copy(c, m->emb_raw, m->x, (long)T * d, D.xscale);
+    for (int l = 0; l < D.fc_layers; ++l) {
+        const SfFcLayer& w = m->fc[l];
+        // x += 0.5 * FF1(LN(x))   (the 0.5 is folded into ff1b at pack time: exact, a power of two)
+        launch_layernorm(c, m->x, d, w.ln_ff1_w, w.ln_ff1_b, m->xn, d, T, d, "sf_ln");
+        sf_linear(c, m->xn, d, w.ff1a_w, w.ff1a_b, m->wide, ff, T, ff, d, kGemmSwish, nullptr, 0, "sf_ff_a");
+        sf_linear(c, m->wide, ff, w.ff1b_w, w.ff1b_b, m->x, d, T, d, ff, kGemmResidual, m->x, d, "sf_ff_b");
+        // x += RelPosMHA(LN(x))
+        launch_layernorm(c, m->x, d, w.ln_att_w, w.ln_att_b, m->xn, d, T, d, "sf_ln");
+        sf_linear(c, m->xn, d, w.qkv_w, w.qkv_b, m->qkv, 3 * d, T, 3 * d, d, 0, nullptr, 0, "sf_qkv");
+        SfAttnArgs a;
+        a.q = m->qkv; a.k = m->qkv + d; a.v = m->qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
+        a.out = m->att; a.ldo = d; a.T = T; a.n_head = D.fc_heads; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
+        a.pos = m->pos_full + (size_t)l * (2 * L - 1) * d; a.ldp = d; a.pos_row0 = L - 1;
+        a.bias_u = w.bias_u; a.bias_v = w.bias_v;
+        launch_sf_attention(c, a);
+        sf_linear(c, m->att, d, w.out_w, w.out_b, m->x, d, T, d, d, kGemmResidual, m->x, d, "sf_att_out");
+        // x += Conv(LN(x))
+        launch_layernorm(c, m->x, d, w.ln_conv_w, w.ln_conv_b, m->xn, d, T, d, "sf_ln");
+        sf_linear(c, m->xn, d, w.pw1_w, w.pw1_b, m->wide, 2 * d, T, 2 * d, d, 0, nullptr, 0, "sf_conv_pw1");
+        launch_sf_glu_dwconv(c, m->wide, w.dw_w, w.dw_b, w.bn_mean, w.bn_invstd, w.bn_w, w.bn_b, m->att, T, d, D.conv_kernel);
+        sf_linear(c, m->att, d, w.pw2_w, w.pw2_b, m->x, d, T, d, d, kGemmResidual, m->x, d, "sf_conv_pw2");
+        // x += 0.5 * FF2(LN(x)); x = LN_out(x)
+        launch_layernorm(c, m->x, d, w.ln_ff2_w, w.ln_ff2_b, m->xn, d, T, d, "sf_ln");
+        sf_linear(c, m->xn, d, w.ff2a_w, w.ff2a_b, m->wide, ff, T, ff, d, kGemmSwish, nullptr, 0, "sf_ff_a");
+        sf_linear(c, m->wide, ff, w.ff2b_w, w.ff2b_b, m->x, d, T, d, ff, kGemmResidual, m->x, d, "sf_ff_b");
+        launch_layernorm(c, m->x, d, w.ln_out_w, w.ln_out_b, m->x, d, T, d, "sf_ln");
+    }
+    const int dt = D.tf_d_model, dht = dt / D.tf_heads, inner = D.tf_inner;
+    sf_linear(c, m->x, d, m->P("proj.w"), m->P("proj.b"), m->tx, dt, T, dt, d, 0, nullptr, 0, "sf_proj");
+    const float qk_scale = 1.0f / sqrtf(sqrtf((float)dht));
+    for (int l = 0; l < D.tf_layers; ++l) {
+        const SfTfLayer& w = m->tf[l];
+        sf_linear(c, m->tx, dt, w.qkv_w, w.qkv_b, m->tqkv, 3 * dt, T, 3 * dt, dt, kGemmScaleCols, nullptr, 0, "sf_tf_qkv",
+                  qk_scale, 2 * dt);
+        SfAttnArgs a;
+        a.q = m->tqkv; a.k = m->tqkv + dt; a.v = m->tqkv + 2 * dt; a.ldq = a.ldk = a.ldv = 3 * dt;
+        a.out = m->tatt; a.ldo = dt; a.T = T; a.n_head = D.tf_heads; a.dh = dht; a.scale = 1.f;
+        launch_sf_attention(c, a);
+        sf_linear(c, m->tatt, dt, w.out_w, w.out_b, m->ty, dt, T, dt, dt, kGemmResidual, m->tx, dt, "sf_tf_out");
+        launch_layernorm(c, m->ty, dt, w.ln1_w, w.ln1_b, m->tx, dt, T, dt, "sf_ln");
+        sf_linear(c, m->tx, dt, w.in_w, w.in_b, m->th, inner, T, inner, dt, kGemmRelu, nullptr, 0, "sf_tf_in");
+        sf_linear(c, m->th, inner, w.outd_w, w.outd_b, m->ty, dt, T, dt, inner, kGemmResidual, m->tx, dt, "sf_tf_outd");
+        launch_layernorm(c, m->ty, dt, w.ln2_w, w.ln2_b, m->tx, dt, T, dt, "sf_ln");
+    }
+    launch_sf_head(c, m->tx, m->P("head.h.w"), m->P("head.h.b"), m->P("head.s.w"), m->P("head.s.b"), m->preds, T, dt,
+                   D.n_spk);
+}
+}  // namespace wlk
+
+extern "C" {
+
+int wlk_sf_arena_floats(const wlk_sf_dims* dims, uint64_t* n_floats) {
+    if (int rc = sf_check_dims(dims)) return rc;
+    if (!n_floats) return sf_fail(WLK_ERR_ARG, "NULL argument");
+    sf_layout(*dims, n_floats);
+    return WLK_OK;
+}
+
+int wlk_sf_tensor_lookup(const wlk_sf_dims* dims, const char* packed_name, uint64_t* offset_floats, uint64_t* numel) {
+    if (int rc = sf_check_dims(dims)) return rc;
+    if (!packed_name) return sf_fail(WLK_ERR_ARG, "NULL argument");
+    for (const auto& s : sf_layout(*dims, nullptr))
+        if (s.name == packed_name) {
+            if (offset_floats) *offset_floats = s.offset;
+            if (numel) *numel = s.numel;
+            return WLK_OK;
+        }
+    return sf_fail(WLK_ERR_ARG, std::string("unknown packed tensor ") + packed_name);
+}
+
+int wlk_sf_tensor_name(const wlk_sf_dims* dims, int index, const char** name) {
+    if (int rc = sf_check_dims(dims)) return rc;
+    if (!name) return sf_fail(WLK_ERR_ARG, "NULL argument");
+    static thread_local std::string hold;
+    const auto v = sf_layout(*dims, nullptr);
+    if (index < 0 || index >= (int)v.size()) return sf_fail(WLK_ERR_ARG, "tensor index out of range");
+    hold = v[index].name;
+    *name = hold.c_str();
+    return WLK_OK;
+}
+
+int wlk_sf_create(const wlk_sf_dims* dims, int device, wlk_sortformer** out) {
+    if (int rc = sf_check_dims(dims)) return rc;
+    if (!out) return sf_fail(WLK_ERR_ARG, "NULL argument");
+    return sf_guarded([&]() {
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+            return sf_fail(WLK_ERR_HIP, "no HIP device: the Sortformer backend has no CPU fallback");
+        WLK_HIP(hipSetDevice(device));
+        auto m = std::make_unique<wlk_sortformer>();
+        m->D = *dims;
+        m->device = device;
+        m->layout = sf_layout(*dims, &m->arena_floats);
+        for (const auto& s : m->layout) m->index[s.name] = &s;
+        WLK_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+        wlk_sortformer* p = m.get();
+        m->arena = sf_alloc(p, m->arena_floats);
+        WLK_HIP(hipMemset(m->arena, 0, m->arena_floats * sizeof(float)));
+        const wlk_sf_dims& D = m->D;
+        const size_t L = D.max_frames, d = D.fc_d_model, dt = D.tf_d_model, C = D.sub_channels;
+        const size_t T1 = sf_sub_len(D.max_feat_frames), F1 = sf_sub_len(D.n_mels);
+        m->feats = sf_alloc(p, (size_t)D.max_feat_frames * D.n_mels);
+        m->ca = sf_alloc(p, T1 * F1 * C);
+        m->cb = sf_alloc(p, T1 * F1 * C);
+        m->emb_raw = sf_alloc(p, L * d);
+        m->x = sf_alloc(p, L * d);
+        m->xn = sf_alloc(p, L * d);
+        m->wide = sf_alloc(p, L * std::max<size_t>(D.fc_ff, 2 * d));
+        m->qkv = sf_alloc(p, L * 3 * d);
+        m->att = sf_alloc(p, L * d);
+        m->pos_full = sf_alloc(p, (size_t)std::max(D.fc_layers, 1) * (2 * L - 1) * d);
+        m->tx = sf_alloc(p, L * dt);
+        m->ty = sf_alloc(p, L * dt);
+        m->tqkv = sf_alloc(p, L * 3 * dt);
+        m->tatt = sf_alloc(p, L * dt);
+        m->th = sf_alloc(p, L * D.tf_inner);
+        m->preds = sf_alloc(p, L * D.n_spk);
+        *out = m.release();
+        return WLK_OK;
+    });
+}
+
+int wlk_sf_upload(wlk_sortformer* m, const char* packed_name, const float* host, uint64_t numel) {
+    if (!m || !packed_name || !host) return sf_fail(WLK_ERR_ARG, "NULL argument");
+    return sf_guarded([&]() {
+        auto it = m->index.find(packed_name);
+        if (it == m->index.end()) return sf_fail(WLK_ERR_ARG, std::string("unknown packed tensor ") + packed_name);
+        if (it->second->numel != numel)
+            return sf_fail(WLK_ERR_ARG, std::string("size mismatch for ") + packed_name + ": expected " +
+                                            std::to_string(it->second->numel) + ", got " + std::to_string(numel));
+        WLK_HIP(hipSetDevice(m->device));
+        WLK_HIP(hipMemcpy(m->arena + it->second->offset, host, numel * sizeof(float), hipMemcpyHostToDevice));
+        m->finalized = false;
+        return WLK_OK;
+    });
+}
+
+int wlk_sf_finalize(wlk_sortformer* m) {
+    if (!m) return sf_fail(WLK_ERR_ARG, "model is NULL");
+    return sf_guarded([&]() {
+        std::lock_guard<std::mutex> lock(m->mu);
+        WLK_HIP(hipSetDevice(m->device));
+        const wlk_sf_dims& D = m->D;
+        m->fc.resize(D.fc_layers);
+        for (int i = 0; i < D.fc_layers; ++i) {
+            const std::string p = "fc." + std::to_string(i) + ".";
+            SfFcLayer& w = m->fc[i];
+            w.ln_ff1_w = m->P(p + "ln_ff1.w"); w.ln_ff1_b = m->P(p + "ln_ff1.b");
+            w.ff1a_w = m->P(p + "ff1a.w"); w.ff1a_b = m->P(p + "ff1a.b");
+            w.ff1b_w = m->P(p + "ff1b.w"); w.ff1b_b = m->P(p + "ff1b.b");
+            w.ln_att_w = m->P(p + "ln_att.w"); w.ln_att_b = m->P(p + "ln_att.b");
+            w.qkv_w = m->P(p + "qkv.w"); w.qkv_b = m->P(p + "qkv.b");
+            w.pos_w = m->P(p + "pos.w"); w.bias_u = m->P(p + "bias_u"); w.bias_v = m->P(p + "bias_v");
+            w.out_w = m->P(p + "out.w"); w.out_b = m->P(p + "out.b");
+            w.ln_conv_w = m->P(p + "ln_conv.w"); w.ln_conv_b = m->P(p + "ln_conv.b");
+            w.pw1_w = m->P(p + "pw1.w"); w.pw1_b = m->P(p + "pw1.b");
+            w.dw_w = m->P(p + "dw.w"); w.dw_b = m->P(p + "dw.b");
+            w.bn_mean = m->P(p + "bn.mean"); w.bn_invstd = m->P(p + "bn.invstd");
+            w.bn_w = m->P(p + "bn.w"); w.bn_b = m->P(p + "bn.b");
+            w.pw2_w = m->P(p + "pw2.w"); w.pw2_b = m->P(p + "pw2.b");
+            w.ln_ff2_w = m->P(p + "ln_ff2.w"); w.ln_ff2_b = m->P(p + "ln_ff2.b");
+            w.ff2a_w = m->P(p + "ff2a.w"); w.ff2a_b = m->P(p + "ff2a.b");
+            w.ff2b_w = m->P(p + "ff2b.w"); w.ff2b_b = m->P(p + "ff2b.b");
+            w.ln_out_w = m->P(p + "ln_out.w"); w.ln_out_b = m->P(p + "ln_out.b");
+        }
+        m->tf.resize(D.tf_layers);
+        for (int i = 0; i < D.tf_layers; ++i) {
+            const std::string p = "tf." + std::to_string(i) + ".";
+            SfTfLayer& w = m->tf[i];
+            w.qkv_w = m->P(p + "qkv.w"); w.qkv_b = m->P(p + "qkv.b");
+            w.out_w = m->P(p + "out.w"); w.out_b = m->P(p + "out.b");
+            w.ln1_w = m->P(p + "ln1.w"); w.ln1_b = m->P(p + "ln1.b");
+            w.in_w = m->P(p + "in.w"); w.in_b = m->P(p + "in.b");
+            w.outd_w = m->P(p + "outd.w"); w.outd_b = m->P(p + "outd.b");
+            w.ln2_w = m->P(p + "ln2.w"); w.ln2_b = m->P(p + "ln2.b");
+        }
+        // linear_pos(pos_emb) of every block for the longest sequence: a shorter sequence of T frames uses rows
+        // [max_frames - T, max_frames + T - 1) of it (RelPositionalEncoding centres its table the same way)
+        LaunchCtx c{m->stream, nullptr};
+        const int d = D.fc_d_model, rows = 2 * D.max_frames - 1;
+        for (int l = 0; l < D.fc_layers; ++l)
+            sf_linear(c, m->P("pos.table"), d, m->fc[l].pos_w, nullptr, m->pos_full + (size_t)l * rows * d, d, rows, d, d, 0,
+                      nullptr, 0, "sf_pos");
+        WLK_HIP(hipStreamSynchronize(m->stream));
+        m->finalized = true;
+        return WLK_OK;
+    });
+}
+
+int wlk_sf_step(wlk_sortformer* m, const float* feats_host, int n_feat, const float* ctx_embs_host, int n_ctx,
+                float* chunk_embs_host, int chunk_capacity_rows, int* n_chunk, float* preds_host,
+                int preds_capacity_rows) {
+    if (!m || !preds_host) return sf_fail(WLK_ERR_ARG, "NULL argument");
+    if (!m->finalized) return sf_fail(WLK_ERR_STATE, "wlk_sf_finalize has not been called");
+    if (n_feat < 0 || n_ctx < 0 || (n_feat > 0 && (!feats_host || !chunk_embs_host)) || (n_ctx > 0 && !ctx_embs_host))
+        return sf_fail(WLK_ERR_ARG, "bad step arguments");
+    if (n_feat > m->D.max_feat_frames) return sf_fail(WLK_ERR_CAPACITY, "feature chunk longer than max_feat_frames");
+    return sf_guarded([&]() {
+        std::lock_guard<std::mutex> lock(m->mu);
+        WLK_HIP(hipSetDevice(m->device));
+        const wlk_sf_dims& D = m->D;
+        const int d = D.fc_d_model, C = D.sub_channels;
+        int Tc = 0;
+        if (n_feat > 0) Tc = sf_sub_len(sf_sub_len(sf_sub_len(n_feat)));
+        const int T = n_ctx + Tc;
+        if (n_chunk) *n_chunk = Tc;
+        if (T < 1) return sf_fail(WLK_ERR_ARG, "empty step");
+        if (T > D.max_frames) return sf_fail(WLK_ERR_CAPACITY, "sequence longer than max_frames");
+        if (Tc > chunk_capacity_rows || T > preds_capacity_rows) return sf_fail(WLK_ERR_CAPACITY, "output buffer too small");
+        LaunchCtx c{m->stream, nullptr};
+        if (n_ctx > 0)
+            WLK_HIP(hipMemcpyAsync(m->emb_raw, ctx_embs_host, (size_t)n_ctx * d * sizeof(float), hipMemcpyHostToDevice, m->stream));
+        if (n_feat > 0) {
+            // ConvSubsampling.forward (dw_striding): conv0+ReLU, 2 x (depthwise s2, pointwise, ReLU), Linear
+            WLK_HIP(hipMemcpyAsync(m->feats, feats_host, (size_t)n_feat * D.n_mels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+            const int T1 = sf_sub_len(n_feat), F1 = sf_sub_len(D.n_mels), T2 = sf_sub_len(T1), F2 = sf_sub_len(F1),
+                      T3 = sf_sub_len(T2), F3 = sf_sub_len(F2);
+            launch_sf_conv0(c, m->feats, m->P("pre.conv0.w"), m->P("pre.conv0.b"), m->ca, n_feat, D.n_mels, C);
+            launch_sf_dwconv2d(c, m->ca, m->P("pre.dw1.w"), m->P("pre.dw1.b"), m->cb, T1, F1, C);
+            sf_linear(c, m->cb, C, m->P("pre.pw1.w"), m->P("pre.pw1.b"), m->ca, C, T2 * F2, C, C, kGemmRelu, nullptr, 0, "sf_pre_pw");
+            launch_sf_dwconv2d(c, m->ca, m->P("pre.dw2.w"), m->P("pre.dw2.b"), m->cb, T2, F2, C);
+            sf_linear(c, m->cb, C, m->P("pre.pw2.w"), m->P("pre.pw2.b"), m->ca, C, T3 * F3, C, C, kGemmRelu, nullptr, 0, "sf_pre_pw");
+            sf_linear(c, m->ca, (long)F3 * C, m->P("pre.out.w"), m->P("pre.out.b"), m->emb_raw + (size_t)n_ctx * d, d, T3, d,
+                      F3 * C, 0, nullptr, 0, "sf_pre_out");
+            WLK_HIP(hipMemcpyAsync(chunk_embs_host, m->emb_raw + (size_t)n_ctx * d, (size_t)Tc * d * sizeof(float),
+                                   hipMemcpyDeviceToHost, m->stream));
+        }
+        sf_network(m, c, T);
+        m->last_T = T;
+        WLK_HIP(hipMemcpyAsync(preds_host, m->preds, (size_t)T * D.n_spk * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        WLK_HIP(hipStreamSynchronize(m->stream));
+        return WLK_OK;
+    });
+}
+
+int wlk_sf_export(wlk_sortformer* m, const char* what, float* host, uint64_t capacity, uint64_t* n_written) {
+    if (!m || !what || !host) return sf_fail(WLK_ERR_ARG, "NULL argument");
+    return sf_guarded([&]() {
+        std::lock_guard<std::mutex> lock(m->mu);
+        WLK_HIP(hipSetDevice(m->device));
+        const float* src = nullptr;
+        uint64_t n = 0;
+        if (!strcmp(what, "fc_out")) { src = m->x; n = (uint64_t)m->last_T * m->D.fc_d_model; }
+        else if (!strcmp(what, "tf_out")) { src = m->tx; n = (uint64_t)m->last_T * m->D.tf_d_model; }
+        else return sf_fail(WLK_ERR_ARG, std::string("unknown export ") + what);
+        if (n > capacity) return sf_fail(WLK_ERR_CAPACITY, "export buffer too small");
+        WLK_HIP(hipMemcpy(host, src, n * sizeof(float), hipMemcpyDeviceToHost));
+        if (n_written) *n_written = n;
+        return WLK_OK;
+    });
+}
+
+int wlk_sf_destroy(wlk_sortformer* m) {
+    if (!m) return WLK_OK;
+    (void)hipSetDevice(m->device);
+    for (float* p : m->owned)
+        if (p) (void)hipFree(p);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+    return WLK_OK;
+}
+
+}  // extern "C"
