@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads for the baseline (0 = torch default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--audio", default="speech", choices=["speech", "noise"])
+    ap.add_argument("--no-diarization", action="store_true",
+                    help="skip the (separately timed) streaming-Sortformer leg reported under 'diarization'")
     return ap.parse_args()
 
 
@@ -100,6 +102,66 @@ def committed_latencies(calls):
         free_at = start + ins + wall
         lat += [free_at - e for e in ends]
     return lat
+
+
+def diarization_leg(audio, seconds, device, cpu_check):
+    """SURVEY 8 row a12, timed on its own (never part of `value`): the same stream through the streaming
+    Sortformer pass in 1.0 s chunks - HIP log-mel, 17 Conformer + 18 Transformer blocks over
+    [speaker cache | FIFO | chunk], host speaker-cache update.  Seeded random weights of the 4-speaker v2 geometry."""
+    from whisperlivekit_amd.diarization import HipSortformerDiarizationOnline
+    from whisperlivekit_amd.sortformer import HipSortformerModel, SortformerDims, synth_sortformer_state_dict
+    dims = SortformerDims()
+    sd = synth_sortformer_state_dict(dims, 0)
+    model = HipSortformerModel(dims, sd, device=device)
+    last = {}
+    inner = model.step
+
+    def step(feats, ctx):
+        a = time.perf_counter()
+        out = inner(feats, ctx)
+        last.update(device_ms=1e3 * (time.perf_counter() - a), feats=feats, ctx=ctx, preds=out[1], chunk=out[0])
+        return out
+
+    model.step = step
+
+    def run():
+        online = HipSortformerDiarizationOnline(model)
+        per_chunk, dev = [], []
+        for lo in range(0, len(audio) - 15999, 16000):
+            online.insert_audio_chunk(audio[lo:lo + 16000])
+            a = time.perf_counter()
+            online.diarize_sync()
+            per_chunk.append(1e3 * (time.perf_counter() - a))
+            dev.append(last["device_ms"])
+        return online, per_chunk, dev
+
+    run()                                   # warm-up: code paths, allocator, cold caches
+    t0 = time.perf_counter()
+    online, per_chunk, dev = run()
+    wall = time.perf_counter() - t0
+    n = len(per_chunk)
+    T = online.streaming_state.spkcache_len + online.streaming_state.fifo_len
+    out = dict(audio_s_per_s=round(n / wall, 2), rtf=round(wall / n, 6), chunks=n, chunk_s=1.0,
+               p50_chunk_ms=round(statistics.median(per_chunk), 3), max_chunk_ms=round(max(per_chunk), 3),
+               p50_device_call_ms=round(statistics.median(dev), 3), last_chunk_ms=round(per_chunk[-1], 3),
+               context_frames_at_end=int(T), weights="seeded random, diar_streaming_sortformer_4spk-v2 geometry",
+               parity="unpinned (NeMo absent); HIP == torch oracle checked in tests/test_gpu_sortformer.py")
+    if cpu_check:
+        import torch
+        from oracle import sortformer_oracle as so
+        tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+        od = so.SortformerDims()
+        with torch.no_grad():
+            a = time.perf_counter()
+            embs = torch.cat(([torch.from_numpy(last["ctx"])] if last["ctx"] is not None else []) +
+                             [so.pre_encode(tsd, od, torch.from_numpy(last["feats"]))], 0)
+            ref = so.forward_embeddings(tsd, od, embs).numpy()
+            cpu_ms = 1e3 * (time.perf_counter() - a)
+        out.update(cpu_oracle_last_chunk_ms=round(cpu_ms, 1), cpu_threads=torch.get_num_threads(),
+                   max_abs_err_vs_oracle_last_chunk=float(np.abs(ref - last["preds"]).max()))
+    model.step = inner
+    model.close()
+    return out
 
 
 def main():
@@ -248,6 +310,14 @@ def main():
                    sample=f"first {n} chunks ({n * 0.5:.1f} s) of the same {args.model} stream, "
                           f"torch {torch.__version__} CPU fp32 oracle, {t_cpu:.1f} s of CPU work")
 
+    diar = None
+    if rank == 0 and not args.no_diarization:
+        try:
+            diar = diarization_leg(audios[0], args.seconds, local, cpu_check=not args.no_cpu_baseline)
+            log(f"diarization leg done: {diar['p50_chunk_ms']} ms per 1 s chunk")
+        except Exception as e:          # never let the side leg take the headline line down
+            diar = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         timed = [p for step in procs[args.warmup:] for p in step]
         n_enc = sum(p.model.counters["encode"] for p in timed)
@@ -282,6 +352,7 @@ def main():
             "kernels": kernels,
             "launch_tags": tags,
             "cpu_baseline": cpu,
+            "diarization": diar,
             "host_cores": os.cpu_count(),
         }
         print(json.dumps(out))

@@ -309,6 +309,31 @@ class OracleConfig:
     static_init_prompt: Optional[str] = None
     language: str = "en"
     never_fire: bool = False
+    cif_ckpt_path: Optional[str] = None          # a11: optional CIF end-of-word head (state dict of a Linear(d, 1))
+
+
+def cif_fire_at_boundary(feature: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> bool:
+    """a11, simul_whisper/eow_detection.py:40-77 on the content rows [T, d] of the encoder output: sigmoid
+    weights rescaled to an integer sum (peaks above 0.999 are flattened, at most 10 rounds), integrated over
+    all but the last frame modulo 1; fire when the first frame at/after the last completed unit is one of
+    the final two."""
+    t = feature.shape[0]
+    alphas = torch.sigmoid(feature @ weight.reshape(-1) + bias.reshape(()))
+    total = alphas.sum()
+    alphas = alphas * (torch.round(total).int().float() / total)
+    rounds = 0
+    while bool((alphas > 0.999).any()):
+        rounds += 1
+        if rounds > 10:
+            break
+        for y in torch.nonzero(alphas > 0.999).flatten().tolist():
+            if alphas[y] >= 0.999:
+                live = alphas.ne(0).float()
+                alphas = alphas * 0.5 + (0.5 * alphas.sum() / live.sum()) * live
+    integ = torch.cumsum(alphas[:-1], dim=0)
+    integ = integ - (integ[-1] // 0.999) * 1.0
+    pos = torch.nonzero(integ >= 0).flatten()
+    return bool(pos.numel() and pos[0] >= t - 2)
 
 
 @dataclass
@@ -317,14 +342,22 @@ class Word:
     end: float
     text: str
     speaker: int = -1
+    detected_language: Optional[str] = None      # align_att_base.py:437
 
 
 class OracleAlignAtt:
     """One streaming session: the AlignAtt loop of align_att_base.py:174-322 over the oracle
     numerics above, with the PyTorch backend's state handling (simul_whisper.py:219-262)."""
 
-    def __init__(self, sd, dims, align_heads, tokenizer, filters, cfg: OracleConfig = OracleConfig()):
+    def __init__(self, sd, dims, align_heads, tokenizer, filters, cfg: OracleConfig = OracleConfig(),
+                 tokenizer_factory=None):
         self.sd, self.dims, self.tok, self.cfg = sd, dims, tokenizer, cfg
+        self.tokenizer_factory = tokenizer_factory      # language code -> tokenizer (language="auto" only)
+        self.detected_language = None if cfg.language == "auto" else cfg.language
+        self.cif = None                                 # eow_detection.py:12-37
+        if cfg.cif_ckpt_path:
+            ck = torch.load(cfg.cif_ckpt_path, map_location="cpu", weights_only=True)
+            self.cif = (ck["weight"].float(), ck["bias"].float())
         self.align_heads = list(align_heads)
         self.filters = torch.from_numpy(np.asarray(filters)).float()
         suppress = [tokenizer.transcribe, tokenizer.translate, tokenizer.sot, tokenizer.sot_prev,
@@ -436,6 +469,38 @@ class OracleAlignAtt:
             flat += list(t)
         return [list(flat) for _ in range(self.cfg.beam_size)]
 
+    def _fire_at_boundary(self, content_feature: torch.Tensor) -> bool:     # simul_whisper.py:256-264
+        if self.cif is None:                      # no checkpoint: always fire unless never_fire (eow_detection.py:12-25)
+            return not self.cfg.never_fire
+        if self.cfg.never_fire:
+            return False
+        return cif_fire_at_boundary(content_feature, *self.cif)
+
+    def _detect_language_if_needed(self, enc):                              # align_att_base.py:153-170
+        """language="auto": once >= 2 s have passed since the first timestamp, one <|sot|> decoder step, soft-max
+        over the language tokens (AlignAtt.lang_id, simul_whisper.py:266-292), then restart the token state with
+        the detected language's tokenizer."""
+        if not (self.cfg.language == "auto" and self.detected_language is None and self.first_timestamp):
+            return None
+        if self.segments_len() - self.first_timestamp < 2.0:
+            return None
+        tok = self.tok
+        logits, _ = decoder_forward(self.sd, self.dims, torch.tensor([[tok.sot]]), enc, DecoderCache(self.dims.n_text_layer))
+        logits = logits[:, 0].clone()
+        mask = torch.ones(logits.shape[-1], dtype=torch.bool)
+        mask[list(tok.all_language_tokens)] = False
+        logits[:, mask] = -np.inf
+        probs = logits.softmax(dim=-1)[0]
+        table = {c: float(probs[j]) for j, c in zip(tok.all_language_tokens, tok.all_language_codes)}
+        top_lan, _ = max(table.items(), key=lambda kv: kv[1])
+        self.tok = self.tokenizer_factory(top_lan)
+        self.last_attend_frame = -self.cfg.rewind_threshold
+        self.cumulative_time_offset = 0.0
+        self._init_tokens()
+        self._init_context()
+        self.detected_language = top_lan
+        return sorted(table.items(), key=lambda kv: -kv[1])[:3]
+
     # -- the AlignAtt call -----------------------------------------------------------------
     @torch.no_grad()
     def infer(self, is_last=False) -> List[Word]:
@@ -445,10 +510,13 @@ class OracleAlignAtt:
         audio = torch.cat(self.segments) if len(self.segments) > 1 else self.segments[0]
         mel, content_mel_len = encoder_input_from_audio(audio, self.filters)
         enc = encoder_forward(self.sd, self.dims, mel)
+        lang_top = self._detect_language_if_needed(enc)
+        tok = self.tok
         self._trim_context()
         cur = torch.tensor(self._current_tokens(), dtype=torch.long)
+        fire = self._fire_at_boundary(enc[0, :content_mel_len])
         rec = {"n_samples": int(audio.shape[0]), "content_mel_len": content_mel_len, "mel": mel,
-               "enc": enc, "prefill_tokens": cur[0].tolist(), "steps": []}
+               "enc": enc, "prefill_tokens": cur[0].tolist(), "steps": [], "fire": fire, "lang_top": lang_top}
         self.trace.append(rec)
 
         sum_logprobs = torch.zeros(cfg.beam_size)
@@ -518,9 +586,8 @@ class OracleAlignAtt:
             new = list(self.pending_tokens) + new
             times = list(self.pending_times) + times
         words, groups = tok.split_to_word_tokens(new)
-        # fire_at_boundary: always True without a CIF checkpoint unless never_fire is set
-        # (eow_detection.py:12-25, simul_whisper.py:256-264); _split_tokens align_att_base.py:326-337
-        if (not cfg.never_fire) or is_last:
+        # _split_tokens align_att_base.py:326-337 (fire decided before decoding, align_att_base.py:193)
+        if fire or is_last:
             hypothesis = new
         else:
             hypothesis = [t for g in groups[:-1] for t in g] if len(words) > 1 else []
@@ -554,7 +621,7 @@ class OracleAlignAtt:
             end = max(end, start + 0.02)
             idx += n
             off = self.global_time_offset
-            out.append(Word(round(start, 2) + off, round(end, 2) + off, word, self.speaker))
+            out.append(Word(round(start, 2) + off, round(end, 2) + off, word, self.speaker, self.detected_language))
         return out
 
     def _hold_incomplete(self, words, groups, times):                       # align_att_base.py:443-488
@@ -677,6 +744,8 @@ class OracleOnlineProcessor:
             return [], self.end
         if not words:
             return [], self.end
+        if self.model.cfg.language == "auto" and words[0].detected_language is None:   # backend.py:239-241
+            return [], self.end                  # held in the display buffer until the language is known
         stable = self._stable(words)
         if not stable:
             if self.last_committed_end - max(float(w.end or 0.0) for w in words) > 1.0:

@@ -197,6 +197,22 @@ def _record_session(proc):
         return new, completed
     m._update_tokens = _upd
 
+    orig_fire = m.fire_at_boundary
+    def _fire(feature):
+        r = bool(orig_fire(feature))
+        cur["fire"] = r
+        log["calls"][-1]["fire"] = r
+        return r
+    m.fire_at_boundary = _fire
+
+    orig_lang = m.lang_id
+    def _lang(enc):
+        toks, probs = orig_lang(enc)
+        top = sorted(probs[0].items(), key=lambda kv: -kv[1])[:3]
+        log["calls"][-1]["lang_top"] = [[c, float(p)] for c, p in top]
+        return toks, probs
+    m.lang_id = _lang
+
     orig_fr = m._get_attended_frames
     def _fr(attn):
         frames, first = orig_fr(attn)
@@ -218,7 +234,10 @@ def run_stream(name, audio, cfg_over=None, chunk=8000, script=None, seed=0, chun
     ``script`` maps a chunk index to an event performed BEFORE that chunk is inserted:
     ("silence", seconds) -> start_silence()+end_silence(), ("speaker", id) -> new_speaker()."""
     model = build_reference_model(name, seed)
-    cfg = engine_cfg(name, **(cfg_over or {}))
+    over = dict(cfg_over or {})
+    if str(over.get("cif_ckpt_path", "")).startswith("golden:"):
+        over["cif_ckpt_path"] = os.path.join(OUT, over["cif_ckpt_path"][len("golden:"):])
+    cfg = engine_cfg(name, **over)
     proc = make_processor(model, cfg)
     if cfg_over and "nonspeech_prob" in cfg_over:
         proc.model.cfg.nonspeech_prob = cfg_over["nonspeech_prob"]
@@ -250,31 +269,63 @@ def run_stream(name, audio, cfg_over=None, chunk=8000, script=None, seed=0, chun
                            hypothesis=[t[0].tolist() for t in proc.model.state.tokens[1:]][-1]
                            if len(proc.model.state.tokens) > 1 else [],
                            context=proc.model.state.context.text,
+                           detected_language=proc.model.state.detected_language,
                            last_attend_frame=int(proc.model.state.last_attend_frame),
                            cumulative_time_offset=float(proc.model.state.cumulative_time_offset)))
     return dict(model=name, seed=seed, cfg=cfg_over or {}, chunk=chunk, n_samples=len(audio),
                 calls=log["calls"], events=events)
 
 
+def gen_cif():
+    """a11: a seeded CIF head for d = 128 and known answers of the reference's fire_at_boundary
+    (simul_whisper/eow_detection.py:62-77) on seeded feature tensors of assorted lengths / scales."""
+    from whisperlivekit.simul_whisper.eow_detection import fire_at_boundary
+    g = torch.Generator().manual_seed(83)     # gives a mix of fire / hold-back on the micro_cif stream
+    lin = torch.nn.Linear(128, 1)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(1, 128, generator=g) * 0.25)
+        lin.bias.copy_(torch.tensor([-1.0]))
+    torch.save({k: v.detach().clone() for k, v in lin.state_dict().items()}, os.path.join(OUT, "cif_micro.pt"))
+    kat = []
+    for i in range(48):
+        T = [2, 3, 5, 8, 13, 25, 50, 75, 150, 400, 901, 1500][i % 12]
+        scale = [0.3, 1.0, 3.0, 8.0][i // 12]
+        feat = torch.randn(1, T, 128, generator=torch.Generator().manual_seed(1000 + i)) * scale
+        with torch.no_grad():
+            kat.append(dict(seed=1000 + i, T=T, scale=scale, fire=bool(fire_at_boundary(feat, lin))))
+    json.dump(kat, open(os.path.join(OUT, "cif_kat.json"), "w"))
+    print("cif: fire in", sum(k["fire"] for k in kat), "of", len(kat), "cases")
+
+
 def gen_streams():
-    cases = {}
+    only = set(os.environ.get("GOLDEN_ONLY", "").split(",")) - {""}    # regenerate a subset: GOLDEN_ONLY=a,b
+    want = lambda k: not only or k in only
     a12 = synth.to_pcm16_roundtrip(synth.speech_like(12.0, 0))
-    cases["micro_12s"] = run_stream("micro.en", a12)
-    a34 = synth.to_pcm16_roundtrip(synth.speech_like(34.0, 1))
-    cases["micro_34s_evict"] = run_stream("micro.en", a34, chunk=16000)
-    cases["micro_beam2"] = run_stream("micro.en", a12[:96000], cfg_over=dict(beam_size=2))
-    cases["micro_neverfire"] = run_stream("micro.en", a12[:96000], cfg_over=dict(never_fire=True))
-    cases["micro_nospeech"] = run_stream("micro.en", a12[:48000], cfg_over=dict(nonspeech_prob=1e-7))
-    cases["micro_events"] = run_stream("micro.en", a12, script={6: ("silence", 1.0), 12: ("silence", 6.0),
-                                                               18: ("speaker", 2)})
-    n8 = synth.to_pcm16_roundtrip(synth.white_noise(6.0, 3))
-    cases["micro_noise_ragged"] = run_stream(
-        "micro.en", n8, chunks=[(0, 700), (700, 861), (861, 5000), (5000, 5000 + 8000), (13000, 40000),
-                                (40000, 96000)])
     a6 = synth.to_pcm16_roundtrip(synth.speech_like(6.0, 2))
-    cases["tiny_6s"] = run_stream("tiny.en", a6)
-    cases["base_4s"] = run_stream("base.en", a6[:64000])
-    for k, v in cases.items():
+    n8 = synth.to_pcm16_roundtrip(synth.white_noise(6.0, 3))
+    table = {
+        "micro_12s": lambda: run_stream("micro.en", a12),
+        "micro_34s_evict": lambda: run_stream("micro.en", synth.to_pcm16_roundtrip(synth.speech_like(34.0, 1)),
+                                              chunk=16000),
+        "micro_beam2": lambda: run_stream("micro.en", a12[:96000], cfg_over=dict(beam_size=2)),
+        "micro_neverfire": lambda: run_stream("micro.en", a12[:96000], cfg_over=dict(never_fire=True)),
+        "micro_nospeech": lambda: run_stream("micro.en", a12[:48000], cfg_over=dict(nonspeech_prob=1e-7)),
+        "micro_events": lambda: run_stream("micro.en", a12, script={6: ("silence", 1.0), 12: ("silence", 6.0),
+                                                                   18: ("speaker", 2)}),
+        "micro_noise_ragged": lambda: run_stream(
+            "micro.en", n8, chunks=[(0, 700), (700, 861), (861, 5000), (5000, 5000 + 8000), (13000, 40000),
+                                    (40000, 96000)]),
+        "tiny_6s": lambda: run_stream("tiny.en", a6),
+        "base_4s": lambda: run_stream("base.en", a6[:64000]),
+        # a11: CIF end-of-word head (seeded synthetic Linear(128, 1), tests/golden/cif_micro.pt) and
+        # language auto-detect on the multilingual twin of the micro shape
+        "micro_cif": lambda: run_stream("micro.en", a12[:128000], cfg_over=dict(cif_ckpt_path="golden:cif_micro.pt")),
+        "micromulti_auto": lambda: run_stream("micro", a12[:128000], cfg_over=dict(language="auto"), seed=4),
+    }
+    for k, make in table.items():
+        if not want(k):
+            continue
+        v = make()
         json.dump(v, open(os.path.join(OUT, f"stream_{k}.json"), "w"))
         n_steps = sum(len(c["steps"]) for c in v["calls"])
         n_tok = sum(len(e["tokens"]) for e in v["events"])
@@ -288,5 +339,7 @@ if __name__ == "__main__":
         gen_mel()
     if not which or "numerics" in which:
         gen_model_numerics()
+    if not which or "cif" in which:
+        gen_cif()
     if not which or "streams" in which:
         gen_streams()

@@ -64,15 +64,37 @@ def stream_audio(case_name):
         "micro_noise_ragged": lambda: synth.to_pcm16_roundtrip(synth.white_noise(6.0, 3)),
         "tiny_6s": lambda: synth.to_pcm16_roundtrip(synth.speech_like(6.0, 2)),
         "base_4s": lambda: synth.to_pcm16_roundtrip(synth.speech_like(6.0, 2))[:64000],
+        "micro_cif": lambda: a12()[:128000],
+        "micromulti_auto": lambda: a12()[:128000],
     }
     return table[case_name]()
+
+
+def resolve_cfg(cfg_over):
+    """Stream fixtures name files of tests/golden as ``golden:<file>`` (scripts/gen_golden.py:run_stream)."""
+    over = dict(cfg_over or {})
+    if str(over.get("cif_ckpt_path") or "").startswith("golden:"):
+        over["cif_ckpt_path"] = os.path.join(GOLDEN, over["cif_ckpt_path"][len("golden:"):])
+    return over
+
+
+def asr_kwargs(cfg_over):
+    """Golden cfg overrides (AlignAttConfig field names) -> HipSimulStreamingASR keyword names."""
+    over = resolve_cfg(cfg_over)
+    kw = {}
+    if "beam_size" in over:
+        kw["beams"] = over.pop("beam_size")
+    if "language" in over:
+        kw["lan"] = over.pop("language")
+    kw.update(over)
+    return kw
 
 
 def make_oracle_session(model_name, cfg_over=None, seed=0):
     from oracle import whisper_oracle as wo
     dims = MODEL_DIMS[model_name]
-    cfg = wo.OracleConfig(**(cfg_over or {}))
-    tok = get_tokenizer(dims.is_multilingual, num_languages=dims.num_languages,
-                        language="en" if dims.is_multilingual else None, synthetic=True)
-    return wo.OracleAlignAtt(oracle_sd(model_name, seed), dims, ALIGNMENT_HEADS[model_name], tok,
-                             mel_filterbank(dims.n_mels), cfg)
+    cfg = wo.OracleConfig(**resolve_cfg(cfg_over))
+    factory = lambda lang: get_tokenizer(dims.is_multilingual, num_languages=dims.num_languages,
+                                         language=lang if dims.is_multilingual else None, synthetic=True)
+    return wo.OracleAlignAtt(oracle_sd(model_name, seed), dims, ALIGNMENT_HEADS[model_name], factory("en"),
+                             mel_filterbank(dims.n_mels), cfg, tokenizer_factory=factory)

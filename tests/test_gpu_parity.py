@@ -309,15 +309,10 @@ def test_select_and_alignment_against_oracle(name, beam):
 from test_oracle_golden import STREAMS, check_stream_against_golden, replay_stream  # noqa: E402
 
 
-def make_hip_processor(model_name, cfg_over):
+def make_hip_processor(model_name, cfg_over, seed=0):
     from test_policy_golden import RecordingProcessor
     from whisperlivekit_amd.backend import HipSimulStreamingASR
-    cfg_over = dict(cfg_over or {})
-    kw = {}
-    if "beam_size" in cfg_over:
-        kw["beams"] = cfg_over.pop("beam_size")
-    kw.update(cfg_over)
-    asr = HipSimulStreamingASR(model_name, hip_model=hip_model(model_name), **kw)
+    asr = HipSimulStreamingASR(model_name, hip_model=hip_model(model_name, seed), **H.asr_kwargs(cfg_over))
     return RecordingProcessor(asr)
 
 

@@ -53,7 +53,8 @@ def test_oracle_encoder_decoder_match_reference(name):
 
 
 STREAMS = ["micro_12s", "micro_34s_evict", "micro_beam2", "micro_neverfire", "micro_nospeech",
-           "micro_events", "micro_noise_ragged", "tiny_6s", "base_4s"]
+           "micro_events", "micro_noise_ragged", "tiny_6s", "base_4s",
+           "micro_cif", "micromulti_auto"]      # a11: CIF end-of-word head, language auto-detect
 
 
 def replay_stream(case, make_processor):
@@ -61,7 +62,7 @@ def replay_stream(case, make_processor):
     the list of (event, tokens, upto)."""
     g = H.golden_json(f"stream_{case}.json")
     audio = H.stream_audio(case)
-    proc = make_processor(g["model"], g["cfg"])
+    proc = make_processor(g["model"], g["cfg"], g.get("seed", 0))
     t_end = 0.0
     got = []
     for ev in g["events"]:
@@ -75,6 +76,9 @@ def replay_stream(case, make_processor):
             t_end += (ev["hi"] - ev["lo"]) / 16000
             proc.insert_audio_chunk(audio[ev["lo"]:ev["hi"]].copy(), t_end)
             toks, upto = proc.process_iter()
+            if "detected_language" in ev:          # a11: language="auto" switches tokenizer mid-stream
+                state = getattr(proc.model, "state", proc.model)
+                assert state.detected_language == ev["detected_language"], (ev["at_chunk"], state.detected_language)
         got.append((ev, toks, upto))
     return g, proc, got
 
@@ -93,6 +97,11 @@ def check_stream_against_golden(g, trace, got, tol=1e-4, allow_ties=False):
     returned as (call index, step index, kind)."""
     for ci, (rec, ref) in enumerate(zip(trace, g["calls"])):
         assert rec["content_mel_len"] == ref["content_mel_len"]
+        if "fire" in ref and "fire" in rec:        # a11: CIF end-of-word decision of this call
+            assert rec["fire"] == ref["fire"], f"fire_at_boundary mismatch at call {ci}"
+        if ref.get("lang_top") and rec.get("lang_top"):
+            assert rec["lang_top"][0][0] == ref["lang_top"][0][0]
+            assert abs(rec["lang_top"][0][1] - ref["lang_top"][0][1]) <= 1e-4
         if ref["steps"] and ref["steps"][0]["fed_tokens"] is not None:
             assert rec["prefill_tokens"] == ref["steps"][0]["fed_tokens"]
         for si, (st, rs) in enumerate(zip(rec["steps"], ref["steps"])):
@@ -124,8 +133,8 @@ def check_stream_against_golden(g, trace, got, tol=1e-4, allow_ties=False):
 
 @pytest.mark.parametrize("case", STREAMS)
 def test_oracle_stream_matches_reference(case):
-    def mk(model, cfg):
-        return wo.OracleOnlineProcessor(H.make_oracle_session(model, cfg))
+    def mk(model, cfg, seed=0):
+        return wo.OracleOnlineProcessor(H.make_oracle_session(model, cfg, seed))
     g, proc, got = replay_stream(case, mk)
     check_stream_against_golden(g, proc.model.trace, got)
     for ev, _, _ in got:
@@ -133,3 +142,21 @@ def test_oracle_stream_matches_reference(case):
             last = ev
     assert proc.model.context_text == last["context"]
     assert proc.model.last_attend_frame == last["last_attend_frame"]
+
+
+# ---- a11: CIF end-of-word head, pinned by the reference's own fire_at_boundary (tests/golden/cif_kat.json) ----
+def _cif_case(k):
+    feat = torch.randn(1, k["T"], 128, generator=torch.Generator().manual_seed(k["seed"])) * k["scale"]
+    return feat[0]
+
+
+def test_cif_fire_at_boundary_known_answers():
+    import os
+    from whisperlivekit_amd.policy import cif_fire_at_boundary as product_cif
+    ck = torch.load(os.path.join(H.GOLDEN, "cif_micro.pt"), map_location="cpu", weights_only=True)
+    kat = H.golden_json("cif_kat.json")
+    assert 8 <= sum(k["fire"] for k in kat) <= len(kat) - 8          # both answers are exercised
+    for k in kat:
+        feat = _cif_case(k)
+        assert wo.cif_fire_at_boundary(feat, ck["weight"], ck["bias"]) == k["fire"], k
+        assert product_cif(feat.numpy(), ck["weight"].numpy().reshape(-1), float(ck["bias"][0])) == k["fire"], k

@@ -49,6 +49,19 @@ class RecordingProcessor(HipSimulStreamingOnlineProcessor):
             self.trace[-1]["steps"][-1]["frame"] = first
             return frames, first
 
+        fire0, lang0 = m.fire_at_boundary, m.lang_id
+
+        def _fire(feature):
+            r = bool(fire0(feature))
+            self.trace[-1]["fire"] = r
+            return r
+
+        def _lang(enc):
+            toks, probs = lang0(enc)
+            self.trace[-1]["lang_top"] = sorted(probs[0].items(), key=lambda kv: -kv[1])[:3]
+            return toks, probs
+
+        m.fire_at_boundary, m.lang_id = _fire, _lang
         m._encode, m._get_logits_and_cross_attn, m._check_no_speech = _encode, _logits, _ns
         m._update_tokens, m._get_attended_frames = _upd, _fr
 
@@ -56,15 +69,10 @@ class RecordingProcessor(HipSimulStreamingOnlineProcessor):
         return super().new_speaker(P.ChangeSpeaker(speaker=speaker, start=start))
 
 
-def make_fake_processor(model_name, cfg_over):
+def make_fake_processor(model_name, cfg_over, seed=0):
     dims = MODEL_DIMS[model_name]
-    fake = FakeHipModel(dims, H.oracle_sd(model_name), ALIGNMENT_HEADS[model_name])
-    cfg_over = dict(cfg_over or {})
-    kw = {}
-    if "beam_size" in cfg_over:
-        kw["beams"] = cfg_over.pop("beam_size")
-    kw.update(cfg_over)
-    asr = HipSimulStreamingASR(model_name, hip_model=fake, **kw)
+    fake = FakeHipModel(dims, H.oracle_sd(model_name, seed), ALIGNMENT_HEADS[model_name])
+    asr = HipSimulStreamingASR(model_name, hip_model=fake, **H.asr_kwargs(cfg_over))
     return RecordingProcessor(asr)
 
 

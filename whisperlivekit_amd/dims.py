@@ -57,6 +57,7 @@ MODEL_DIMS: Dict[str, ModelDims] = {
     # structural constant of the path (1500 audio positions, 448 text positions, 64-wide
     # heads, the .en vocabulary) and is used by the parity tests to stay fast on CPU.
     "micro.en": _d(80, 128, 2, 2, 51864, 128, 2, 2),
+    "micro": _d(80, 128, 2, 2, 51865, 128, 2, 2),      # multilingual twin (language auto-detect tests)
     "tiny.en": _d(80, 384, 6, 4, 51864, 384, 6, 4),
     "tiny": _d(80, 384, 6, 4, 51865, 384, 6, 4),
     "base.en": _d(80, 512, 8, 6, 51864, 512, 8, 6),
@@ -72,6 +73,7 @@ MODEL_DIMS: Dict[str, ModelDims] = {
 
 ALIGNMENT_HEADS: Dict[str, List[Tuple[int, int]]] = {
     "micro.en": [(1, 0), (1, 1)],
+    "micro": [(1, 0), (1, 1)],
     "tiny.en": [(1, 0), (2, 0), (2, 5), (3, 0), (3, 1), (3, 2), (3, 3), (3, 4)],
     "tiny": [(2, 2), (3, 0), (3, 2), (3, 3), (3, 4), (3, 5)],
     "base.en": [(3, 3), (4, 7), (5, 1), (5, 5), (5, 7)],

@@ -525,25 +525,32 @@ class GreedyUpdate:
 def cif_fire_at_boundary(features: np.ndarray, weight: np.ndarray, bias: float) -> bool:
     """End-of-word test of the optional CIF head (simul_whisper/eow_detection.py:40-77) on the
     content part of the encoder output [T, d]: alpha = sigmoid(Linear(x)); rescale so the sum is
-    an integer; fire if the first position after the last full unit lies in the final two frames."""
+    an integer; fire if the first position after the last full unit lies in the final two frames.
+
+    Host-side and tiny (one [T, d] x [d] product); evaluated with torch's CPU operators in the reference's
+    operation order because the decision is discrete and sits on fp32 rounding when the final frames carry
+    ~zero weight (the integral then lands within an ulp of an integer; tests/golden/cif_kat.json has such a
+    case) - numpy's reduction order flips it."""
+    import torch
     t = features.shape[0]
-    alphas = 1.0 / (1.0 + np.exp(-(features.astype(np.float32) @ weight.astype(np.float32) + np.float32(bias))))
-    alphas = alphas.astype(np.float32)
+    x = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32))
+    lin_w = torch.from_numpy(np.ascontiguousarray(weight, dtype=np.float32)).reshape(1, -1)
+    lin_b = torch.tensor([bias], dtype=torch.float32)
+    alphas = torch.sigmoid(torch.nn.functional.linear(x.unsqueeze(0), lin_w, lin_b).squeeze(2))[0]
     total = alphas.sum()
-    target = np.float32(np.round(total))
-    a = alphas * (target / total)
+    a = alphas * (torch.round(total).int().float() / total)
     rounds = 0
-    while (a > 0.999).any():
+    while bool((a > 0.999).any()):
         rounds += 1
         if rounds > 10:
             break
-        for idx in np.nonzero(a > 0.999)[0]:
+        for idx in torch.nonzero(a > 0.999).flatten().tolist():
             if a[idx] >= 0.999:
-                mask = (a != 0).astype(np.float32)
+                mask = a.ne(0).float()
                 a = a * 0.5 + (0.5 * a.sum() / mask.sum()) * mask
-    integ = np.cumsum(a[:-1], dtype=np.float32)
-    if integ.size == 0:
+    integ = torch.cumsum(a[:-1], dim=0)
+    if integ.numel() == 0:
         return False
-    integ = integ - np.float32(integ[-1] // 0.999) * 1.0
-    pos = np.nonzero(integ >= 0)[0]
-    return bool(pos.size and pos[0] >= t - 2)
+    integ = integ - (integ[-1] // 0.999) * 1.0
+    pos = torch.nonzero(integ >= 0).flatten()
+    return bool(pos.numel() and int(pos[0]) >= t - 2)
