@@ -188,7 +188,8 @@ int wlk_sf_destroy(wlk_sortformer* m);
 const char* wlk_diag_last_error(void);
 /* c[m,n] = epilogue(a[m,k](row stride lda, a_floats floats in total) . w[n,k]^T + bias); flags:
  * 1 = exact-erf GELU, 2 = add r[m, ldr] after the activation, 4 = scale columns < scale_cols,
- * 8 = ReLU, 16 = Swish */
+ * 8 = ReLU, 16 = Swish.  force_gemv: 0 = shape-based choice among the MFMA kernels, 1 = weight-streaming kernel
+ * (m <= 8), 2 = the k-wave MFMA kernel of under-filled grids (four waves split K of one 32x32 tile) */
 int wlk_diag_linear(const float* a, int64_t lda, int64_t a_floats, const float* w, const float* bias,
                     const float* r, int64_t ldr, int m, int n, int k, int flags, float scale, int scale_cols,
                     int force_gemv, float* c);

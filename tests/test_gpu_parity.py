@@ -86,6 +86,44 @@ def test_gemm_matches_torch(lib, M, N, K, lda, flags, tag):
     assert err <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("M,N,K,flags", [(60, 512, 512, 2), (60, 512, 2048, 2), (9, 1536, 512, 4), (149, 2048, 512, 1),
+                                         (401, 512, 2048, 2), (401, 2048, 512, 16), (401, 1536, 512, 0),
+                                         (401, 192, 768, 2 | 8), (1500, 512, 2048, 3), (1500, 512, 512, 2),
+                                         (33, 70, 1284, 0)])
+def test_kwave_gemm_matches_torch_and_is_deterministic(lib, M, N, K, flags):
+    """Grids that under-fill the chip (decoder prefill, Sortformer) let the four waves of a workgroup split K of one
+    32x32 tile; the partial tiles are added in wave order, so the result is run-to-run identical."""
+    rng = np.random.default_rng(7)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    r = rng.standard_normal((M, N)).astype(np.float32)
+    outs = []
+    for mode in (2, 2, 0):
+        c = np.empty((M, N), np.float32)
+        rc = lib.wlk_diag_linear(vp(a), K, M * K, vp(w), vp(bias), vp(r) if flags & 2 else None, N, M, N, K, flags,
+                                 0.5, N // 2, mode, vp(c))
+        assert rc == 0, lib.wlk_diag_last_error()
+        outs.append(c)
+    assert np.array_equal(outs[0], outs[1])
+    ref = torch.from_numpy(a).double() @ torch.from_numpy(w).double().T + torch.from_numpy(bias).double()
+    if flags & 4:
+        ref[:, : N // 2] *= 0.5
+    if flags & 1:
+        ref = torch.nn.functional.gelu(ref)
+    if flags & 8:
+        ref = torch.relu(ref)
+    if flags & 16:
+        ref = ref * torch.sigmoid(ref)
+    if flags & 2:
+        ref = ref + torch.from_numpy(r).double()
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((torch.from_numpy(outs[0]).double() - ref).abs().max())
+    report(f"gemm_kwave_{M}x{N}x{K}", max_abs_err=err, vs_unsplit=float(np.abs(outs[0] - outs[2]).max()))
+    assert err <= 2e-5 * scale
+    assert np.abs(outs[0] - outs[2]).max() <= 2e-5 * scale
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 512, 512), (1, 2048, 512), (1, 512, 2048), (2, 1536, 512), (3, 130, 384),
                                    (4, 51864, 128), (8, 257, 512), (1, 51864, 512)])
 def test_gemv_matches_torch(lib, M, N, K):

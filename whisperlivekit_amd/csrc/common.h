@@ -82,6 +82,7 @@ struct GemmArgs {
     float* vcache = nullptr;
     const int* kv_pos = nullptr;
     int kv_d = 0, kv_ctx = 0;
+    bool force_kwave = false;   // diagnostics: take the k-wave kernel (under-filled grids) whatever the shape
 };
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag);
 // weight-streaming path for M <= 8 rows (decode steps); same contract as launch_gemm

@@ -43,7 +43,8 @@ int wlk_diag_linear(const float* a, int64_t lda, int64_t a_floats, const float* 
         g.R = r ? R.p : nullptr; g.ldr = ldr; g.M = m; g.N = n; g.K = k; g.flags = flags; g.scale = scale;
         g.scale_cols = scale_cols;
         LaunchCtx ctx;
-        if (force_gemv) launch_gemv(ctx, g, "diag_gemv");
+        g.force_kwave = force_gemv == 2;
+        if (force_gemv == 1) launch_gemv(ctx, g, "diag_gemv");
         else launch_gemm(ctx, g, "diag_gemm");
         WLK_HIP(hipDeviceSynchronize());
         WLK_HIP(hipMemcpy(c, Cc.p, (size_t)m * n * sizeof(float), hipMemcpyDeviceToHost));

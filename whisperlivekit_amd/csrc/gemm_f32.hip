@@ -17,6 +17,8 @@
 // k-permutation trick: MFMA step j of k-group s takes k = 8s+j from lanes 0-31 and k = 8s+4+j
 // from lanes 32-63, for A and B alike.  A contraction is order-free, so each lane fetches its
 // four k values with ONE 16-byte LDS read instead of four strided 4-byte reads.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace wlk {
@@ -196,6 +198,144 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Under-filled grids (decoder prefill: M ~ 60 rows; Sortformer: M <= 401 rows).  One wave computes a
+// 32x32xK tile at 153.6 GFLOP/s at best (one SIMD's share of the matrix peak), so a 32x32x2048 tile costs
+// >= 27 us however idle the rest of the chip is.  Here the four waves of a workgroup own the SAME 32x32
+// output tile and split K between them: the workgroup stages 32x128 slabs of A and W, wave w multiplies
+// k-sub-tile w of every slab, and the four partial tiles are added in wave order through LDS (fixed order:
+// run-to-run identical).  4x the waves per output tile, no cross-workgroup reduction, same k-permutation
+// and buffer-load pipeline as the main kernel.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_nt_f32_kwave_kernel(GemmArgs g) {
+    constexpr int KW = 4, SLAB = BK * KW, SUB = 32 * LDS_LD;
+    __shared__ __attribute__((aligned(16))) float As[2][KW * SUB];
+    __shared__ __attribute__((aligned(16))) float Ws[2][KW * SUB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (g.N + 31) / 32;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * 32, n0 = tile_n * 32;
+
+    constexpr unsigned kOob = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.A), 0, (int)((((long)g.M - 1) * g.lda + g.K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.W), 0, (int)((long)g.N * g.K * 4), 0x00020000);
+    // a slab row is 32 float4 (512 contiguous bytes); thread t moves float4 (t & 31) of rows (t >> 5) + 8 i
+    unsigned a_byte[4], w_byte[4];
+    int lds_at[4];
+    const int c4 = tid & 31, kcol = c4 * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 5) + 8 * i;
+        a_byte[i] = (m0 + row) < g.M ? (unsigned)(((long)(m0 + row) * g.lda + kcol) * 4) : kOob;
+        w_byte[i] = (n0 + row) < g.N ? (unsigned)(((long)(n0 + row) * g.K + kcol) * 4) : kOob;
+        lds_at[i] = (c4 >> 3) * SUB + row * LDS_LD + (c4 & 7) * 4;
+    }
+    struct Slab {
+        float4 a[4], w[4];
+    };
+    auto fetch = [&](Slab& st, int ks) {
+        const int k0 = ks * SLAB;
+        const bool in = (k0 + kcol) < g.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)(in ? a_byte[i] + (unsigned)k0 * 4u : kOob), 0, 0);
+            st.a[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)(in ? w_byte[i] + (unsigned)k0 * 4u : kOob), 0, 0);
+            st.w[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+    };
+    auto stash = [&](const Slab& st, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&As[buf][lds_at[i]]) = st.a[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Ws[buf][lds_at[i]]) = st.w[i];
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int frag = wave * SUB + (lane & 31) * LDS_LD + (lane >> 5) * 4;
+    auto mma = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][frag + s * 8]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&Ws[buf][frag + s * 8]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+    };
+    const int ns = (g.K + SLAB - 1) / SLAB, ns2 = (ns + 1) & ~1;
+    Slab s0, s1;
+    fetch(s0, 0);
+    fetch(s1, 1);
+    stash(s0, 0);
+    __syncthreads();
+    for (int ks = 0; ks < ns2; ks += 2) {
+        fetch(s0, ks + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0);
+        stash(s1, 1);
+        __syncthreads();
+        fetch(s1, ks + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1);
+        stash(s0, 0);
+        __syncthreads();
+    }
+    // fold the four k-partials in wave order (the loop's last barrier already separates the final LDS reads)
+    float* red = &As[0][0];
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < KW - 1; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[(w * 16 + r) * 64 + lane];
+
+    const int col = n0 + (lane & 31);
+    if (col >= g.N) return;
+    const float b = g.bias ? g.bias[col] : 0.f;
+    const bool do_scale = (g.flags & kGemmScaleCols) && col < g.scale_cols;
+    const int row_base = m0 + 4 * (lane >> 5);
+    float res[16];
+    if (g.flags & kGemmResidual) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) res[r] = g.R[(long)min(row_base + (r & 3) + 8 * (r >> 2), g.M - 1) * g.ldr + col];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) res[r] = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row_base + (r & 3) + 8 * (r >> 2);
+        float v = acc[r] + b;
+        if (do_scale) v *= g.scale;
+        if (g.flags & kGemmGelu) v = gelu_erf(v);
+        if (g.flags & kGemmRelu) v = fmaxf(v, 0.f);
+        if (g.flags & kGemmSwish) v = v / (1.0f + expf(-v));
+        v += res[r];
+        if (row < g.M) g.C[(long)row * g.ldc + col] = v;
+    }
+}
+
+// 32x32 output tiles at or below which the k-wave kernel is used (WLK_KWAVE_MAX_TILES overrides; 0 disables)
+static long kwave_max_tiles() {
+    static const long v = [] {
+        const char* e = getenv("WLK_KWAVE_MAX_TILES");
+        return e ? atol(e) : 416L;
+    }();
+    return v;
+}
+
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (g.M <= 0 || g.N <= 0) return;
     if (g.K % 4 != 0 || g.lda % 4 != 0) throw std::invalid_argument("gemm: K and lda must be multiples of 4");
@@ -204,7 +344,10 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     KernelScope ks(ctx, tag, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
     const long tiles64 = (long)((g.N + 63) / 64) * ((g.M + 63) / 64);
     const int tiles_n = (g.N + 63) / 64;
-    if (tiles64 >= 64) {
+    const long tiles32 = (long)((g.N + 31) / 32) * ((g.M + 31) / 32);
+    if ((g.force_kwave || tiles32 <= kwave_max_tiles()) && g.K >= 256) {
+        hipLaunchKernelGGL(gemm_nt_f32_kwave_kernel, dim3((unsigned)tiles32), dim3(256), 0, ctx.stream, g);
+    } else if (tiles64 >= 64) {
         const int tiles_m = (g.M + 63) / 64;
         const int blocks = tiles_m >= 8 ? 8 * ((tiles_m + 3) / 4) * ((tiles_n + 1) / 2) : tiles_m * tiles_n;
         hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64>), dim3(blocks), dim3(256), 0, ctx.stream, g);
