@@ -252,6 +252,22 @@ def main():
         achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
         roof = dict(bound="hbm", kernel=dom_name, achieved=round(achieved, 2), peak=PEAK_HBM_GBPS, unit="GB/s",
                     frac=round(achieved / PEAK_HBM_GBPS, 4), traffic=None)
+    # HBM traffic of that kernel from the committed PMC passes over this same command (bench.py cannot collect
+    # counters itself): profiles/r01_pmc_bench.json, produced by scripts/gpu_job_pmc.sh + scripts/export_pmc.py
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench.json")))
+        hit = next((v for k, v in pmc.items() if k.startswith(dom_name)), None)
+        if hit and "hbm_read_bytes_per_launch" in hit:
+            roof["traffic"] = round(hit["hbm_read_bytes_per_launch"] + hit.get("hbm_write_bytes_per_launch", 0.0))
+            roof["traffic_unit"] = "bytes per launch (HBM read + write)"
+            roof["traffic_source"] = ("profiles/r01_pmc_bench.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                                      "`bench.py --steps 1 --warmup 1`, FETCH_SIZE x2 gfx950 correction")
+            if "mfma_util" in hit:
+                roof["mfma_util_pmc"] = round(hit["mfma_util"], 4)
+    except (OSError, ValueError):
+        pass
+    roof["algorithmic_per_launch"] = round((dom["flops"] if roof["bound"] == "mfma" else dom["bytes"]) / max(dom["launches"], 1))
+    roof["algorithmic_bytes_per_launch"] = round(dom["bytes"] / max(dom["launches"], 1))
     roof.update(avg_launch_us=round(1e3 * dom["ms"] / max(dom["launches"], 1), 2), launches=dom["launches"],
                 share_of_gpu_time=round(dom["ms"] / gpu_ms, 3),
                 timing="HIP events around every launch, separate profiled replay of one step")

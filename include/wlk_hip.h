@@ -80,6 +80,9 @@ int wlk_session_set_debug(wlk_session* s, int on);
 /* a1: AlignAtt.insert_audio (simul_whisper.py:219-237): append a chunk / evict the oldest
  * samples / drop everything.  Only the new chunk crosses PCIe. */
 int wlk_audio_append(wlk_session* s, const float* pcm_host, int n);
+/* (f-next, rank 3) the same append for int16 PCM as it arrives on the wire: replaces convert_pcm_to_float
+ * (whisperlivekit/audio_processor.py:416-418: int16 -> float32 / 32768.0) + the fp32 upload; half the PCIe bytes */
+int wlk_audio_append_pcm16(wlk_session* s, const int16_t* pcm_host, int n);
 int wlk_audio_append_zeros(wlk_session* s, int n);
 int wlk_audio_drop_front(wlk_session* s, int n);
 int wlk_audio_clear(wlk_session* s);

@@ -40,6 +40,9 @@ class FakeSession:
     def append(self, pcm):
         self.audio = np.concatenate([self.audio, np.asarray(pcm, np.float32)])
 
+    def append_pcm16(self, pcm):
+        self.append(np.asarray(pcm, np.int16).astype(np.float32) / 32768.0)     # audio_processor.py:416-418
+
     def append_zeros(self, n):
         self.audio = np.concatenate([self.audio, np.zeros(n, np.float32)])
 

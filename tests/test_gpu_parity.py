@@ -374,6 +374,30 @@ def test_stream_matches_reference_golden(case):
         proc.close()
 
 
+def test_pcm16_upload_equals_float_upload():
+    """wlk_audio_append_pcm16 == convert_pcm_to_float (audio_processor.py:416-418) + wlk_audio_append, bit for bit
+    (the widening is an exact power-of-two scale), including a chunk larger than the pinned staging buffer."""
+    from whisperlivekit_amd import synth
+    m = hip_model("micro.en")
+    audio = synth.speech_like(40.0, 3)
+    pcm = np.clip(np.round(audio * 32768.0), -32768, 32767).astype(np.int16)
+    mels = []
+    for mode in ("float", "pcm16"):
+        sess = m.new_session(beam=1, max_audio_seconds=64.0)
+        for lo, hi in ((0, 1), (1, 8000), (8000, 8000 + 600001)):
+            if mode == "float":
+                sess.append(pcm[lo:hi].astype(np.float32) / 32768.0)
+            else:
+                sess.append_pcm16(pcm[lo:hi])
+        assert sess.audio_len == 608001
+        sess.drop_front(608001 - 480000)
+        cml = sess.encode()
+        mels.append((cml, sess.export("mel").copy()))
+        sess.close()
+    assert mels[0][0] == mels[1][0] == 1500
+    assert np.array_equal(mels[0][1], mels[1][1])
+
+
 def test_hipgraph_replay_equals_eager_launches(monkeypatch):
     """The captured decode-step graph and the eager launch sequence are the same arithmetic: identical
     tokens, frames and log-prob sums, bit for bit, over a whole stream."""

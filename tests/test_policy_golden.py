@@ -95,3 +95,30 @@ def test_repetition_detectors():
     words = ("a b " * 4 + "c d e f").split()
     assert not has_repetition_loop(words)      # 4 x 2 words < 12-word minimum
     assert has_repetition_loop(("a b c " * 4 + "d e f g").split())   # 4 x 3 = 12 words, 75 % coverage
+
+
+def test_pcm16_wire_format_stream_equals_float_stream():
+    """s16le chunks straight into the backend (insert_pcm16_chunk) give exactly the stream the
+    float path gives after AudioProcessor.convert_pcm_to_float (audio_processor.py:416-418)."""
+    from whisperlivekit_amd import synth
+    audio = synth.speech_like(6.0, 0)
+    pcm = np.clip(np.round(audio * 32768.0), -32768, 32767).astype(np.int16)
+    as_float = pcm.astype(np.float32) / 32768.0
+    outs = []
+    for mode in ("float", "pcm16", "bytes"):
+        proc = make_fake_processor("micro.en", {})
+        words = []
+        for lo in range(0, len(pcm), 8000):
+            t_end = min(lo + 8000, len(pcm)) / 16000
+            if mode == "float":
+                proc.insert_audio_chunk(as_float[lo:lo + 8000], t_end)
+            elif mode == "pcm16":
+                proc.insert_pcm16_chunk(pcm[lo:lo + 8000], t_end)
+            else:
+                proc.insert_pcm16_chunk(pcm[lo:lo + 8000].tobytes(), t_end)
+            toks, _ = proc.process_iter()
+            words += [(t.start, t.end, t.text) for t in toks]
+        outs.append((words, [(r["content_mel_len"], [s.get("token") for s in r["steps"]]) for r in proc.trace]))
+    assert outs[0] == outs[1] == outs[2] and len(outs[0][1]) == 12
+    with pytest.raises(TypeError):
+        make_fake_processor("micro.en", {}).insert_pcm16_chunk(as_float[:100], 0.1)

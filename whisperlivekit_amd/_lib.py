@@ -54,6 +54,7 @@ def _declare(lib: C.CDLL) -> None:
         "wlk_session_destroy": (cint, [p]),
         "wlk_session_set_debug": (cint, [p, cint]),
         "wlk_audio_append": (cint, [p, p, cint]),
+        "wlk_audio_append_pcm16": (cint, [p, p, cint]),
         "wlk_audio_append_zeros": (cint, [p, cint]),
         "wlk_audio_drop_front": (cint, [p, cint]),
         "wlk_audio_clear": (cint, [p]),
@@ -96,7 +97,7 @@ EXPORTED_SYMBOLS = (
     "wlk_last_error", "wlk_abi_version", "wlk_device_count", "wlk_arena_floats", "wlk_tensor_lookup",
     "wlk_tensor_name", "wlk_model_create", "wlk_model_arena", "wlk_model_upload",
     "wlk_model_set_alignment_heads", "wlk_model_finalize", "wlk_model_destroy", "wlk_session_create",
-    "wlk_session_destroy", "wlk_session_set_debug", "wlk_audio_append", "wlk_audio_append_zeros",
+    "wlk_session_destroy", "wlk_session_set_debug", "wlk_audio_append", "wlk_audio_append_pcm16", "wlk_audio_append_zeros",
     "wlk_audio_drop_front", "wlk_audio_clear", "wlk_audio_len", "wlk_encode", "wlk_decode",
     "wlk_no_speech_prob", "wlk_select", "wlk_kv_reorder", "wlk_sync", "wlk_export", "wlk_prof_begin",
     "wlk_prof_end", "wlk_melspec_create", "wlk_melspec_run", "wlk_melspec_destroy",

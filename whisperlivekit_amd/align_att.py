@@ -207,7 +207,15 @@ class HipAlignAttHooks:
     def _to_numpy(segment) -> np.ndarray:
         if hasattr(segment, "detach"):
             segment = segment.detach().cpu().numpy()
+        if isinstance(segment, np.ndarray) and segment.dtype == np.int16:      # wire-format PCM: widened on the GPU
+            return np.ascontiguousarray(segment.reshape(-1))
         return np.ascontiguousarray(np.asarray(segment, dtype=np.float32).reshape(-1))
+
+    def _upload(self, data: np.ndarray) -> None:
+        if data.dtype == np.int16:
+            self.session.append_pcm16(data)
+        else:
+            self.session.append(data)
 
     def insert_audio(self, segment=None):
         """simul_whisper.py:219-237.  The chunk goes straight to HBM; eviction shifts the attention
@@ -217,7 +225,7 @@ class HipAlignAttHooks:
             seg = _Segment(self._to_numpy(segment))
             self._sync_device_audio()
             st.segments.append(seg)
-            self.session.append(seg.data)
+            self._upload(seg.data)
             self._dev_segments.append((seg.uid, seg.shape[0]))
         removed_len = 0
         total = self.segments_len()
@@ -246,7 +254,7 @@ class HipAlignAttHooks:
         else:                                               # anything else: rebuild from the host copies
             self.session.clear_audio()
             for seg in self.state.segments:
-                self.session.append(seg.data)
+                self._upload(seg.data)
         self._dev_segments = want
 
     def _concat_segments(self):

@@ -162,6 +162,16 @@ class HipSimulStreamingOnlineProcessor:
         self.end = audio_stream_end_time
         self.model.insert_audio(np.asarray(audio, dtype=np.float32))
 
+    def insert_pcm16_chunk(self, pcm, audio_stream_end_time: float):
+        """The same insert for s16le PCM as it arrives from the client (bytes or an int16 array): what
+        AudioProcessor.convert_pcm_to_float (audio_processor.py:416-418) + insert_audio_chunk do, with the
+        int16 -> fp32 / 32768 widening done on the GPU."""
+        self.end = audio_stream_end_time
+        a = np.frombuffer(pcm, dtype=np.int16) if isinstance(pcm, (bytes, bytearray, memoryview)) else np.asarray(pcm)
+        if a.dtype != np.int16:
+            raise TypeError("insert_pcm16_chunk expects s16le bytes or an int16 array")
+        self.model.insert_audio(a)
+
     def start_silence(self):
         return self.process_iter(is_last=True)
 

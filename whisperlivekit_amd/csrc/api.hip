@@ -217,6 +217,9 @@ struct wlk_session {
     bool debug = false;
     bool use_graph = true;
     hipGraphExec_t step_exec[2] = {nullptr, nullptr};   // single-token decode step, per KV buffer
+    int enc_ksplit = 1;                                 // key split of the encoder attention (WLK_ENC_KSPLIT)
+    float* esplit = nullptr;
+    short* pcm16_dev = nullptr;                         // staging of wlk_audio_append_pcm16 (lazily allocated)
 
     // audio (two buffers: eviction copies the tail into the other one)
     float* audio[2] = {nullptr, nullptr};
@@ -507,6 +510,11 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         if (m->n_align > 0) s->ring = dev_alloc<float>((size_t)m->n_align * beam * s->ring_rows * T);
         s->xsplit = dev_alloc<float>(cross_split_scratch_floats(8, D.n_text_head, (int)T));
         s->fsplit = dev_alloc<float>(flash_split_scratch_floats(s->max_rows, D.n_text_head, wlk_session::kFlashSplits));
+        if (const char* e = getenv("WLK_ENC_KSPLIT")) {
+            s->enc_ksplit = std::max(1, std::min(8, atoi(e)));
+            if (s->enc_ksplit > 1)
+                s->esplit = dev_alloc<float>(flash_split_scratch_floats(D.n_audio_ctx, D.n_audio_head, s->enc_ksplit));
+        }
         s->z = dev_alloc<float>((size_t)beam * std::max(m->n_align, 1) * T);
         s->attn_last = dev_alloc_zero<float>((size_t)beam * T, st);
         s->adj_row = dev_alloc<int>(3 * wlk_session::kAdjCap);   // [rows n | ids n | deltas n] packed per call
@@ -539,6 +547,8 @@ int wlk_session_destroy(wlk_session* s) {
     for (auto& e : s->step_exec)
         if (e) (void)hipGraphExecDestroy(e);
     if (s->topk_scratch) (void)hipFree(s->topk_scratch);
+    if (s->pcm16_dev) (void)hipFree(s->pcm16_dev);
+    if (s->esplit) (void)hipFree(s->esplit);
     if (s->pinned) (void)hipHostFree(s->pinned);
     for (auto& r : s->prof.recs) {
         (void)hipEventDestroy(r.a);
@@ -580,6 +590,34 @@ int wlk_audio_append(wlk_session* s, const float* pcm_host, int n) {
             WLK_HIP(hipStreamSynchronize(s->stream));  // pinned buffer is single-entry
             std::memcpy(s->pinned, pcm_host + done, chunk * sizeof(float));
             WLK_HIP(hipMemcpyAsync(dst + done, s->pinned, chunk * sizeof(float), hipMemcpyHostToDevice, s->stream));
+            done += chunk;
+        }
+        WLK_HIP(hipStreamSynchronize(s->stream));
+        s->audio_len += n;
+        s->encoded = false;
+        return WLK_OK;
+    });
+}
+
+int wlk_audio_append_pcm16(wlk_session* s, const int16_t* pcm_host, int n) {
+    if (!s || (n > 0 && !pcm_host) || n < 0) return fail(WLK_ERR_ARG, "bad audio chunk");
+    if (s->audio_len + n > s->audio_cap)
+        return fail(WLK_ERR_CAPACITY, "audio buffer capacity exceeded (" + std::to_string(s->audio_len + n) + " > " +
+                                          std::to_string(s->audio_cap) + " samples)");
+    if (n == 0) return WLK_OK;
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(s->m->device));
+        constexpr size_t kMax = wlk_session::kPinnedBytes / sizeof(int16_t);
+        if (!s->pcm16_dev) WLK_HIP(hipMalloc(reinterpret_cast<void**>(&s->pcm16_dev), kMax * sizeof(int16_t)));
+        float* dst = s->audio[s->audio_cur] + s->audio_len;
+        const LaunchCtx c = s->ctx();
+        size_t done = 0;
+        while (done < (size_t)n) {   // half the PCIe bytes of the fp32 path; widened on the device
+            const size_t chunk = std::min((size_t)n - done, kMax);
+            WLK_HIP(hipStreamSynchronize(s->stream));  // pinned buffer and staging buffer are single-entry
+            std::memcpy(s->pinned, pcm_host + done, chunk * sizeof(int16_t));
+            WLK_HIP(hipMemcpyAsync(s->pcm16_dev, s->pinned, chunk * sizeof(int16_t), hipMemcpyHostToDevice, s->stream));
+            launch_pcm16_to_float(c, s->pcm16_dev, dst + done, (int)chunk);
             done += chunk;
         }
         WLK_HIP(hipStreamSynchronize(s->stream));
@@ -698,7 +736,7 @@ int wlk_encode(wlk_session* s, int32_t* content_mel_len) {
             g.A = s->eh; g.lda = d; g.W = L.qkvw; g.bias = L.qkvb; g.C = s->eqkv; g.ldc = 3 * d; g.M = T; g.N = 3 * d;
             g.K = d; g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = 2 * d;
             launch_gemm(c, g, "enc_qkv");
-            launch_encoder_attention(c, s->eqkv, s->eatt, T, d, D.n_audio_head);
+            launch_encoder_attention(c, s->eqkv, s->eatt, T, d, D.n_audio_head, s->enc_ksplit, s->esplit);
             GemmArgs o;
             o.A = s->eatt; o.lda = d; o.W = L.outw; o.bias = L.outb; o.C = s->ex; o.ldc = d; o.M = T; o.N = d; o.K = d;
             o.flags = kGemmResidual; o.R = s->ex; o.ldr = d;

@@ -261,10 +261,17 @@ size_t flash_split_scratch_floats(int rows, int n_head, int k_splits) {
     return (size_t)rows * n_head * k_splits * (64 + 2);
 }
 
-void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out, int T, int d, int n_head) {
+void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out, int T, int d, int n_head,
+                              int k_splits, float* split_scratch) {
     FlashArgs a;
     a.q = qkv; a.ldq = 3L * d; a.k = qkv + d; a.v = qkv + 2 * d; a.ldkv = 3L * d; a.out = out; a.ldo = d;
     a.Tq = T; a.Tk = T; a.n_head = n_head;
+    if (k_splits > 1 && split_scratch) {   // key ranges on separate workgroups + merge: evens out the 376-tile grid
+        a.k_splits = k_splits;
+        a.part_o = split_scratch;
+        a.part_m = split_scratch + (size_t)T * n_head * k_splits * 64;
+        a.part_l = a.part_m + (size_t)T * n_head * k_splits;
+    }
     launch_flash(ctx, a, "enc_attention");
 }
 

@@ -117,6 +117,7 @@ struct MelArgs {
     int n_total;           // frames the reference's STFT yields before trimming to 3000
 };
 void launch_mel(const LaunchCtx& ctx, const MelArgs& a);
+void launch_pcm16_to_float(const LaunchCtx& ctx, const short* in, float* out, int n);
 
 // ---- melspec.hip (diarization front end) ---------------------------------------------------------
 struct MelSpecArgs {
@@ -155,7 +156,8 @@ struct FlashArgs {
 };
 size_t flash_split_scratch_floats(int rows, int n_head, int k_splits);
 // encoder self-attention over qkv[T][3d] (q and k pre-scaled), out[T][d]
-void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out, int T, int d, int n_head);
+void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out, int T, int d, int n_head,
+                              int k_splits = 1, float* split_scratch = nullptr);
 void launch_prefill_cross_attention(const LaunchCtx& ctx, const FlashArgs& a);
 void launch_ring_softmax(const LaunchCtx& ctx, float* ring, const int* ring_row, const int* beam_of_row,
                          const int* ranks_dev, int n_ranks, int rows, int ring_rows, int n_beam, int T);

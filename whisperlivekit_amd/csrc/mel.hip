@@ -104,4 +104,18 @@ void launch_mel(const LaunchCtx& ctx, const MelArgs& a) {
     }
 }
 
+// int16 PCM straight off the wire -> the fp32 sample buffer: np.frombuffer(int16).astype(float32) / 32768.0
+// (convert_pcm_to_float, whisperlivekit/audio_processor.py:416-418); the division is an exact power-of-two scale.
+__global__ void pcm16_to_float_kernel(const short* __restrict__ in, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i] * (1.0f / 32768.0f);
+}
+
+void launch_pcm16_to_float(const LaunchCtx& ctx, const short* in, float* out, int n) {
+    if (n <= 0) return;
+    KernelScope ks(ctx, "pcm16_to_float", 0.0, 6.0 * n);
+    hipLaunchKernelGGL(pcm16_to_float_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx.stream, in, out, n);
+    WLK_HIP(hipGetLastError());
+}
+
 }  // namespace wlk

@@ -207,6 +207,11 @@ class HipSession:
         a = np.ascontiguousarray(pcm, dtype=np.float32).reshape(-1)
         _lib.check(self.lib.wlk_audio_append(self._h, a.ctypes.data_as(C.c_void_p), a.size))
 
+    def append_pcm16(self, pcm: np.ndarray) -> None:
+        """int16 samples as they arrive on the wire; widened to fp32 / 32768 on the device."""
+        a = np.ascontiguousarray(pcm, dtype=np.int16).reshape(-1)
+        _lib.check(self.lib.wlk_audio_append_pcm16(self._h, a.ctypes.data_as(C.c_void_p), a.size))
+
     def append_zeros(self, n: int) -> None:
         _lib.check(self.lib.wlk_audio_append_zeros(self._h, int(n)))
 
