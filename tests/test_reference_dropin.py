@@ -21,7 +21,7 @@ from test_oracle_golden import check_stream_against_golden, replay_stream  # noq
 from whisperlivekit_amd.dims import ALIGNMENT_HEADS, MODEL_DIMS  # noqa: E402
 
 
-def _make(model_name, cfg_over):
+def _make(model_name, cfg_over, seed=0):
     ref_stubs.install(synthetic_vocab=True)
     from whisperlivekit.simul_whisper.config import AlignAttConfig
     from whisperlivekit.timed_objects import ChangeSpeaker
@@ -30,13 +30,13 @@ def _make(model_name, cfg_over):
               language="en", audio_max_len=30.0, audio_min_len=0.0, cif_ckpt_path=None, decoder_type="beam",
               beam_size=1, task="transcribe", never_fire=False, init_prompt=None, max_context_tokens=None,
               static_init_prompt=None)
-    over = dict(cfg_over or {})
+    over = H.resolve_cfg(cfg_over)
     nonspeech = over.pop("nonspeech_prob", None)
     kw.update(over)
     cfg = AlignAttConfig(**kw)
     if nonspeech is not None:
         cfg.nonspeech_prob = nonspeech
-    fake = FakeHipModel(MODEL_DIMS[model_name], H.oracle_sd(model_name), ALIGNMENT_HEADS[model_name])
+    fake = FakeHipModel(MODEL_DIMS[model_name], H.oracle_sd(model_name, seed), ALIGNMENT_HEADS[model_name])
     asr = types.SimpleNamespace(cfg=cfg, hip_model=fake, shared_model=fake, use_full_mlx=False, mlx_encoder=None,
                                 fw_encoder=None, tokenizer=None)
     proc = reference_online_processor_class()(asr)
@@ -83,7 +83,8 @@ def _make(model_name, cfg_over):
     return proc
 
 
-@pytest.mark.parametrize("case", ["micro_12s", "micro_34s_evict", "micro_beam2", "micro_neverfire", "micro_events"])
+@pytest.mark.parametrize("case", ["micro_12s", "micro_34s_evict", "micro_beam2", "micro_neverfire", "micro_events",
+                                  "micro_cif", "micromulti_auto"])
 def test_reference_policy_runs_unmodified_on_hip_hooks(case):
     g, proc, got = replay_stream(case, _make)
     from whisperlivekit.simul_whisper.align_att_base import AlignAttBase
