@@ -374,6 +374,46 @@ def test_stream_matches_reference_golden(case):
         proc.close()
 
 
+def test_barrier_free_single_row_gemv_is_bit_identical_to_the_staged_kernel(tmp_path):
+    """gemv1_f32_kernel (beam-1 decode steps: no LDS, no barrier) keeps the staged kernel's reduction and fmaf
+    order, so switching it off (WLK_NO_GEMV1, read once per process) must not change a single bit."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, sys, numpy as np
+from whisperlivekit_amd import _lib
+lib = _lib.load()
+vp = lambda a: a.ctypes.data_as(C.c_void_p)
+rng = np.random.default_rng(5)
+out = []
+for (N, K, flags, ln) in [(512, 512, 2, 0), (2048, 512, 1, 1), (512, 2048, 2, 0), (1536, 512, 4, 1), (384, 384, 0, 1),
+                          (1280, 1280, 2, 0), (130, 768, 0, 1)]:
+    a = rng.standard_normal((1, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    r = rng.standard_normal((1, N)).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    be = (0.1 * rng.standard_normal(K)).astype(np.float32)
+    c = np.empty((1, N), np.float32)
+    if ln:
+        rc = lib.wlk_diag_linear_ln(vp(a), vp(w), vp(b), vp(g), vp(be), 1, N, K, 1, vp(c))
+    else:
+        rc = lib.wlk_diag_linear(vp(a), K, K, vp(w), vp(b), vp(r) if flags & 2 else None, N, 1, N, K, flags, 0.5, N // 2, 1, vp(c))
+    assert rc == 0
+    out.append(c.copy())
+np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
+"""
+    import os
+    outs = []
+    for tag, extra in (("new", {}), ("old", {"WLK_NO_GEMV1": "1"})):
+        path = str(tmp_path / f"{tag}.npy")
+        env = dict(os.environ, **extra)
+        env["PYTHONPATH"] = os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env.get("PYTHONPATH", "")])
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=300)
+        outs.append(np.load(path))
+    assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1])
+
+
 def test_pcm16_upload_equals_float_upload():
     """wlk_audio_append_pcm16 == convert_pcm_to_float (audio_processor.py:416-418) + wlk_audio_append, bit for bit
     (the widening is an exact power-of-two scale), including a chunk larger than the pinned staging buffer."""

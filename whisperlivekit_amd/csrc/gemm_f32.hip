@@ -492,6 +492,109 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
     }
 }
 
+// Single-row variant (beam 1 decode steps, the common case): no LDS and no barrier at all.  Every wave loads the
+// activation row itself, in the same lane-strided float4 mapping it uses for the weights, so the x fetch, the
+// gamma/beta fetch and the weight fetch are ONE memory round trip instead of "stage x -> barrier -> read LDS".
+// The fused LayerNorm statistics use the scalar lane-strided order of layernorm_kernel (so fused == unfused bit
+// for bit) and the dot products the same fmaf order as gemv_f32_kernel: results are identical to that kernel.
+template <int UB, int RPW>
+__global__ __launch_bounds__(256) void gemv1_f32_kernel(GemmArgs g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int K4 = g.K >> 2;
+    const int n_groups = (g.N + RPW - 1) / RPW;
+    const int grp = blockIdx.x * 4 + wave;
+    if (grp >= n_groups) return;
+    const int n_base = grp * RPW;
+    float4 w[UB][RPW], x[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        const int c = lane + 64 * u;
+        const bool ok = c < K4;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+            w[u][r] = *reinterpret_cast<const float4*>(g.W + (long)min(n_base + r, g.N - 1) * g.K + (ok ? c : 0) * 4);
+        x[u] = *reinterpret_cast<const float4*>(g.A + (ok ? c : 0) * 4);
+    }
+    if (g.ln_gamma) {
+        float v[UB * 4];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < UB * 4; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < g.K ? g.A[c] : 0.f;
+            sum += v[i];
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const float mean = sum / (float)g.K;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < UB * 4; ++i) {
+            const float t = (lane + 64 * i) < g.K ? v[i] - mean : 0.f;
+            sq += t * t;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        const float rstd = 1.0f / sqrtf(sq / (float)g.K + 1e-5f);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int c = lane + 64 * u;
+            const int cc = (c < K4 ? c : 0) * 4;
+            const float4 ga = *reinterpret_cast<const float4*>(g.ln_gamma + cc);
+            const float4 be = *reinterpret_cast<const float4*>(g.ln_beta + cc);
+            x[u].x = (x[u].x - mean) * rstd * ga.x + be.x;
+            x[u].y = (x[u].y - mean) * rstd * ga.y + be.y;
+            x[u].z = (x[u].z - mean) * rstd * ga.z + be.z;
+            x[u].w = (x[u].w - mean) * rstd * ga.w + be.w;
+        }
+    }
+    float acc[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        if (lane + 64 * u < K4) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                acc[r] = fmaf(w[u][r].x, x[u].x, acc[r]);
+                acc[r] = fmaf(w[u][r].y, x[u].y, acc[r]);
+                acc[r] = fmaf(w[u][r].z, x[u].z, acc[r]);
+                acc[r] = fmaf(w[u][r].w, x[u].w, acc[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc[r] += __shfl_xor(acc[r], off, 64);
+    if (lane < RPW) {
+        const int n = n_base + lane;
+        if (n < g.N) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+                if (r == lane) v = acc[r];
+            if (g.bias) v += g.bias[n];
+            if ((g.flags & kGemmScaleCols) && n < g.scale_cols) v *= g.scale;
+            if (g.flags & kGemmGelu) v = gelu_erf(v);
+            if (g.flags & kGemmRelu) v = fmaxf(v, 0.f);
+            if (g.flags & kGemmSwish) v = v / (1.0f + expf(-v));
+            if (g.flags & kGemmResidual) v += g.R[n];
+            g.C[n] = v;
+            if (g.kcache && n >= g.kv_d) {
+                const long at = (long)(*g.kv_pos) * g.kv_d;
+                if (n < 2 * g.kv_d) g.kcache[at + n - g.kv_d] = v;
+                else g.vcache[at + n - 2 * g.kv_d] = v;
+            }
+        }
+    }
+}
+
+static bool gemv1_enabled() {
+    static const bool on = getenv("WLK_NO_GEMV1") == nullptr;
+    return on;
+}
+
 void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (g.M <= 0 || g.N <= 0) return;
     if (!gemv_applicable(g.M, g.K) || g.lda % 4 != 0) throw std::invalid_argument("gemv: unsupported shape");
@@ -504,6 +607,20 @@ void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (blocks > 2048) blocks = 2048;
     const size_t lds = (size_t)mr * g.K * sizeof(float);
     KernelScope ks(ctx, tag, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    if (g.M == 1 && g.K <= 2048 && rpw <= 2 && gemv1_enabled()) {
+        const int ub = (g.K / 4 + 63) / 64;
+#define WLK_GEMV1(UBv)                                                                                             \
+    do {                                                                                                           \
+        if (rpw == 2) hipLaunchKernelGGL((gemv1_f32_kernel<UBv, 2>), dim3(blocks), dim3(256), 0, ctx.stream, g);   \
+        else hipLaunchKernelGGL((gemv1_f32_kernel<UBv, 1>), dim3(blocks), dim3(256), 0, ctx.stream, g);            \
+    } while (0)
+        if (ub <= 2) WLK_GEMV1(2);
+        else if (ub <= 4) WLK_GEMV1(4);
+        else WLK_GEMV1(8);
+#undef WLK_GEMV1
+        WLK_HIP(hipGetLastError());
+        return;
+    }
 #define WLK_GEMV(MRv, RPWv) \
     hipLaunchKernelGGL((gemv_f32_kernel<MRv, RPWv>), dim3(blocks), dim3(256), lds, ctx.stream, g)
 #define WLK_GEMV_R(MRv)                      \
