@@ -168,6 +168,10 @@ struct wlk_model {
     std::vector<TensorSlot> slots;
     std::map<std::string, const TensorSlot*> by_name;
     double* twiddle = nullptr;        // [400] fp64 cos table
+    // cross-attention k|v projections of ALL decoder layers side by side ([L*2d, d] and [L*2d]; copies of the
+    // arena's per-layer tensors made by wlk_model_finalize): one GEMM per encode instead of L
+    float* xkv_all_w = nullptr;
+    float* xkv_all_b = nullptr;
     int* filt_lo = nullptr;           // [n_mels]
     int* filt_hi = nullptr;
     int* head_rank = nullptr;         // [L][H] alignment rank or -1
@@ -433,6 +437,17 @@ int wlk_model_finalize(wlk_model* m) {
         m->dec_layers.clear();
         for (int i = 0; i < m->D.n_audio_layer; ++i) m->enc_layers.push_back(layer_weights(m, "enc", i, false));
         for (int i = 0; i < m->D.n_text_layer; ++i) m->dec_layers.push_back(layer_weights(m, "dec", i, true));
+        {
+            const size_t d = m->D.n_text_state, da = m->D.n_audio_state, Ld = m->D.n_text_layer;
+            if (!m->xkv_all_w) m->xkv_all_w = dev_alloc<float>(Ld * 2 * d * da);
+            if (!m->xkv_all_b) m->xkv_all_b = dev_alloc<float>(Ld * 2 * d);
+            for (size_t i = 0; i < Ld; ++i) {
+                WLK_HIP(hipMemcpy(m->xkv_all_w + i * 2 * d * da, m->dec_layers[i].xkvw, 2 * d * da * sizeof(float),
+                                  hipMemcpyDeviceToDevice));
+                WLK_HIP(hipMemcpy(m->xkv_all_b + i * 2 * d, m->dec_layers[i].xkvb, 2 * d * sizeof(float),
+                                  hipMemcpyDeviceToDevice));
+            }
+        }
         m->w_tok_emb = m->w("dec.tok_emb");
         m->w_dec_pos = m->w("dec.pos");
         m->w_ln_w = m->w("dec.ln.w");
@@ -446,6 +461,8 @@ int wlk_model_destroy(wlk_model* m) {
     if (!m) return WLK_OK;
     (void)hipSetDevice(m->device);
     if (m->owns_arena) (void)hipFree(m->arena);
+    if (m->xkv_all_w) (void)hipFree(m->xkv_all_w);
+    if (m->xkv_all_b) (void)hipFree(m->xkv_all_b);
     (void)hipFree(m->twiddle);
     (void)hipFree(m->filt_lo);
     (void)hipFree(m->filt_hi);
@@ -744,11 +761,11 @@ int wlk_encode(wlk_session* s, int32_t* content_mel_len) {
             transformer_mlp(c, L, s->ex, s->eh, s->emlp, T, d, "enc_ln2", "enc_fc1", "enc_fc2");
         }
         launch_layernorm(c, s->ex, d, m->w("enc.ln_post.w"), m->w("enc.ln_post.b"), s->enc_out, d, T, d, "enc_ln_post");
-        for (int i = 0; i < D.n_text_layer; ++i) {  // cross-attention K (scaled) and V of every decoder layer
-            const LayerW& L = m->dec_layers[i];
+        {   // cross-attention K (scaled) and V of every decoder layer in ONE GEMM: cross_kv is [T][L][k | v]
             GemmArgs g;
-            g.A = s->enc_out; g.lda = d; g.W = L.xkvw; g.bias = L.xkvb; g.C = s->cross_kv + (size_t)i * T * 2 * d;
-            g.ldc = 2 * d; g.M = T; g.N = 2 * d; g.K = d; g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = d;
+            g.A = s->enc_out; g.lda = d; g.W = m->xkv_all_w; g.bias = m->xkv_all_b; g.C = s->cross_kv;
+            g.ldc = (long)D.n_text_layer * 2 * d; g.M = T; g.N = D.n_text_layer * 2 * d; g.K = d;
+            g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = d; g.scale_period = 2 * d;
             launch_gemm(c, g, "dec_cross_kv");
         }
         s->encoded = true;
@@ -795,8 +812,13 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
         } else {
             launch_layernorm(c, s->dx, d, L.ln1w, L.ln1b, s->dh, d, R, d, "dec_ln1");
             g.A = s->dh;
-            launch_linear(c, g, "dec_qkv");
-            launch_kv_append(c, s->dqkv, kc, vc, n_rows, n_tok, s->d_offset, d, ctx_len);
+            if (!gemv_applicable(R, d) && gemm_takes_kwave(R, 3 * d, d)) {   // k/v also land in the caches
+                g.kcache = kc; g.vcache = vc; g.kv_pos = s->d_offset; g.kv_d = d; g.kv_ctx = ctx_len; g.kv_ntok = n_tok;
+                launch_gemm(c, g, "dec_qkv");
+            } else {
+                launch_linear(c, g, "dec_qkv");
+                launch_kv_append(c, s->dqkv, kc, vc, n_rows, n_tok, s->d_offset, d, ctx_len);
+            }
         }
         launch_decoder_self_attention(c, s->dqkv, kc, vc, s->datt, n_rows, n_tok, s->d_offset, d, H, ctx_len);
         GemmArgs o;
@@ -820,7 +842,7 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
             // prefill: MFMA flash kernel shares every K/V tile between 32 query rows
             FlashArgs fa;
             fa.q = s->dq; fa.ldq = d;
-            fa.k = s->cross_kv + (size_t)i * T * 2 * d; fa.v = fa.k + d; fa.ldkv = 2 * d;
+            fa.k = s->cross_kv + (size_t)i * 2 * d; fa.v = fa.k + d; fa.ldkv = (long)D.n_text_layer * 2 * d;
             fa.out = s->datt; fa.ldo = d; fa.Tq = R; fa.Tk = T; fa.n_head = H;
             fa.head_rank = ranks_l; fa.ring = s->ring; fa.ring_row = s->ring_row;
             fa.beam_of_row = s->beam_of_row; fa.ring_rows = s->ring_rows; fa.n_beam = s->beam;
@@ -836,9 +858,9 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
         } else {
             CrossAttnArgs ca;
             ca.q = s->dq;
-            ca.k = s->cross_kv + (size_t)i * T * 2 * d;
+            ca.k = s->cross_kv + (size_t)i * 2 * d;
             ca.v = ca.k + d;
-            ca.ldkv = 2 * d;
+            ca.ldkv = (long)D.n_text_layer * 2 * d;
             ca.out = s->datt;
             ca.rows = R; ca.d = d; ca.n_head = H; ca.T = T;
             ca.head_rank = ranks_l;

@@ -73,6 +73,7 @@ struct GemmArgs {
     int flags = 0;
     float scale = 1.f;
     int scale_cols = 0;
+    int scale_period = 0;  // > 0: the rule is (col % scale_period) < scale_cols (several [k | v] blocks side by side)
     // GEMV path only (decode steps): fused pre-LayerNorm of the A rows (eps 1e-5) ...
     const float* ln_gamma = nullptr;
     const float* ln_beta = nullptr;
@@ -82,9 +83,11 @@ struct GemmArgs {
     float* vcache = nullptr;
     const int* kv_pos = nullptr;
     int kv_d = 0, kv_ctx = 0;
+    int kv_ntok = 1;       // k-wave GEMM path: rows are [beam][kv_ntok] (decoder prefill)
     bool force_kwave = false;   // diagnostics: take the k-wave kernel (under-filled grids) whatever the shape
 };
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag);
+bool gemm_takes_kwave(int M, int N, int K);   // launch_gemm's shape rule for the k-wave kernel (under-filled grids)
 // weight-streaming path for M <= 8 rows (decode steps); same contract as launch_gemm
 void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag);
 inline int gemv_row_bucket(int M) { return M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : 8; }

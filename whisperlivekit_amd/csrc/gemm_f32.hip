@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
     const int col = n0 + wc * 32 + (lane & 31);
     if (col < g.N) {
         const float b = g.bias ? g.bias[col] : 0.f;
-        const bool do_scale = (g.flags & kGemmScaleCols) && col < g.scale_cols;
+        const bool do_scale = (g.flags & kGemmScaleCols) && (g.scale_period ? col % g.scale_period : col) < g.scale_cols;
         const int row_base = m0 + wr * 32 + 4 * (lane >> 5);
         float res[16];
         if (g.flags & kGemmResidual) {
@@ -304,8 +304,16 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kwave_kernel(GemmArgs g) {
     const int col = n0 + (lane & 31);
     if (col >= g.N) return;
     const float b = g.bias ? g.bias[col] : 0.f;
-    const bool do_scale = (g.flags & kGemmScaleCols) && col < g.scale_cols;
+    const bool do_scale = (g.flags & kGemmScaleCols) && (g.scale_period ? col % g.scale_period : col) < g.scale_cols;
     const int row_base = m0 + 4 * (lane >> 5);
+    // decoder prefill: the k / v thirds of the projection also go to the self-attention caches (row = beam * n_tok + t)
+    float* kv_dst = nullptr;
+    int kv_col = 0, kv_off = 0;
+    if (g.kcache && col >= g.kv_d) {
+        kv_dst = col < 2 * g.kv_d ? g.kcache : g.vcache;
+        kv_col = col < 2 * g.kv_d ? col - g.kv_d : col - 2 * g.kv_d;
+        kv_off = *g.kv_pos;
+    }
     float res[16];
     if (g.flags & kGemmResidual) {
 #pragma unroll
@@ -323,7 +331,13 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kwave_kernel(GemmArgs g) {
         if (g.flags & kGemmRelu) v = fmaxf(v, 0.f);
         if (g.flags & kGemmSwish) v = v / (1.0f + expf(-v));
         v += res[r];
-        if (row < g.M) g.C[(long)row * g.ldc + col] = v;
+        if (row < g.M) {
+            g.C[(long)row * g.ldc + col] = v;
+            if (kv_dst) {
+                const int bm = row / g.kv_ntok, t = row - bm * g.kv_ntok;
+                kv_dst[((long)bm * g.kv_ctx + kv_off + t) * g.kv_d + kv_col] = v;
+            }
+        }
     }
 }
 
@@ -336,6 +350,11 @@ static long kwave_max_tiles() {
     return v;
 }
 
+bool gemm_takes_kwave(int M, int N, int K) {
+    const long tiles32 = (long)((N + 31) / 32) * ((M + 31) / 32);
+    return K >= 256 && tiles32 <= kwave_max_tiles();
+}
+
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (g.M <= 0 || g.N <= 0) return;
     if (g.K % 4 != 0 || g.lda % 4 != 0) throw std::invalid_argument("gemm: K and lda must be multiples of 4");
@@ -345,7 +364,9 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     const long tiles64 = (long)((g.N + 63) / 64) * ((g.M + 63) / 64);
     const int tiles_n = (g.N + 63) / 64;
     const long tiles32 = (long)((g.N + 31) / 32) * ((g.M + 31) / 32);
-    if ((g.force_kwave || tiles32 <= kwave_max_tiles()) && g.K >= 256) {
+    if (g.kcache && !(gemm_takes_kwave(g.M, g.N, g.K) || g.force_kwave))
+        throw std::invalid_argument("gemm: fused KV-cache append is only available on the k-wave path");
+    if (gemm_takes_kwave(g.M, g.N, g.K) || (g.force_kwave && g.K >= 256)) {
         hipLaunchKernelGGL(gemm_nt_f32_kwave_kernel, dim3((unsigned)tiles32), dim3(256), 0, ctx.stream, g);
     } else if (tiles64 >= 64) {
         const int tiles_m = (g.M + 63) / 64;
