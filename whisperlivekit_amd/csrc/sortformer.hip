@@ -91,10 +91,14 @@ void launch_sf_scale_copy(const LaunchCtx& ctx, const float* src, float* dst, lo
 //   Conformer (RelPositionMultiHeadAttention.forward): score[i][j] = ((q_i + u).k_j + (q_i + v).p[T-1-i+j]) / sqrt(dk)
 //     - the rel_shift of matrix_bd is just that index map, so it is never materialised;
 //   Transformer (NeMo MultiHeadAttention): score = q.k with q and k pre-scaled by dk^-1/4 in the projection GEMM.
-// Scores: lane j-strided over keys (each lane reads whole 4*dh-byte rows); softmax through LDS; P.V with lanes
-// over head dims (DHP-padded) and 64/DHP key sub-groups folded by shuffles.
+// Scores: DHP/4 lanes share one key row (a coalesced 4*dh-byte read per row, 4 rows in flight per lane) and fold
+// their partial dot products with xor shuffles; softmax through LDS; P.V with lanes over head dims (DHP-padded)
+// and 64/DHP key sub-groups folded by shuffles.
 template <int DHP>
 __global__ __launch_bounds__(256) void sf_attention_kernel(SfAttnArgs a) {
+    constexpr int LPK = DHP / 4;          // lanes per key row (one float4 each): 16 or 8
+    constexpr int KPI = 64 / LPK;         // key rows per wave-instruction: 4 or 8
+    constexpr int UNR = 4;                // row loads in flight per lane
     __shared__ __attribute__((aligned(16))) float qs[4][2][64];
     __shared__ float sc[4][kSfMaxFrames];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -104,33 +108,47 @@ __global__ __launch_bounds__(256) void sf_attention_kernel(SfAttnArgs a) {
         const float q = a.q[(long)i * a.ldq + h * dh + lane];
         qs[wave][0][lane] = a.bias_u ? q + a.bias_u[h * dh + lane] : q;
         qs[wave][1][lane] = a.bias_v ? q + a.bias_v[h * dh + lane] : q;
+    } else {
+        qs[wave][0][lane] = 0.f;
+        qs[wave][1][lane] = 0.f;
     }
     __syncthreads();
-    const float4* qu = reinterpret_cast<const float4*>(qs[wave][0]);
-    const float4* qv = reinterpret_cast<const float4*>(qs[wave][1]);
+    // scores: LPK lanes share one key row (coalesced 4*dh-byte reads), partial dot products folded by xor shuffles
+    const int sub = lane % LPK, kq = lane / LPK;
+    const bool live4 = sub * 4 < dh;
+    const float4 qu = reinterpret_cast<const float4*>(qs[wave][0])[sub];
+    const float4 qv = reinterpret_cast<const float4*>(qs[wave][1])[sub];
+    const float* kb = a.k + h * dh + (live4 ? sub * 4 : 0);
+    const float* pb = a.pos ? a.pos + (long)(a.pos_row0 - i) * a.ldp + h * dh + (live4 ? sub * 4 : 0) : nullptr;
     float mx = -INFINITY;
-    for (int j = lane; j < a.T; j += 64) {
-        const float4* kp = reinterpret_cast<const float4*>(a.k + (long)j * a.ldk + h * dh);
-        float ac = 0.f;
-        for (int c = 0; c < dh / 4; ++c) {
-            const float4 kk = kp[c], qq = qu[c];
-            ac = fmaf(qq.x, kk.x, ac); ac = fmaf(qq.y, kk.y, ac); ac = fmaf(qq.z, kk.z, ac); ac = fmaf(qq.w, kk.w, ac);
+    for (int j0 = 0; j0 < a.T; j0 += KPI * UNR) {
+        float4 kk[UNR], pp[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int j = min(j0 + u * KPI + kq, a.T - 1);
+            kk[u] = *reinterpret_cast<const float4*>(kb + (long)j * a.ldk);
+            pp[u] = pb ? *reinterpret_cast<const float4*>(pb + (long)j * a.ldp) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (a.pos) {
-            const float4* pp = reinterpret_cast<const float4*>(a.pos + (long)(a.pos_row0 - i + j) * a.ldp + h * dh);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int j = j0 + u * KPI + kq;
+            float ac = 0.f;
+            ac = fmaf(qu.x, kk[u].x, ac); ac = fmaf(qu.y, kk[u].y, ac); ac = fmaf(qu.z, kk[u].z, ac); ac = fmaf(qu.w, kk[u].w, ac);
             float bd = 0.f;
-            for (int c = 0; c < dh / 4; ++c) {
-                const float4 kk = pp[c], qq = qv[c];
-                bd = fmaf(qq.x, kk.x, bd); bd = fmaf(qq.y, kk.y, bd); bd = fmaf(qq.z, kk.z, bd); bd = fmaf(qq.w, kk.w, bd);
+            bd = fmaf(qv.x, pp[u].x, bd); bd = fmaf(qv.y, pp[u].y, bd); bd = fmaf(qv.z, pp[u].z, bd); bd = fmaf(qv.w, pp[u].w, bd);
+            float s = live4 ? ac + bd : 0.f;
+#pragma unroll
+            for (int off = LPK / 2; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+            s *= a.scale;
+            if (j < a.T) {
+                if (sub == 0) sc[wave][j] = s;
+                mx = fmaxf(mx, s);
             }
-            ac += bd;
         }
-        ac *= a.scale;
-        sc[wave][j] = ac;
-        mx = fmaxf(mx, ac);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    __syncthreads();
     float sum = 0.f;
     for (int j = lane; j < a.T; j += 64) {
         const float e = expf(sc[wave][j] - mx);
