@@ -187,6 +187,27 @@ int wlk_sf_step(wlk_sortformer* m, const float* feats_host, int n_feat, const fl
 int wlk_sf_export(wlk_sortformer* m, const char* what, float* host, uint64_t capacity, uint64_t* n_written);
 int wlk_sf_destroy(wlk_sortformer* m);
 
+/* ---- (f-next, rank 3) Silero VAD gate -------------------------------------------------------------------
+ * Replaces the TorchScript model the reference evaluates on the CPU once per 512-sample window
+ * (whisperlivekit/silero_vad_iterator.py:163-184 load_jit_vad; called at :254 from VADIterator.__call__, driven by
+ * FixedVADIterator :288-319 from audio_processor.py:1189-1190).  16 kHz model only.  The packed weight layout is
+ * defined by wlk_vad_tensor_name / wlk_vad_tensor_lookup (the host shim transposes the archive's tensors).
+ * A wlk_vad holds the weights of one GPU; a wlk_vad_stream holds what the TorchScript wrapper keeps per stream:
+ * the 64-sample context and the LSTM (h, c).  wlk_vad_stream_run consumes n_windows x 512 samples and returns one
+ * speech probability per window (two launches whatever n_windows is). */
+typedef struct wlk_vad wlk_vad;
+typedef struct wlk_vad_stream wlk_vad_stream;
+int wlk_vad_weights_floats(uint64_t* n_floats);
+int wlk_vad_tensor_lookup(const char* packed_name, uint64_t* offset_floats, uint64_t* numel);
+int wlk_vad_tensor_name(int index, const char** name);
+int wlk_vad_create(int device, const float* packed_host, uint64_t n_floats, wlk_vad** out);
+int wlk_vad_destroy(wlk_vad* m);
+int wlk_vad_stream_create(wlk_vad* m, int max_windows, wlk_vad_stream** out);
+int wlk_vad_stream_reset(wlk_vad_stream* s);                       /* model.reset_states() */
+int wlk_vad_stream_run(wlk_vad_stream* s, const float* pcm_host, int n_windows, float* probs_host);
+int wlk_vad_stream_state(wlk_vad_stream* s, float* h_host /* [128] */, float* c_host /* [128] */);
+int wlk_vad_stream_destroy(wlk_vad_stream* s);
+
 /* ---- diagnostics: one kernel on host data (used by the GPU parity tests only) ---------------- */
 const char* wlk_diag_last_error(void);
 /* c[m,n] = epilogue(a[m,k](row stride lda, a_floats floats in total) . w[n,k]^T + bias); flags:

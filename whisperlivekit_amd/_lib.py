@@ -80,6 +80,16 @@ def _declare(lib: C.CDLL) -> None:
         "wlk_sf_step": (cint, [p, p, cint, p, cint, p, cint, C.POINTER(cint), p, cint]),
         "wlk_sf_export": (cint, [p, C.c_char_p, p, u64, C.POINTER(u64)]),
         "wlk_sf_destroy": (cint, [p]),
+        "wlk_vad_weights_floats": (cint, [C.POINTER(u64)]),
+        "wlk_vad_tensor_lookup": (cint, [C.c_char_p, C.POINTER(u64), C.POINTER(u64)]),
+        "wlk_vad_tensor_name": (cint, [cint, C.POINTER(C.c_char_p)]),
+        "wlk_vad_create": (cint, [cint, p, u64, C.POINTER(p)]),
+        "wlk_vad_destroy": (cint, [p]),
+        "wlk_vad_stream_create": (cint, [p, cint, C.POINTER(p)]),
+        "wlk_vad_stream_reset": (cint, [p]),
+        "wlk_vad_stream_run": (cint, [p, p, cint, p]),
+        "wlk_vad_stream_state": (cint, [p, p, p]),
+        "wlk_vad_stream_destroy": (cint, [p]),
         "wlk_diag_last_error": (C.c_char_p, []),
         "wlk_diag_linear": (cint, [p, C.c_int64, C.c_int64, p, p, p, C.c_int64, cint, cint, cint, cint, C.c_float,
                                    cint, cint, p]),
@@ -103,6 +113,9 @@ EXPORTED_SYMBOLS = (
     "wlk_prof_end", "wlk_melspec_create", "wlk_melspec_run", "wlk_melspec_destroy",
     "wlk_sf_arena_floats", "wlk_sf_tensor_lookup", "wlk_sf_tensor_name", "wlk_sf_create", "wlk_sf_upload",
     "wlk_sf_finalize", "wlk_sf_step", "wlk_sf_export", "wlk_sf_destroy",
+    "wlk_vad_weights_floats", "wlk_vad_tensor_lookup", "wlk_vad_tensor_name", "wlk_vad_create", "wlk_vad_destroy",
+    "wlk_vad_stream_create", "wlk_vad_stream_reset", "wlk_vad_stream_run", "wlk_vad_stream_state",
+    "wlk_vad_stream_destroy",
     "wlk_diag_last_error", "wlk_diag_linear", "wlk_diag_linear_ln", "wlk_diag_layernorm",
     "wlk_diag_encoder_attention",
 )

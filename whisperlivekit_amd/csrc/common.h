@@ -227,8 +227,6 @@ void launch_sf_head(const LaunchCtx& ctx, const float* x, const float* w1, const
                     const float* b2, float* out, int T, int d, int n_spk);
 
 // ---- select.hip -----------------------------------------------------------------------------
-void launch_apply_adjust(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, const int* adj_row,
-                         const int* adj_ids, const float* adj_deltas, int n_adj);
 // adjustments (may be n_adj = 0) are applied to the logits in place before the reduction
 void launch_logsoftmax_topk(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, int k,
                             float* top_vals, int* top_ids, void* scratch, const int* adj_row, const int* adj_ids,

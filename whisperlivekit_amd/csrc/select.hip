@@ -12,30 +12,6 @@
 
 namespace wlk {
 
-__global__ void apply_adjust_kernel(float* logits, int n_vocab, int n_rows, const int* adj_row, const int* adj_ids,
-                                    const float* adj_deltas, int n_adj) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_adj) return;
-    const int id = adj_ids[i];
-    if (id < 0 || id >= n_vocab) return;
-    const float dl = adj_deltas[i];
-    const int r = adj_row[i];
-    if (r >= 0) {
-        if (r < n_rows) logits[(long)r * n_vocab + id] += dl;
-    } else {
-        for (int b = 0; b < n_rows; ++b) logits[(long)b * n_vocab + id] += dl;
-    }
-}
-
-void launch_apply_adjust(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, const int* adj_row,
-                         const int* adj_ids, const float* adj_deltas, int n_adj) {
-    if (n_adj <= 0) return;
-    KernelScope ks(ctx, "sel_adjust");
-    hipLaunchKernelGGL(apply_adjust_kernel, dim3((n_adj + 255) / 256), dim3(256), 0, ctx.stream, logits, n_vocab,
-                       n_rows, adj_row, adj_ids, adj_deltas, n_adj);
-    WLK_HIP(hipGetLastError());
-}
-
 constexpr int kSelThreads = 1024;
 constexpr int kMaxTopK = 8;
 
