@@ -58,7 +58,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--audio", default="speech", choices=["speech", "noise"])
     ap.add_argument("--no-diarization", action="store_true",
-                    help="skip the (separately timed) streaming-Sortformer leg reported under 'diarization'")
+                    help="skip the separately timed side legs ('diarization': streaming Sortformer; 'vad': Silero gate)")
     return ap.parse_args()
 
 
@@ -161,6 +161,45 @@ def diarization_leg(audio, seconds, device, cpu_check):
                    max_abs_err_vs_oracle_last_chunk=float(np.abs(ref - last["preds"]).max()))
     model.step = inner
     model.close()
+    return out
+
+
+def vad_leg(audio, device, cpu_check):
+    """SURVEY 8f rank 3, timed on its own: the Silero VAD gate over the same stream in 0.5 s chunks (real weights:
+    the reference's vendored checkpoint, carried as tests/golden/vad_weights_16k.npz)."""
+    from whisperlivekit_amd import vad as V
+    w = dict(np.load(os.path.join(ROOT, "tests", "golden", "vad_weights_16k.npz")))
+    weights = V.HipSileroVADWeights(w, device=device)
+    model = V.HipSileroVAD(weights)
+    it = V.HipFixedVADIterator(model)
+    out = {}
+    for rep in range(2):
+        it.reset_states()
+        ms, n_events = [], 0
+        for lo in range(0, len(audio), CHUNK):
+            a = time.perf_counter()
+            n_events += len(it(audio[lo:lo + CHUNK]))
+            ms.append(1e3 * (time.perf_counter() - a))
+        out = dict(p50_chunk_ms=round(statistics.median(ms), 4), max_chunk_ms=round(max(ms), 4), chunks=len(ms),
+                   chunk_s=0.5, events=n_events, weights="reference checkpoint silero_vad.jit (16 kHz sub-model)",
+                   parity="pinned: tests/golden/vad_cases.npz produced by the reference (tests/test_gpu_vad.py)")
+    if cpu_check:
+        import torch
+        from oracle import vad_oracle as vo
+        n = (len(audio) // 512) * 512
+        model.reset_states()
+        probs = model.probs(audio[:n])
+        threads = torch.get_num_threads()
+        torch.set_num_threads(1)
+        om = vo.OracleSileroVAD(w)
+        a = time.perf_counter()
+        ref = np.array([float(om(audio[i:i + 512])) for i in range(0, 64 * 512, 512)], np.float32)
+        cpu_ms = 1e3 * (time.perf_counter() - a) / 64
+        torch.set_num_threads(threads)
+        out.update(cpu_oracle_ms_per_chunk=round(cpu_ms * CHUNK / 512, 3), cpu_threads=1,
+                   max_abs_prob_err_vs_oracle=float(np.abs(probs[:64] - ref).max()))
+    model.close()
+    weights.close()
     return out
 
 
@@ -334,6 +373,13 @@ def main():
         except Exception as e:          # never let the side leg take the headline line down
             diar = {"error": f"{type(e).__name__}: {e}"}
 
+    vad = None
+    if rank == 0 and not args.no_diarization:
+        try:
+            vad = vad_leg(audios[0], local, cpu_check=not args.no_cpu_baseline)
+        except Exception as e:
+            vad = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         timed = [p for step in procs[args.warmup:] for p in step]
         n_enc = sum(p.model.counters["encode"] for p in timed)
@@ -369,6 +415,7 @@ def main():
             "launch_tags": tags,
             "cpu_baseline": cpu,
             "diarization": diar,
+            "vad": vad,
             "host_cores": os.cpu_count(),
         }
         print(json.dumps(out))
