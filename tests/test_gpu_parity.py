@@ -454,6 +454,24 @@ def test_hipgraph_replay_equals_eager_launches(monkeypatch):
     assert with_graph == eager
 
 
+@pytest.mark.parametrize("case", ["micro_12s", "tiny_6s", "base_4s", "micro_cif"])
+def test_merge_folded_into_out_projection_is_bit_identical(monkeypatch, case):
+    """Beam-1 steps: the merge of the 8 key splits of the cross-attention is the A-operand load of the out-projection
+    GEMV (and spare workgroups write the alignment rows) instead of a kernel of its own - same arithmetic, same order."""
+    def run():
+        g, proc, got = replay_stream(case, make_hip_processor)
+        trace = [(r["content_mel_len"], [(s.get("token"), s.get("frame"), s.get("sum_logprob")) for s in r["steps"]])
+                 for r in proc.trace]
+        words = [[(t.start, t.end, t.text) for t in toks] for _, toks, _ in got]
+        proc.close()
+        return trace, words
+    folded = run()
+    monkeypatch.setenv("WLK_NO_MERGE_FOLD", "1")
+    separate = run()
+    assert folded == separate
+    assert sum(len(steps) for _, steps in folded[0]) > 20
+
+
 def test_diarization_melspec_against_oracle():
     """a12 front end: 128-bin log-mel of 1 s chunks (NeMo FilterbankFeatures config) vs the torch restatement."""
     from oracle.sortformer_oracle import nemo_log_mel

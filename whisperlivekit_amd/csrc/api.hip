@@ -838,6 +838,8 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
             launch_linear(c, q, "dec_xq");
         }
         const int* ranks_l = m->n_align > 0 ? m->head_rank + (size_t)i * H : nullptr;
+        bool merged_xout = false;
+        GemmArgs xo_mg;   // carries the split-form operand description to the out projection when merged_xout
         if (R > 8 && !s->debug) {
             // prefill: MFMA flash kernel shares every K/V tile between 32 query rows
             FlashArgs fa;
@@ -875,12 +877,21 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
                 float* pm = sc + (size_t)8 * H * T;
                 float* pl = pm + (size_t)8 * H * 8;
                 float* po = pl + (size_t)8 * H * 8;
-                launch_decoder_cross_attention_split(c, ca, sc, pm, pl, po);
+                // beam-1 steps: the merge of the key splits is the A-operand load of the out projection below
+                merged_xout = fused && R == 1 && gemv1_folds_merge(d);
+                launch_decoder_cross_attention_split(c, ca, sc, pm, pl, po, !merged_xout);
+                if (merged_xout) {
+                    xo_mg.mg_pm = pm; xo_mg.mg_pl = pl; xo_mg.mg_po = po; xo_mg.mg_scores = sc;
+                    xo_mg.mg_head_rank = ranks_l; xo_mg.mg_ring = s->ring; xo_mg.mg_ring_row = s->ring_row;
+                    xo_mg.mg_beam_of_row = s->beam_of_row; xo_mg.mg_heads = H; xo_mg.mg_T = T;
+                    xo_mg.mg_ring_rows = s->ring_rows; xo_mg.mg_n_beam = s->beam;
+                    xo_mg.mg_side_blocks = ranks_l ? m->layer_rank_count[i] : 0;
+                }
             } else {
                 launch_decoder_cross_attention(c, ca);
             }
         }
-        GemmArgs xo;
+        GemmArgs xo = xo_mg;
         xo.A = s->datt; xo.lda = d; xo.W = L.xoutw; xo.bias = L.xoutb; xo.C = s->dx; xo.ldc = d; xo.M = R; xo.N = d;
         xo.K = d; xo.flags = kGemmResidual; xo.R = s->dx; xo.ldr = d;
         launch_linear(c, xo, "dec_xout");

@@ -84,6 +84,18 @@ struct GemmArgs {
     const int* kv_pos = nullptr;
     int kv_d = 0, kv_ctx = 0;
     int kv_ntok = 1;       // k-wave GEMM path: rows are [beam][kv_ntok] (decoder prefill)
+    // single-row GEMV (beam-1 decode step) whose A row is the cross-attention output still in split form: the merge
+    // of the kCrossSplit partial softmax states (cross_merge_kernel's arithmetic) is the operand load, and the last
+    // `mg_side_blocks` workgroups of the launch write the alignment heads' softmax rows into the alignment window
+    const float* mg_pm = nullptr;        // [H][kCrossSplit]
+    const float* mg_pl = nullptr;
+    const float* mg_po = nullptr;        // [H][kCrossSplit][64]
+    const float* mg_scores = nullptr;    // [H][T] raw scores of this layer
+    const int* mg_head_rank = nullptr;   // [H] alignment rank or -1
+    float* mg_ring = nullptr;
+    const int* mg_ring_row = nullptr;
+    const int* mg_beam_of_row = nullptr;
+    int mg_heads = 0, mg_T = 0, mg_ring_rows = 0, mg_n_beam = 1, mg_side_blocks = 0;
     bool force_kwave = false;   // diagnostics: take the k-wave kernel (under-filled grids) whatever the shape
 };
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag);
@@ -94,6 +106,8 @@ inline int gemv_row_bucket(int M) { return M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 
 inline bool gemv_applicable(int M, int K) {
     return M <= 8 && (long)gemv_row_bucket(M) * K * 4 <= 64 * 1024 && K % 4 == 0;
 }
+// can launch_gemv take the cross-attention output in split form (single-row kernel, K = d)?
+bool gemv1_folds_merge(int K);
 inline void launch_linear(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (gemv_applicable(g.M, g.K)) launch_gemv(ctx, g, tag);
     else launch_gemm(ctx, g, tag);
@@ -191,7 +205,8 @@ void launch_decoder_cross_attention(const LaunchCtx& ctx, const CrossAttnArgs& a
 // decode steps: keys split over several workgroups per (row, head) + merge; scratch layout is
 // [scores rows*H*T | pm rows*H*S | pl rows*H*S | po rows*H*S*64] (cross_split_scratch_floats)
 void launch_decoder_cross_attention_split(const LaunchCtx& ctx, const CrossAttnArgs& a, float* scores, float* pm,
-                                          float* pl, float* po);
+                                          float* pl, float* po, bool merge = true);
+constexpr int kCrossSplitWays = 8;   // == kCrossSplit of decoder.hip (checked there)
 size_t cross_split_scratch_floats(int rows, int n_head, int T);
 void launch_kv_gather(const LaunchCtx& ctx, const float* src, float* dst, const int* source_rows, int n_rows,
                       int len, int d, int ctx_len, int n_layer);

@@ -318,6 +318,7 @@ void launch_decoder_cross_attention(const LaunchCtx& ctx, const CrossAttnArgs& a
 // the full row into the alignment window.
 // ---------------------------------------------------------------------------------------------
 constexpr int kCrossSplit = 8;
+static_assert(kCrossSplit == kCrossSplitWays, "gemv1's merged operand load assumes the same split count");
 constexpr int kCrossUnroll = 12;   // key-row loads in flight per wave: covers ceil(1500/8)=188 keys / 16
 
 __global__ __launch_bounds__(256) void cross_split_kernel(CrossAttnArgs a, float* __restrict__ scores,
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256) void cross_merge_kernel(CrossAttnArgs a, const
 }
 
 void launch_decoder_cross_attention_split(const LaunchCtx& ctx, const CrossAttnArgs& a, float* scores, float* pm,
-                                          float* pl, float* po) {
+                                          float* pl, float* po, bool merge) {
     if ((a.T + kCrossSplit - 1) / kCrossSplit > kCrossUnroll * 16) throw std::invalid_argument("cross-attention: T too large");
     {
         KernelScope ks(ctx, "dec_cross_split", 4.0 * a.rows * (double)a.T * a.d, 4.0 * 2.0 * a.rows * (double)a.T * a.d);
@@ -449,7 +450,7 @@ void launch_decoder_cross_attention_split(const LaunchCtx& ctx, const CrossAttnA
                            pm, pl, po);
         WLK_HIP(hipGetLastError());
     }
-    {
+    if (merge) {   // beam-1 steps fold the merge into the out-projection GEMV (GemmArgs::mg_*)
         KernelScope ks(ctx, "dec_cross_merge");
         hipLaunchKernelGGL(cross_merge_kernel, dim3(a.rows, a.n_head), dim3(256), 0, ctx.stream, a, scores, pm, pl, po);
         WLK_HIP(hipGetLastError());

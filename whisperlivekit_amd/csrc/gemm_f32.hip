@@ -523,6 +523,25 @@ __global__ __launch_bounds__(256) void gemv1_f32_kernel(GemmArgs g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K4 = g.K >> 2;
     const int n_groups = (g.N + RPW - 1) / RPW;
+    if (g.mg_pm && (int)blockIdx.x >= (int)gridDim.x - g.mg_side_blocks) {
+        // side job (cross_merge_kernel's tail): softmax row of the k-th alignment head of this layer -> alignment window
+        int k = (int)blockIdx.x - ((int)gridDim.x - g.mg_side_blocks), head = -1;
+        for (int h = 0; h < g.mg_heads; ++h)
+            if (g.mg_head_rank[h] >= 0 && k-- == 0) head = h;
+        if (head < 0) return;
+        const long base = (long)head * kCrossSplitWays;
+        float M = g.mg_pm[base];
+#pragma unroll
+        for (int s = 1; s < kCrossSplitWays; ++s) M = fmaxf(M, g.mg_pm[base + s]);
+        float L = 0.f;
+#pragma unroll
+        for (int s = 0; s < kCrossSplitWays; ++s) L += g.mg_pl[base + s] * expf(g.mg_pm[base + s] - M);
+        float* dst = g.mg_ring + (((long)g.mg_head_rank[head] * g.mg_n_beam + g.mg_beam_of_row[0]) * g.mg_ring_rows +
+                                  g.mg_ring_row[0]) * (long)g.mg_T;
+        const float* srow = g.mg_scores + (long)head * g.mg_T;
+        for (int j = threadIdx.x; j < g.mg_T; j += 256) dst[j] = expf(srow[j] - M) / L;
+        return;
+    }
     const int grp = blockIdx.x * 4 + wave;
     if (grp >= n_groups) return;
     const int n_base = grp * RPW;
@@ -534,7 +553,30 @@ __global__ __launch_bounds__(256) void gemv1_f32_kernel(GemmArgs g) {
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
             w[u][r] = *reinterpret_cast<const float4*>(g.W + (long)min(n_base + r, g.N - 1) * g.K + (ok ? c : 0) * 4);
-        x[u] = *reinterpret_cast<const float4*>(g.A + (ok ? c : 0) * 4);
+        if (!g.mg_pm) {
+            x[u] = *reinterpret_cast<const float4*>(g.A + (ok ? c : 0) * 4);
+        } else {   // cross_merge_kernel's arithmetic for the head that owns dims 4c .. 4c+3
+            const int cc = ok ? c : 0;
+            const int head = (4 * cc) >> 6, dd = (4 * cc) & 63;
+            const long base = (long)head * kCrossSplitWays;
+            float M = g.mg_pm[base];
+#pragma unroll
+            for (int s = 1; s < kCrossSplitWays; ++s) M = fmaxf(M, g.mg_pm[base + s]);
+            float L = 0.f;
+            float f[kCrossSplitWays];
+#pragma unroll
+            for (int s = 0; s < kCrossSplitWays; ++s) {
+                f[s] = expf(g.mg_pm[base + s] - M);
+                L += g.mg_pl[base + s] * f[s];
+            }
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int s = 0; s < kCrossSplitWays; ++s) {
+                const float4 o = *reinterpret_cast<const float4*>(g.mg_po + (base + s) * 64 + dd);
+                acc.x += o.x * f[s]; acc.y += o.y * f[s]; acc.z += o.z * f[s]; acc.w += o.w * f[s];
+            }
+            x[u] = make_float4(acc.x / L, acc.y / L, acc.z / L, acc.w / L);
+        }
     }
     if (g.ln_gamma) {
         float v[UB * 4];
@@ -616,6 +658,8 @@ static bool gemv1_enabled() {
     return on;
 }
 
+bool gemv1_folds_merge(int K) { return gemv1_enabled() && K <= 2048 && K % 64 == 0 && getenv("WLK_NO_MERGE_FOLD") == nullptr; }
+
 void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (g.M <= 0 || g.N <= 0) return;
     if (!gemv_applicable(g.M, g.K) || g.lda % 4 != 0) throw std::invalid_argument("gemv: unsupported shape");
@@ -628,8 +672,11 @@ void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (blocks > 2048) blocks = 2048;
     const size_t lds = (size_t)mr * g.K * sizeof(float);
     KernelScope ks(ctx, tag, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    if (g.mg_pm && !(g.M == 1 && g.K <= 2048 && rpw <= 2 && gemv1_enabled() && !g.ln_gamma))
+        throw std::invalid_argument("gemv: the merged cross-attention operand needs the single-row kernel");
     if (g.M == 1 && g.K <= 2048 && rpw <= 2 && gemv1_enabled()) {
         const int ub = (g.K / 4 + 63) / 64;
+        blocks += g.mg_pm ? g.mg_side_blocks : 0;
 #define WLK_GEMV1(UBv)                                                                                             \
     do {                                                                                                           \
         if (rpw == 2) hipLaunchKernelGGL((gemv1_f32_kernel<UBv, 2>), dim3(blocks), dim3(256), 0, ctx.stream, g);   \
