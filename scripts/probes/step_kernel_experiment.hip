@@ -1,12 +1,13 @@
 // EXPERIMENT, NOT BUILT INTO libwlk_hip.so (kept as groundwork; see DESIGN.md "Things tried and reverted").
-// Round-1 measurement on MI355X (base.en, 128 workgroups): 473 us per step against 330 us for the one-kernel-per-op
-// path, and one of 11 golden streams (micro_cif, a 96-step call) deviated by 1e-2 in a log-prob sum - i.e. slower
-// AND not yet bit-exact.  Why slower: after each barrier the activation row is a fabric read (it was written
-// write-through by another XCD), the LayerNorm statistics wait for it, and only then are the weight loads issued -
-// two dependent memory round trips per phase plus the 2.9 us barrier, where a kernel launch overlaps the weight
-// fetch with the activation fetch.  A second attempt has to prefetch each phase's first weight rows BEFORE the
-// barrier wait and find the stale read.  It needs StepLayer / StepArgs declarations (see git history of this file's
-// first version in common.h) to compile.
+// v2, measured on MI355X (base.en): BIT-IDENTICAL to the one-kernel-per-op path on 5 golden streams, but slower:
+// 419 us per step with 128 workgroups (471 with 64, 609 with 32) against ~330 us.  v1's wrong results came from
+// phase buffers sharing a 128-byte cache line (a reader of buffer A cached the neighbouring, not yet written, head of
+// buffer B) - every buffer is padded to 256 bytes now.  Why it is still slower: a cross-XCD hand-off through memory
+// is a chain of write-through drain (s_waitcnt) -> atomic arrive -> poll -> fabric read of the activation row ->
+// epilogue operands, about 8.5 us per phase under real load (the isolated probe measured 2.9), i.e. no cheaper
+// than a kernel boundary; and at 485 VGPRs a workgroup owns its CU, so the kernel would also starve other streams.
+// Next idea: keep one step inside ONE XCD (32 CUs, hand-offs through its shared L2).  Needs the StepLayer / StepArgs
+// declarations and the api.hip hook of commit history to compile.
 // Persistent decode-step kernel (beam 1, one fed token): every decoder layer of TextDecoder.forward
 // (whisper/model.py:279-332 via AlignAtt._get_logits_and_cross_attn, simul_whisper.py:357-368) in ONE launch.
 //
@@ -19,6 +20,10 @@
 //     the consumers use plain loads - no release/acquire fence (those write back / invalidate whole caches);
 //   * arrive = s_waitcnt vmcnt(0) + one relaxed agent atomicAdd; wait = bounded relaxed polling (a timeout sets
 //     an error word the host checks; no spin is unbounded);
+//   * "never read earlier" holds per 128-byte cache line, so every phase buffer is padded to 256 bytes;
+//   * weights do not depend on activations: each wave loads the first K-chunk of the rows it will compute in the
+//     NEXT phase (and that phase's LayerNorm affine, bias and residual operands) BEFORE it waits at the barrier, so
+//     after the barrier only the activation row itself is a memory round trip;
 //   * the two barrier words alternate between launches (a device-side launch counter picks one; the other is
 //     re-zeroed), so the captured hipGraph node needs no memset node in front of it.
 // Arithmetic is the existing kernels' (gemv1_f32_kernel, decoder_self_attention_kernel, cross_split_kernel,
@@ -99,27 +104,65 @@ __device__ __forceinline__ float4 phase_x4(const GemvPhase& p, int c) {
     return make_float4(acc.x / L, acc.y / L, acc.z / L, acc.w / L);
 }
 
-// rows [n_base, n_base + RPW) of y = epilogue(W . LN(x) + b) by ONE wave; same reduction / fmaf order as gemv1_f32_kernel
+constexpr int kCH = 4;   // float4 chunks of K in flight per lane
+
+// What a wave can fetch for its first row group of a GEMV phase before the activations exist
+struct Pref {
+    float4 w[kCH][4];
+    float4 ga[kCH], be[kCH];
+};
+
+__device__ __forceinline__ int phase_rpw(const GemvPhase& p, int n_waves) { return p.N > n_waves ? 4 : 1; }
+
 template <int RPW>
-__device__ void gemv_rows(const GemvPhase& p, int n_base, int lane, float mean, float rstd) {
-    constexpr int CH = 4;
+__device__ __forceinline__ void gemv_prefetch_rows(const GemvPhase& p, int n_base, int lane, Pref& pf) {
+    const int K4 = p.K >> 2;
+#pragma unroll
+    for (int u = 0; u < kCH; ++u) {
+        const int c = lane + 64 * u;
+        const int cc = (c < K4 ? c : 0) * 4;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+            pf.w[u][r] = *reinterpret_cast<const float4*>(p.W + (long)min(n_base + r, p.N - 1) * p.K + cc);
+        if (p.ln_g) {
+            pf.ga[u] = *reinterpret_cast<const float4*>(p.ln_g + cc);
+            pf.be[u] = *reinterpret_cast<const float4*>(p.ln_b + cc);
+        }
+    }
+}
+
+__device__ __forceinline__ void gemv_prefetch(const GemvPhase& p, int wid, int n_waves, int lane, Pref& pf) {
+    if (phase_rpw(p, n_waves) == 4) {
+        if (wid * 4 < p.N) gemv_prefetch_rows<4>(p, wid * 4, lane, pf);
+    } else {
+        if (wid < p.N) gemv_prefetch_rows<1>(p, wid, lane, pf);
+    }
+}
+
+// rows [n_base, n_base + RPW) of y = epilogue(W . LN(x) + b) by ONE wave; same reduction / fmaf order as
+// gemv1_f32_kernel.  `pf` holds chunk 0 of W (and of the LayerNorm affine) when `use_pf`.
+template <int RPW>
+__device__ __forceinline__ void gemv_rows(const GemvPhase& p, int n_base, int lane, float mean, float rstd, const Pref& pf,
+                                          bool use_pf) {
     const int K4 = p.K >> 2;
     float acc[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) acc[r] = 0.f;
-    for (int c0 = 0; c0 < K4; c0 += 64 * CH) {
-        float4 w[CH][RPW], x[CH];
+    for (int c0 = 0; c0 < K4; c0 += 64 * kCH) {
+        float4 w[kCH][RPW], x[kCH];
+        const bool first = use_pf && c0 == 0;
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
+        for (int u = 0; u < kCH; ++u) {
             const int c = c0 + lane + 64 * u;
             const bool ok = c < K4;
+            const int cc = (ok ? c : 0) * 4;
 #pragma unroll
             for (int r = 0; r < RPW; ++r)
-                w[u][r] = *reinterpret_cast<const float4*>(p.W + (long)min(n_base + r, p.N - 1) * p.K + (ok ? c : 0) * 4);
+                w[u][r] = first ? pf.w[u][r] : *reinterpret_cast<const float4*>(p.W + (long)min(n_base + r, p.N - 1) * p.K + cc);
             x[u] = ok ? phase_x4(p, c) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.ln_g) {
-                const float4 ga = *reinterpret_cast<const float4*>(p.ln_g + (ok ? c : 0) * 4);
-                const float4 be = *reinterpret_cast<const float4*>(p.ln_b + (ok ? c : 0) * 4);
+                const float4 ga = first ? pf.ga[u] : *reinterpret_cast<const float4*>(p.ln_g + cc);
+                const float4 be = first ? pf.be[u] : *reinterpret_cast<const float4*>(p.ln_b + cc);
                 x[u].x = (x[u].x - mean) * rstd * ga.x + be.x;
                 x[u].y = (x[u].y - mean) * rstd * ga.y + be.y;
                 x[u].z = (x[u].z - mean) * rstd * ga.z + be.z;
@@ -127,7 +170,7 @@ __device__ void gemv_rows(const GemvPhase& p, int n_base, int lane, float mean, 
             }
         }
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
+        for (int u = 0; u < kCH; ++u) {
             if (c0 + lane + 64 * u < K4) {
 #pragma unroll
                 for (int r = 0; r < RPW; ++r) {
@@ -164,7 +207,7 @@ __device__ void gemv_rows(const GemvPhase& p, int n_base, int lane, float mean, 
     }
 }
 
-__device__ __attribute__((noinline)) void gemv_phase(const GemvPhase& p, int wid, int n_waves, int lane) {
+__device__ __forceinline__ void gemv_phase(const GemvPhase& p, int wid, int n_waves, int lane, const Pref& pf) {
     float mean = 0.f, rstd = 0.f;
     if (p.ln_g) {   // layernorm_kernel's statistics order: lane-strided scalar partial sums, xor fold
         constexpr int kMax = 24;
@@ -189,10 +232,10 @@ __device__ __attribute__((noinline)) void gemv_phase(const GemvPhase& p, int wid
         for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
         rstd = 1.0f / sqrtf(sq / (float)p.K + 1e-5f);
     }
-    if (p.N > n_waves) {
-        for (int n0 = wid * 4; n0 < p.N; n0 += n_waves * 4) gemv_rows<4>(p, n0, lane, mean, rstd);
+    if (phase_rpw(p, n_waves) == 4) {
+        for (int n0 = wid * 4, it = 0; n0 < p.N; n0 += n_waves * 4, ++it) gemv_rows<4>(p, n0, lane, mean, rstd, pf, it == 0);
     } else {
-        for (int n0 = wid; n0 < p.N; n0 += n_waves) gemv_rows<1>(p, n0, lane, mean, rstd);
+        for (int n0 = wid, it = 0; n0 < p.N; n0 += n_waves, ++it) gemv_rows<1>(p, n0, lane, mean, rstd, pf, it == 0);
     }
 }
 
@@ -379,11 +422,13 @@ __device__ __attribute__((noinline)) void cross_split_part(StepShared& sh, const
     __syncthreads();
 }
 
+__device__ __forceinline__ size_t pad64(size_t n) { return (n + 63) / 64 * 64; }
+
 __global__ __launch_bounds__(256) void decode_step_kernel(StepArgs a) {
     __shared__ __attribute__((aligned(16))) StepShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = gridDim.x, b = blockIdx.x;
-    const int wid = b * 4 + wave, n_waves = G * 4;
+    const int wid = wave * G + b, n_waves = G * 4;     // consecutive row groups land on different workgroups
     const int d = a.d, H = a.n_head, T = a.T;
     // which barrier word this launch uses; the other one is made ready for the next launch
     const unsigned launch_no = a.bar[2];
@@ -392,17 +437,28 @@ __global__ __launch_bounds__(256) void decode_step_kernel(StepArgs a) {
     unsigned phase = 0;
     const int offset = *a.offset_p;
     const int n_keys = offset + 1;
+    Pref pf;
 
-    // phase 0: token + position embedding (embed_kernel)
+    auto make_qkv = [&](const StepLayer& L, const float* x_in, float* qkv) {
+        GemvPhase p;
+        p.W = L.qkvw; p.bias = L.qkvb; p.N = 3 * d; p.K = d; p.x = x_in; p.ln_g = L.ln1w; p.ln_b = L.ln1b;
+        p.flags = kGemmScaleCols; p.scale = a.scale; p.scale_cols = 2 * d; p.out = qkv;
+        p.kc = L.kc; p.vc = L.vc; p.kv_d = d; p.kv_at = (long)offset * d;
+        return p;
+    };
+
+    // phase 0: token + position embedding (embed_kernel); the first layer's qkv rows are fetched meanwhile
     float* x_in = a.scratch;
+    float* lay = a.scratch + a.emb_floats;
     {
         const float* e = a.tok_emb + (long)a.tokens[0] * d;
         const float* pe = a.pos_emb + (long)offset * d;
         for (int c = b * 256 + tid; c < d; c += G * 256) st_sc1(x_in + c, e[c] + pe[c]);
     }
+    GemvPhase p_next = make_qkv(a.layers[0], x_in, lay);
+    gemv_prefetch(p_next, wid, n_waves, lane, pf);
     step_barrier(word, ++phase * G, a.err);
 
-    float* lay = a.scratch + a.emb_floats;
     for (int l = 0; l < a.n_layer; ++l, lay += a.layer_floats) {
         const StepLayer& L = a.layers[l];
         float* qkv = lay;
@@ -410,105 +466,100 @@ __global__ __launch_bounds__(256) void decode_step_kernel(StepArgs a) {
         float* x1 = att + d;
         float* q = x1 + d;
         float* pm = q + d;
-        float* pl = pm + H * kStepSplit;
-        float* po = pl + H * kStepSplit;
+        float* pl = pm + pad64((size_t)H * kStepSplit);
+        float* po = pl + pad64((size_t)H * kStepSplit);
         float* scores = po + (size_t)H * kStepSplit * 64;
-        float* x2 = scores + (size_t)H * T;
+        float* x2 = scores + pad64((size_t)H * T);
         float* mlp = x2 + d;
         float* x3 = mlp + 4 * d;
-        const long kv_at = (long)offset * d;
 
-        {   // x -> [q | k | v], k/v appended to the self-attention caches
-            GemvPhase p;
-            p.W = L.qkvw; p.bias = L.qkvb; p.N = 3 * d; p.K = d; p.x = x_in; p.ln_g = L.ln1w; p.ln_b = L.ln1b;
-            p.flags = kGemmScaleCols; p.scale = a.scale; p.scale_cols = 2 * d; p.out = qkv;
-            p.kc = L.kc; p.vc = L.vc; p.kv_d = d; p.kv_at = kv_at;
-            gemv_phase(p, wid, n_waves, lane);
-        }
+        gemv_phase(p_next, wid, n_waves, lane, pf);            // x -> [q | k | v] (+ caches)
+        GemvPhase p_out;
+        p_out.W = L.outw; p_out.bias = L.outb; p_out.N = d; p_out.K = d; p_out.x = att; p_out.flags = kGemmResidual;
+        p_out.R = x_in; p_out.out = x1;
         step_barrier(word, ++phase * G, a.err);
         if (b < H) self_attention_head(sh, qkv, L.kc, L.vc, att, b, d, n_keys);
+        gemv_prefetch(p_out, wid, n_waves, lane, pf);
         step_barrier(word, ++phase * G, a.err);
-        {
-            GemvPhase p;
-            p.W = L.outw; p.bias = L.outb; p.N = d; p.K = d; p.x = att; p.flags = kGemmResidual; p.R = x_in; p.out = x1;
-            gemv_phase(p, wid, n_waves, lane);
-        }
+        gemv_phase(p_out, wid, n_waves, lane, pf);             // self-attention out projection + residual
+        GemvPhase p_xq;
+        p_xq.W = L.xqw; p_xq.bias = L.xqb; p_xq.N = d; p_xq.K = d; p_xq.x = x1; p_xq.ln_g = L.lnxw; p_xq.ln_b = L.lnxb;
+        p_xq.flags = kGemmScaleCols; p_xq.scale = a.scale; p_xq.scale_cols = d; p_xq.out = q;
+        gemv_prefetch(p_xq, wid, n_waves, lane, pf);
         step_barrier(word, ++phase * G, a.err);
-        {
-            GemvPhase p;
-            p.W = L.xqw; p.bias = L.xqb; p.N = d; p.K = d; p.x = x1; p.ln_g = L.lnxw; p.ln_b = L.lnxb;
-            p.flags = kGemmScaleCols; p.scale = a.scale; p.scale_cols = d; p.out = q;
-            gemv_phase(p, wid, n_waves, lane);
-        }
+        gemv_phase(p_xq, wid, n_waves, lane, pf);              // cross-attention query
+        GemvPhase p_xo;   // merged cross-attention output -> out projection (+ residual); the merge is the operand load
+        p_xo.W = L.xoutw; p_xo.bias = L.xoutb; p_xo.N = d; p_xo.K = d; p_xo.x = nullptr; p_xo.pm = pm; p_xo.pl = pl;
+        p_xo.po = po; p_xo.flags = kGemmResidual; p_xo.R = x1; p_xo.out = x2;
         step_barrier(word, ++phase * G, a.err);
         for (int w = b; w < H * kStepSplit; w += G) {
             const int head = w / kStepSplit, ks = w - head * kStepSplit;
             const bool keep = L.head_rank && L.head_rank[head] >= 0;
             cross_split_part(sh, q, L.xk, L.xv, a.ldkv, T, head, ks, keep, scores, pm, pl, po);
         }
+        gemv_prefetch(p_xo, wid, n_waves, lane, pf);
         step_barrier(word, ++phase * G, a.err);
-        {   // merged cross-attention output -> out projection (+ residual); the merge is the A-operand load
-            GemvPhase p;
-            p.W = L.xoutw; p.bias = L.xoutb; p.N = d; p.K = d; p.x = nullptr; p.pm = pm; p.pl = pl; p.po = po;
-            p.flags = kGemmResidual; p.R = x1; p.out = x2;
-            gemv_phase(p, wid, n_waves, lane);
-            // side job of the last workgroups: softmax rows of this layer's alignment heads into the alignment window
-            // (cross_merge_kernel's tail); consumed by later KERNELS, so plain stores
-            if (L.head_rank) {
-                int k = G - 1 - b, found = -1;
-                for (int h = 0; h < H; ++h)
-                    if (L.head_rank[h] >= 0 && k-- == 0) found = h;
-                if (found >= 0) {
-                    const long base = (long)found * kStepSplit;
-                    float M = pm[base];
+        gemv_phase(p_xo, wid, n_waves, lane, pf);
+        // side job of the last workgroups: softmax rows of this layer's alignment heads into the alignment window
+        // (cross_merge_kernel's tail); consumed by later KERNELS, so plain stores
+        if (L.head_rank) {
+            int k = G - 1 - b, found = -1;
+            for (int h = 0; h < H; ++h)
+                if (L.head_rank[h] >= 0 && k-- == 0) found = h;
+            if (found >= 0) {
+                const long base = (long)found * kStepSplit;
+                float M = pm[base];
 #pragma unroll
-                    for (int s = 1; s < kStepSplit; ++s) M = fmaxf(M, pm[base + s]);
-                    float Lsum = 0.f;
+                for (int s = 1; s < kStepSplit; ++s) M = fmaxf(M, pm[base + s]);
+                float Lsum = 0.f;
 #pragma unroll
-                    for (int s = 0; s < kStepSplit; ++s) Lsum += pl[base + s] * expf(pm[base + s] - M);
-                    float* dst = a.ring + (((long)L.head_rank[found] * a.n_beam + a.beam_of_row[0]) * a.ring_rows + a.ring_row[0]) * T;
-                    const float* srow = scores + (long)found * T;
-                    for (int j = tid; j < T; j += 256) dst[j] = expf(srow[j] - M) / Lsum;
-                }
+                for (int s = 0; s < kStepSplit; ++s) Lsum += pl[base + s] * expf(pm[base + s] - M);
+                float* dst = a.ring + (((long)L.head_rank[found] * a.n_beam + a.beam_of_row[0]) * a.ring_rows + a.ring_row[0]) * T;
+                const float* srow = scores + (long)found * T;
+                for (int j = tid; j < T; j += 256) dst[j] = expf(srow[j] - M) / Lsum;
             }
         }
+        GemvPhase p_fc1;
+        p_fc1.W = L.fc1w; p_fc1.bias = L.fc1b; p_fc1.N = 4 * d; p_fc1.K = d; p_fc1.x = x2; p_fc1.ln_g = L.ln2w;
+        p_fc1.ln_b = L.ln2b; p_fc1.flags = kGemmGelu; p_fc1.out = mlp;
+        gemv_prefetch(p_fc1, wid, n_waves, lane, pf);
         step_barrier(word, ++phase * G, a.err);
-        {
-            GemvPhase p;
-            p.W = L.fc1w; p.bias = L.fc1b; p.N = 4 * d; p.K = d; p.x = x2; p.ln_g = L.ln2w; p.ln_b = L.ln2b;
-            p.flags = kGemmGelu; p.out = mlp;
-            gemv_phase(p, wid, n_waves, lane);
-        }
+        gemv_phase(p_fc1, wid, n_waves, lane, pf);
+        const bool last = l + 1 == a.n_layer;
+        GemvPhase p_fc2;
+        p_fc2.W = L.fc2w; p_fc2.bias = L.fc2b; p_fc2.N = d; p_fc2.K = 4 * d; p_fc2.x = mlp; p_fc2.flags = kGemmResidual;
+        p_fc2.R = x2; p_fc2.out = last ? a.x_out : x3; p_fc2.out_plain = last;
+        gemv_prefetch(p_fc2, wid, n_waves, lane, pf);
         step_barrier(word, ++phase * G, a.err);
-        {
-            const bool last = l + 1 == a.n_layer;
-            GemvPhase p;
-            p.W = L.fc2w; p.bias = L.fc2b; p.N = d; p.K = 4 * d; p.x = mlp; p.flags = kGemmResidual; p.R = x2;
-            p.out = last ? a.x_out : x3; p.out_plain = last;
-            gemv_phase(p, wid, n_waves, lane);
+        gemv_phase(p_fc2, wid, n_waves, lane, pf);
+        if (!last) {
+            p_next = make_qkv(a.layers[l + 1], x3, lay + a.layer_floats);
+            gemv_prefetch(p_next, wid, n_waves, lane, pf);
+            step_barrier(word, ++phase * G, a.err);
         }
-        if (l + 1 < a.n_layer) step_barrier(word, ++phase * G, a.err);
         x_in = x3;
     }
     if (b == 0 && tid == 0) a.bar[2] = launch_no + 1u;
 }
 
+static size_t step_layer_floats(int d, int n_head, int T) {
+    auto pad = [](size_t n) { return (n + 63) / 64 * 64; };
+    return (size_t)3 * d + d + d + d + 2 * pad((size_t)n_head * kStepSplit) + (size_t)n_head * kStepSplit * 64 +
+           pad((size_t)n_head * T) + d + 4 * (size_t)d + d;
+}
+
 size_t step_scratch_floats(int n_layer, int d, int n_head, int T) {
-    const size_t layer = (size_t)3 * d + d + d + d + 2 * (size_t)n_head * kStepSplit + (size_t)n_head * kStepSplit * 64 +
-                         (size_t)n_head * T + d + 4 * (size_t)d + d;
-    return (size_t)d + (size_t)n_layer * ((layer + 63) / 64 * 64) + 64;
+    return (size_t)d + (size_t)n_layer * step_layer_floats(d, n_head, T) + 64;
 }
 
 void launch_decode_step(const LaunchCtx& ctx, StepArgs a, int n_blocks) {
     if (a.d % 64 != 0 || a.d > 1536) throw std::invalid_argument("decode step kernel: unsupported width");
     if ((a.T + kStepSplit - 1) / kStepSplit > kStepUnroll * 16) throw std::invalid_argument("decode step kernel: T too large");
-    const size_t layer = (size_t)3 * a.d + a.d + a.d + a.d + 2 * (size_t)a.n_head * kStepSplit + (size_t)a.n_head * kStepSplit * 64 +
-                         (size_t)a.n_head * a.T + a.d + 4 * (size_t)a.d + a.d;
     a.emb_floats = a.d;
-    a.layer_floats = (layer + 63) / 64 * 64;
-    double bytes = 0.0;   // algorithmic: every decoder-layer weight once + the cross K/V of every layer
-    bytes += 4.0 * a.n_layer * (12.0 * a.d * a.d + 2.0 * a.T * a.d);
-    KernelScope ks(ctx, "dec_step_persistent", 2.0 * a.n_layer * 12.0 * a.d * a.d, bytes);
+    a.layer_floats = step_layer_floats(a.d, a.n_head, a.T);
+    // algorithmic bytes: every decoder-layer weight once + the cross K/V of every layer
+    KernelScope ks(ctx, "dec_step_persistent", 2.0 * a.n_layer * 12.0 * a.d * a.d,
+                   4.0 * a.n_layer * (12.0 * a.d * a.d + 2.0 * a.T * a.d));
     hipLaunchKernelGGL(decode_step_kernel, dim3(n_blocks), dim3(256), 0, ctx.stream, a);
     WLK_HIP(hipGetLastError());
 }
