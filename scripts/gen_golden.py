@@ -321,6 +321,12 @@ def gen_streams():
         # language auto-detect on the multilingual twin of the micro shape
         "micro_cif": lambda: run_stream("micro.en", a12[:128000], cfg_over=dict(cif_ckpt_path="golden:cif_micro.pt")),
         "micromulti_auto": lambda: run_stream("micro", a12[:128000], cfg_over=dict(language="auto"), seed=4),
+        # a9/a10 corners: prompt context with a static prefix and a tight token budget for it; minimum segment
+        # length + a tight frame threshold + beam 3
+        "micro_prompt": lambda: run_stream("micro.en", a12, cfg_over=dict(static_init_prompt=" ab cd", init_prompt=" ef gh ij",
+                                                                            max_context_tokens=12)),
+        "micro_minlen_beam3": lambda: run_stream("micro.en", a12[:112000], cfg_over=dict(audio_min_len=1.0, frame_threshold=10,
+                                                                                           beam_size=3)),
     }
     for k, make in table.items():
         if not want(k):

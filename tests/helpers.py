@@ -65,6 +65,8 @@ def stream_audio(case_name):
         "tiny_6s": lambda: synth.to_pcm16_roundtrip(synth.speech_like(6.0, 2)),
         "base_4s": lambda: synth.to_pcm16_roundtrip(synth.speech_like(6.0, 2))[:64000],
         "micro_cif": lambda: a12()[:128000],
+        "micro_prompt": lambda: a12(),
+        "micro_minlen_beam3": lambda: a12()[:112000],
         "micromulti_auto": lambda: a12()[:128000],
     }
     return table[case_name]()
