@@ -472,6 +472,30 @@ def test_merge_folded_into_out_projection_is_bit_identical(monkeypatch, case):
     assert sum(len(steps) for _, steps in folded[0]) > 20
 
 
+def test_transcribe_wav_script_streams_a_file(tmp_path):
+    """scripts/transcribe_wav.py: s16le WAV -> insert_pcm16_chunk / process_iter loop; same words as the float path."""
+    import sys
+    import wave
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import transcribe_wav
+    audio = synth.speech_like(6.0, 0)
+    pcm = np.clip(np.round(audio * 32768.0), -32768, 32767).astype(np.int16)
+    path = str(tmp_path / "a.wav")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+    words = transcribe_wav.main([path, "--synthetic", "micro.en"])
+    from whisperlivekit_amd.backend import HipSimulStreamingASR, HipSimulStreamingOnlineProcessor
+    proc = HipSimulStreamingOnlineProcessor(HipSimulStreamingASR("micro.en", hip_model=hip_model("micro.en")))
+    ref = []
+    as_float = pcm.astype(np.float32) / 32768.0
+    for lo in range(0, len(pcm), 8000):
+        proc.insert_audio_chunk(as_float[lo:lo + 8000], min(lo + 8000, len(pcm)) / 16000)
+        ref += proc.process_iter()[0]
+    ref += proc.process_iter(is_last=True)[0]
+    proc.close()
+    assert [(t.start, t.end, t.text) for t in words] == [(t.start, t.end, t.text) for t in ref]
+
+
 def test_diarization_melspec_against_oracle():
     """a12 front end: 128-bin log-mel of 1 s chunks (NeMo FilterbankFeatures config) vs the torch restatement."""
     from oracle.sortformer_oracle import nemo_log_mel
