@@ -150,3 +150,48 @@ def test_warmup_raises_when_inference_is_broken():
 
     with pytest.raises(RuntimeError, match="refusing to serve"):
         Broken().warmup(np.zeros(16000, dtype=np.float32))
+
+
+def test_new_speaker_returns_the_tail_tokens_and_position():
+    """reference tests/test_asr_coalescing_boundaries.py:265-290"""
+    class Model:
+        speaker = -1
+        global_time_offset = 0.0
+
+        def refresh_segment(self, complete=False):
+            self.refreshed = complete
+
+    token = tok(0.0, 2.5, "tail")
+    p = object.__new__(HipSimulStreamingOnlineProcessor)
+    p.asr = SimpleNamespace()
+    p.process_iter = lambda is_last=False: ([token], 2.5)
+    p.model = Model()
+    p._last_committed_end = 0.0
+    p._recent_words = ["old"]
+    tokens, upto = p.new_speaker(P.ChangeSpeaker(speaker=3, start=3))
+    assert tokens == [token] and upto == 2.5
+    assert p.model.refreshed is True and p.model.speaker == 3 and p.model.global_time_offset == 3
+    assert p._recent_words == []
+
+
+def test_silence_shorter_than_five_seconds_becomes_zeros_longer_resets_the_segment():
+    """simul_whisper/backend.py:77-93 (exercised end to end by the micro_events golden stream; here the contract)"""
+    class Model:
+        global_time_offset = 0.0
+
+        def __init__(self):
+            self.inserted, self.refreshed = [], []
+
+        def insert_audio(self, a=None):
+            self.inserted.append(len(a))
+
+        def refresh_segment(self, complete=False):
+            self.refreshed.append(complete)
+
+    p = object.__new__(HipSimulStreamingOnlineProcessor)
+    p.model, p.end, p._last_committed_end, p._recent_words = Model(), 10.0, 9.0, ["w"]
+    p.end_silence(1.5, 10.0)
+    assert p.model.inserted == [24000] and p.model.refreshed == [] and p.end == pytest.approx(11.5)
+    p.end_silence(6.0, 11.5)
+    assert p.model.refreshed == [True] and p.model.global_time_offset == pytest.approx(17.5)
+    assert p._last_committed_end == pytest.approx(17.5) and p._recent_words == [] and p.end == pytest.approx(17.5)
