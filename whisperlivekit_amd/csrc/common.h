@@ -96,7 +96,8 @@ struct GemmArgs {
     const int* mg_ring_row = nullptr;
     const int* mg_beam_of_row = nullptr;
     int mg_heads = 0, mg_T = 0, mg_ring_rows = 0, mg_n_beam = 1, mg_side_blocks = 0;
-    bool force_kwave = false;   // diagnostics: take the k-wave kernel (under-filled grids) whatever the shape
+    bool force_kwave = false;
+    bool gemm_plain_loop = false;   // A/B switch: LDS fragment reads right before use instead of a group ahead   // diagnostics: take the k-wave kernel (under-filled grids) whatever the shape
 };
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag);
 bool gemm_takes_kwave(int M, int N, int K);   // launch_gemm's shape rule for the k-wave kernel (under-filled grids)

@@ -130,38 +130,53 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const int a_off = (wr * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
     const int w_off = (wc * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
-    auto mma = [&](int buf) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][a_off + s * 8]);
-            const float4 b4 = *reinterpret_cast<const float4*>(&Ws[buf][w_off + s * 8]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
-        }
-    };
-
-    // Straight-line software pipeline, two k-tiles per trip, no conditionals inside: tiles past the end
-    // of K are fetched out of bounds (-> zeros, contributing nothing), so the load count in flight is a
-    // compile-time constant and hipcc emits counted vmcnt waits instead of vmcnt(0).
+    // Straight-line software pipeline, two k-tiles per trip, no conditionals inside: tiles past the end of K are
+    // fetched out of bounds (-> zeros, contributing nothing), so the load count in flight is a compile-time
+    // constant and hipcc emits counted vmcnt waits instead of vmcnt(0).
+    //
+    // The 16 MFMAs of a k-tile are one dependent chain (64 cycles each) and a wave issues in order, so every LDS
+    // fragment read is placed right AFTER an MFMA has been issued and is consumed a full MFMA group later: the
+    // fragments of groups 2-3 are read during group 0-1's matrix work, those of the next tile's groups 0-1 (after
+    // the barrier that publishes that tile) during groups 2-3.  Same accumulation order as the plain loop.
     Stage<NA, NW> s0, s1;
     fetch(s0, 0);
     fetch(s1, 1);
     stash(s0, 0);
     __syncthreads();
     const int nk2 = (nk + 1) & ~1;
-    for (int kt = 0; kt < nk2; kt += 2) {
-        fetch(s0, kt + 2);
-        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch loads ahead of the MFMA block
-        mma(0);            // tile kt
-        stash(s1, 1);      // tile kt+1 (loaded one full trip ago)
-        __syncthreads();
-        fetch(s1, kt + 3);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1);            // tile kt+1
-        stash(s0, 0);      // tile kt+2
-        __syncthreads();
+    {
+#define WLK_MFMA(a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
+#define WLK_SB() __builtin_amdgcn_sched_barrier(0)
+        auto rd_a = [&](int buf, int grp) { return *reinterpret_cast<const float4*>(&As[buf][a_off + grp * 8]); };
+        auto rd_w = [&](int buf, int grp) { return *reinterpret_cast<const float4*>(&Ws[buf][w_off + grp * 8]); };
+        float4 fa0 = rd_a(0, 0), fb0 = rd_w(0, 0), fa1 = rd_a(0, 1), fb1 = rd_w(0, 1), fa2, fb2, fa3, fb3;
+        // one k-tile in LDS buffer `buf`; `nxt` is the register stage that goes to the other buffer meanwhile
+        auto tile = [&](int buf, const Stage<NA, NW>& nxt) {
+            WLK_MFMA(fa0.x, fb0.x); WLK_SB();
+            fa2 = rd_a(buf, 2); fb2 = rd_w(buf, 2); WLK_SB();
+            WLK_MFMA(fa0.y, fb0.y); WLK_MFMA(fa0.z, fb0.z); WLK_MFMA(fa0.w, fb0.w);
+            WLK_MFMA(fa1.x, fb1.x); WLK_SB();
+            fa3 = rd_a(buf, 3); fb3 = rd_w(buf, 3); WLK_SB();
+            WLK_MFMA(fa1.y, fb1.y); WLK_MFMA(fa1.z, fb1.z); WLK_MFMA(fa1.w, fb1.w); WLK_SB();
+            stash(nxt, buf ^ 1);
+            __syncthreads();
+            WLK_MFMA(fa2.x, fb2.x); WLK_SB();
+            fa0 = rd_a(buf ^ 1, 0); fb0 = rd_w(buf ^ 1, 0); WLK_SB();
+            WLK_MFMA(fa2.y, fb2.y); WLK_MFMA(fa2.z, fb2.z); WLK_MFMA(fa2.w, fb2.w);
+            WLK_MFMA(fa3.x, fb3.x); WLK_SB();
+            fa1 = rd_a(buf ^ 1, 1); fb1 = rd_w(buf ^ 1, 1); WLK_SB();
+            WLK_MFMA(fa3.y, fb3.y); WLK_MFMA(fa3.z, fb3.z); WLK_MFMA(fa3.w, fb3.w); WLK_SB();
+        };
+        for (int kt = 0; kt < nk2; kt += 2) {
+            fetch(s0, kt + 2);
+            WLK_SB();
+            tile(0, s1);       // tile kt; tile kt+1 goes to buffer 1
+            fetch(s1, kt + 3);
+            WLK_SB();
+            tile(1, s0);       // tile kt+1; tile kt+2 goes to buffer 0
+        }
+#undef WLK_MFMA
+#undef WLK_SB
     }
 
     // epilogue: acc[r] is C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31] of the wave tile.
