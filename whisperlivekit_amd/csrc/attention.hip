@@ -124,14 +124,25 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
             f32x16 s;
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[i] = 0.f;
+            // the 32 MFMAs are one dependent chain and the wave issues in order: the LDS fragments of group g+1 are
+            // requested right after the first MFMA of group g has been issued (same idea as gemm_f32.hip)
+            float4 k4 = *reinterpret_cast<const float4*>(Kw);
+            float4 q4 = *reinterpret_cast<const float4*>(Qw);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
-                const float4 k4 = *reinterpret_cast<const float4*>(Kw + g * 8);
-                const float4 q4 = *reinterpret_cast<const float4*>(Qw + g * 8);
                 s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, q4.x, s, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                float4 kn = k4, qn = q4;
+                if (g + 1 < 8) {
+                    kn = *reinterpret_cast<const float4*>(Kw + (g + 1) * 8);
+                    qn = *reinterpret_cast<const float4*>(Qw + (g + 1) * 8);
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, q4.y, s, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, q4.z, s, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, q4.w, s, 0, 0, 0);
+                k4 = kn;
+                q4 = qn;
             }
             // rows of s: key = key0 + (r&3) + 8*(r>>2) + 4*half ; column: query lq
             if (dump) {
@@ -163,13 +174,22 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
             m_run = m_new;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            // V values of key r+1 are requested before the two MFMAs of key r are issued (one LDS latency ahead)
+            float v0 = Vw[(4 * half) * 64], v1 = Vw[(4 * half) * 64 + 32];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int kk = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float v0 = Vw[kk * 64];
-                const float v1 = Vw[kk * 64 + 32];
+                float v0n = v0, v1n = v1;
+                if (r + 1 < 16) {
+                    const int kn = ((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * half;
+                    v0n = Vw[kn * 64];
+                    v1n = Vw[kn * 64 + 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[r], o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[r], o1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                v0 = v0n;
+                v1 = v1n;
             }
         }
     }
