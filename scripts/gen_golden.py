@@ -25,7 +25,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import ref_stubs  # noqa: E402
 
-ref_stubs.install(synthetic_vocab=True)
+# GOLDEN_REAL_VOCAB=1: the reference's Tokenizer runs over its own vendored gpt2.tiktoken ranks (a17 evidence)
+REAL_VOCAB = os.environ.get("GOLDEN_REAL_VOCAB") == "1"
+ref_stubs.install(synthetic_vocab=not REAL_VOCAB)
 
 from whisperlivekit.simul_whisper.backend import SimulStreamingOnlineProcessor  # noqa: E402
 from whisperlivekit.simul_whisper.config import AlignAttConfig  # noqa: E402
@@ -117,7 +119,8 @@ def gen_mel():
 def gen_model_numerics():
     """Encoder output, decoder logits and cross-attention QK from the reference modules for
     micro.en / tiny.en / base.en on a 3.2 s clip: prefill of 7 tokens, then 2 single-token steps."""
-    for name in ("micro.en", "tiny.en", "base.en"):
+    names = [n for n in os.environ.get("GOLDEN_NUMERICS", "micro.en,tiny.en,base.en").split(",") if n]
+    for name in names:      # GOLDEN_NUMERICS=large-v3 adds config 3 at full depth (minutes of CPU, ~13 GB of RAM)
         model = build_reference_model(name, seed=0)
         dims = MODEL_DIMS[name]
         a = synth.to_pcm16_roundtrip(synth.speech_like(3.2, 11))
@@ -297,6 +300,20 @@ def gen_cif():
     print("cif: fire in", sum(k["fire"] for k in kat), "of", len(kat), "cases")
 
 
+def slow_case(k):
+    """Long-running cases are regenerated only when named in GOLDEN_ONLY (they take minutes of CPU)."""
+    return k.startswith("bench_base_30s") or k.startswith("large_v3")
+
+
+def dump_stream(k, v):
+    import gzip
+    if slow_case(k) or v.get("vocab") == "real":
+        with gzip.open(os.path.join(OUT, f"stream_{k}.json.gz"), "wt") as fh:
+            json.dump(v, fh)
+    else:
+        json.dump(v, open(os.path.join(OUT, f"stream_{k}.json"), "w"))
+
+
 def gen_streams():
     only = set(os.environ.get("GOLDEN_ONLY", "").split(",")) - {""}    # regenerate a subset: GOLDEN_ONLY=a,b
     want = lambda k: not only or k in only
@@ -328,11 +345,35 @@ def gen_streams():
         "micro_minlen_beam3": lambda: run_stream("micro.en", a12[:112000], cfg_over=dict(audio_min_len=1.0, frame_threshold=10,
                                                                                            beam_size=3)),
     }
+    # the workload bench.py times (BASELINE.json configs[1] and the 8-stream half of the metric): base.en, 30 s
+    # speech-like streams seeds 0..7, 60 x 0.5 s chunks, engine defaults.  bench.py replays these on the timed
+    # sessions and reports parity_checked; tests replay them serially and from 8 threads at once.
+    for seed in range(8):
+        table[f"bench_base_30s_s{seed}"] = (
+            lambda seed=seed: run_stream("base.en", synth.to_pcm16_roundtrip(synth.speech_like(30.0, seed))))
+    # config 3 at FULL depth (32 + 32 layers, 1280 wide, 128 mels, multilingual vocabulary): 2 s in 4 calls
+    table["large_v3_2s"] = lambda: run_stream("large-v3", synth.to_pcm16_roundtrip(synth.speech_like(2.0, 5)))
+    if REAL_VOCAB:
+        # a17 with the REAL vocabulary: word splitting / pending UTF-8 / prompt encoding on real GPT-2 byte sequences.
+        #   GOLDEN_REAL_VOCAB=1 python scripts/gen_golden.py streams
+        def real(name, *a, **k):
+            v = run_stream(name, *a, **k)
+            v["vocab"] = "real"
+            return v
+        table = {
+            "micro_realvocab": lambda: real("micro.en", synth.to_pcm16_roundtrip(synth.speech_like(16.0, 6)), seed=3,
+                                            cfg_over=dict(static_init_prompt=" Hello, world.",
+                                                          init_prompt=" The quick brown fox", max_context_tokens=24)),
+            "micro_realvocab_beam2": lambda: real("micro.en", synth.to_pcm16_roundtrip(synth.speech_like(10.0, 7)), seed=5,
+                                                  cfg_over=dict(beam_size=2)),
+        }
     for k, make in table.items():
         if not want(k):
             continue
+        if slow_case(k) and not only:
+            continue
         v = make()
-        json.dump(v, open(os.path.join(OUT, f"stream_{k}.json"), "w"))
+        dump_stream(k, v)
         n_steps = sum(len(c["steps"]) for c in v["calls"])
         n_tok = sum(len(e["tokens"]) for e in v["events"])
         print(f"stream {k}: {len(v['calls'])} calls, {n_steps} decode steps, {n_tok} words")

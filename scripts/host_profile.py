@@ -1,5 +1,6 @@
 """Where does the HOST time of one stream go?  cProfile over bench.run_stream (base.en, 30 s, 0.5 s chunks), plus the
 split of each call's wall time into 'inside libwlk_hip.so' (ctypes calls) and 'Python'."""
+import os as _os; _os.environ.setdefault("WLK_SYNTHETIC_VOCAB", "1")
 import cProfile
 import io
 import pstats

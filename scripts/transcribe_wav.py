@@ -5,8 +5,8 @@
     python scripts/transcribe_wav.py audio.wav --model-path base.en.pt            # openai-whisper checkpoint
     python scripts/transcribe_wav.py audio.wav --synthetic base.en                # seeded random weights (smoke runs)
 
-Real text needs the reference's tiktoken rank files (WLK_VOCAB_DIR or an installed WhisperLiveKit); without them the
-synthetic vocabulary is used and only ids / timestamps are meaningful."""
+Real text needs the reference's tiktoken rank files (WLK_VOCAB_DIR or an installed WhisperLiveKit); without them a real
+checkpoint fails loudly.  --synthetic selects the stand-in vocabulary too (only ids / timestamps are meaningful)."""
 import argparse
 import sys
 import time
@@ -42,6 +42,8 @@ def main(argv=None):
 
     from whisperlivekit_amd.backend import HipSimulStreamingASR, HipSimulStreamingOnlineProcessor
     if args.synthetic:
+        import os
+        os.environ.setdefault("WLK_SYNTHETIC_VOCAB", "1")
         asr = HipSimulStreamingASR(args.synthetic, synthetic_seed=0, lan=args.lan, beams=args.beams,
                                    frame_threshold=args.frame_threshold)
     elif args.model_path:

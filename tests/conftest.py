@@ -9,6 +9,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# random-weight parity runs use the stand-in vocabulary (no rank file travels to the GPU box); it is opt-in
+os.environ.setdefault("WLK_SYNTHETIC_VOCAB", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")

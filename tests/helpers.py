@@ -20,8 +20,75 @@ def golden_npz(name):
 
 
 def golden_json(name):
-    with open(os.path.join(GOLDEN, name)) as fh:
+    path = os.path.join(GOLDEN, name)
+    if not os.path.exists(path) and os.path.exists(path + ".gz"):
+        path += ".gz"
+    if path.endswith(".gz"):
+        import gzip
+        with gzip.open(path, "rt") as fh:
+            return json.load(fh)
+    with open(path) as fh:
         return json.load(fh)
+
+
+def golden_exists(name):
+    path = os.path.join(GOLDEN, name)
+    return os.path.exists(path) or os.path.exists(path + ".gz")
+
+
+TIE_EPS = 2e-5   # a reference decision whose winning margin is below this is a tie in fp32
+
+
+def compare_decisions(g, decision_log, emitted=None):
+    """Non-asserting form of test_oracle_golden.check_stream_against_golden for bench.py and the concurrency test:
+    ``decision_log`` is HipAlignAttHooks.decision_log ([content_mel_len, [(token, frame), ...]] per infer), ``emitted``
+    the per-chunk word lists [(start, end, text), ...].  Every decode decision (token id of beam 0, attended frame) is
+    compared with the reference's; a mismatch where the reference's own winning margin is below TIE_EPS is reported as
+    a tie divergence (comparison stops there, as the stream legitimately takes another path), anything else as a
+    mismatch.  -> dict(decisions, identical, calls, tie_divergence, mismatch, words_identical)."""
+    out = dict(decisions=0, identical=0, calls=0, tie_divergence=None, mismatch=None, words_identical=None)
+    stop = False
+    for ci, ref in enumerate(g["calls"]):
+        if ci >= len(decision_log):
+            out["mismatch"] = out["mismatch"] or [ci, 0, "missing call"]
+            break
+        cml, steps = decision_log[ci]
+        if cml != ref["content_mel_len"]:
+            out["mismatch"] = [ci, 0, "content_mel_len"]
+            break
+        ref_steps = [rs for rs in ref["steps"] if rs.get("token") is not None]
+        for si, rs in enumerate(ref_steps):
+            out["decisions"] += 1
+            if si >= len(steps):
+                out["mismatch"] = [ci, si, "missing step"]
+                stop = True
+                break
+            tok, frame = steps[si]
+            if tok != rs["token"]:
+                margin = rs["lp_top_vals"][0] - rs["lp_top_vals"][1]
+                out["tie_divergence" if margin < TIE_EPS else "mismatch"] = [ci, si, "token", margin]
+                stop = True
+                break
+            if frame != rs["frame"]:
+                vals = rs["attn_top_vals"]
+                margin = vals[0] - vals[1] if len(vals) > 1 else 1.0
+                out["tie_divergence" if margin < TIE_EPS else "mismatch"] = [ci, si, "frame", margin]
+                stop = True
+                break
+            out["identical"] += 1
+        if stop:
+            break
+        if len(steps) != len(ref_steps):
+            out["mismatch"] = [ci, len(ref_steps), "extra steps"]
+            break
+        out["calls"] += 1
+    if out["mismatch"] is None and out["tie_divergence"] is None and len(decision_log) != len(g["calls"]):
+        out["mismatch"] = [len(g["calls"]), 0, "extra calls"]
+    if emitted is not None and out["mismatch"] is None and out["tie_divergence"] is None:
+        want = [[(round(s, 2), round(e, 2), x) for s, e, x, _sp in ev["tokens"]] for ev in g["events"] if ev["kind"] == "chunk"]
+        got = [[(round(s, 2), round(e, 2), x) for s, e, x in words] for words in emitted]
+        out["words_identical"] = bool(want == got)
+    return out
 
 
 def mel_case_audio(meta):
@@ -68,7 +135,12 @@ def stream_audio(case_name):
         "micro_prompt": lambda: a12(),
         "micro_minlen_beam3": lambda: a12()[:112000],
         "micromulti_auto": lambda: a12()[:128000],
+        "large_v3_2s": lambda: synth.to_pcm16_roundtrip(synth.speech_like(2.0, 5)),
+        "micro_realvocab": lambda: synth.to_pcm16_roundtrip(synth.speech_like(16.0, 6)),
+        "micro_realvocab_beam2": lambda: synth.to_pcm16_roundtrip(synth.speech_like(10.0, 7)),
     }
+    if case_name.startswith("bench_base_30s_s"):
+        return synth.to_pcm16_roundtrip(synth.speech_like(30.0, int(case_name.rsplit("_s", 1)[1])))
     return table[case_name]()
 
 
@@ -100,3 +172,19 @@ def make_oracle_session(model_name, cfg_over=None, seed=0):
                                          language=lang if dims.is_multilingual else None, synthetic=True)
     return wo.OracleAlignAtt(oracle_sd(model_name, seed), dims, ALIGNMENT_HEADS[model_name], factory("en"),
                              mel_filterbank(dims.n_mels), cfg, tokenizer_factory=factory)
+
+
+def real_vocab_dir(tmp_dir):
+    """Materialise tests/golden/vocab_gpt2.npz / vocab_multilingual.npz (scripts/gen_golden_vocab.py,
+    scripts/gen_golden_tokenizer.py) as ``gpt2.tiktoken`` / ``multilingual.tiktoken`` under ``tmp_dir`` in
+    the rank-file format the product loads (WLK_VOCAB_DIR); returns the directory."""
+    import base64
+    for name in ("gpt2", "multilingual"):
+        z = np.load(os.path.join(GOLDEN, f"vocab_{name}.npz"))
+        lengths, blob = z["lengths"].astype(np.int64), z["blob"].tobytes()
+        ends = np.cumsum(lengths)
+        with open(os.path.join(str(tmp_dir), f"{name}.tiktoken"), "wb") as fh:
+            for rank, (e, n) in enumerate(zip(ends, lengths)):
+                # the multilingual table ends with an EMPTY token spelled "=" in the rank file (rank 50256)
+                fh.write((base64.b64encode(blob[e - n:e]) or b"=") + b" " + str(rank).encode() + b"\n")
+    return str(tmp_dir)

@@ -1,0 +1,202 @@
+"""GPU tests of the serving shape of the path (run with -m gpu on an MI355X):
+
+* concurrency: 8 host threads, 8 sessions, ONE model - the reference's threading contract
+  (whisperlivekit/audio_processor.py:543-551 runs process_iter on asyncio.to_thread workers concurrently across
+  sessions with no model lock; simul_whisper/simul_whisper.py:109-114 "the model can be shared");
+* the multi-GPU weight path: sharding.replicated_model (torch CUDA arena adopted by wlk_model_create) at world size 1
+  and, when two devices are visible, over a real 2-rank RCCL broadcast;
+* bench.py end to end: it must check its own outputs against the reference's golden streams, and `--gpus N` must
+  refuse to run on fewer than N devices.
+"""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import helpers as H
+from whisperlivekit_amd import _lib, synth
+from whisperlivekit_amd.dims import ALIGNMENT_HEADS, MODEL_DIMS
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHUNK = 8000
+
+
+def _run_stream(proc, audio, chunk=CHUNK):
+    words = []
+    t_end = 0.0
+    for lo in range(0, len(audio), chunk):
+        t_end += len(audio[lo:lo + chunk]) / 16000
+        proc.insert_audio_chunk(audio[lo:lo + chunk].copy(), t_end)
+        toks, _ = proc.process_iter()
+        words.append([(float(t.start), float(t.end), t.text) for t in toks])
+    return words
+
+
+def _new_proc(asr):
+    from whisperlivekit_amd.backend import HipSimulStreamingOnlineProcessor
+    p = HipSimulStreamingOnlineProcessor(asr)
+    p.model.decision_log = []
+    return p
+
+
+@pytest.mark.parametrize("model_name,cases", [
+    ("base.en", [f"bench_base_30s_s{i}" for i in range(8)]),
+    ("micro.en", ["micro_12s", "micro_34s_evict", "micro_neverfire", "micro_12s", "micro_34s_evict", "micro_neverfire",
+                  "micro_12s", "micro_12s"]),
+])
+def test_eight_threads_share_one_model(model_name, cases):
+    """8 threads replay 8 golden streams simultaneously on ONE HipWhisperModel: every session's decisions equal the
+    reference's, and equal (bit for bit: token ids, frames, emitted words) what the same session yields when run alone."""
+    from whisperlivekit_amd.backend import HipSimulStreamingASR
+    from whisperlivekit_amd.engine import HipWhisperModel
+    for c in cases:
+        if not H.golden_exists(f"stream_{c}.json"):
+            pytest.skip(f"golden stream {c} not generated")
+    goldens = [H.golden_json(f"stream_{c}.json") for c in cases]
+    audios = [H.stream_audio(c) for c in cases]
+    chunks = [g["chunk"] for g in goldens]
+    cfgs = [H.asr_kwargs(g["cfg"]) for g in goldens]
+    model = HipWhisperModel.synthetic(model_name, 0)
+    asrs = [HipSimulStreamingASR(model_name, hip_model=model, **kw) for kw in cfgs]
+
+    serial = []
+    for asr, a, ch in zip(asrs, audios, chunks):
+        p = _new_proc(asr)
+        w = _run_stream(p, a, ch)
+        serial.append((p.model.decision_log, w))
+        p.close()
+
+    for round_ in range(2):                 # second round: sessions created while others are mid-stream
+        procs = [_new_proc(asr) for asr in asrs]
+        start = threading.Barrier(len(procs))
+        out = [None] * len(procs)
+        errs = []
+
+        def work(i):
+            try:
+                start.wait()
+                out[i] = _run_stream(procs[i], audios[i], chunks[i])
+            except Exception as e:          # pragma: no cover - reported below
+                errs.append((i, repr(e)))
+
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(procs))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errs, errs
+        for i, p in enumerate(procs):
+            assert getattr(p, "last_error", None) is None, (i, p.last_error)
+            assert p.model.decision_log == serial[i][0], f"session {i}: concurrent decisions differ from the serial run"
+            assert out[i] == serial[i][1], f"session {i}: concurrent words differ from the serial run"
+            r = H.compare_decisions(goldens[i], p.model.decision_log, out[i])
+            assert r["mismatch"] is None, (cases[i], r)
+            if r["tie_divergence"] is None:
+                assert r["identical"] == r["decisions"] and r["words_identical"], (cases[i], r)
+            p.close()
+    model.close()
+
+
+def test_replicated_model_world1_equals_uploaded_model():
+    """sharding.replicated_model: the arena is a torch CUDA tensor (what RCCL broadcasts) adopted by
+    wlk_model_create(arena_dev); logits / encoder output must equal the model that uploaded tensor by tensor."""
+    import torch
+    from whisperlivekit_amd import sharding
+    from whisperlivekit_amd.engine import HipWhisperModel, pack_state_dict
+    name = "tiny.en"
+    dims = MODEL_DIMS[name]
+    sd = synth.synth_state_dict(dims, 0)
+    timing = {}
+    a = sharding.replicated_model(dims, pack_state_dict(dims, sd), ALIGNMENT_HEADS[name], device=0, timing=timing)
+    b = HipWhisperModel.from_state_dict(dims, sd, ALIGNMENT_HEADS[name], device=0)
+    assert timing["arena_bytes"] > 0 and a._arena_keepalive.is_cuda
+    audio = synth.to_pcm16_roundtrip(synth.speech_like(3.0, 3))
+    outs = []
+    for m in (a, b):
+        s = m.new_session()
+        s.append(audio)
+        cml = s.encode()
+        s.decode(np.array([[50257, 50362, 1000, 2000]]), first=True, sot_index=0)
+        lp, ids, fr = s.select([], [], [], 2, cml)
+        outs.append((cml, s.export("enc").copy(), s.export("logits_last").copy(), lp.copy(), ids.copy(), fr.copy()))
+        s.close()
+    for x, y in zip(outs[0], outs[1]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    a.close(); b.close()
+    torch.cuda.synchronize()
+
+
+_RCCL_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from whisperlivekit_amd import sharding, synth
+from whisperlivekit_amd.dims import ALIGNMENT_HEADS, MODEL_DIMS
+from whisperlivekit_amd.engine import pack_state_dict
+rank, world, local = sharding.init_process_group("nccl")
+name = "tiny.en"
+dims = MODEL_DIMS[name]
+packed = pack_state_dict(dims, synth.synth_state_dict(dims, 0)) if rank == 0 else None
+timing = {}
+model = sharding.replicated_model(dims, packed, ALIGNMENT_HEADS[name], device=local, timing=timing)
+s = model.new_session()
+s.append(synth.to_pcm16_roundtrip(synth.speech_like(2.0, 1)))
+cml = s.encode()
+s.decode(np.array([[50257, 50362, 1000]]), first=True, sot_index=0)
+logits = torch.from_numpy(s.export("logits_last").copy()).to(f"cuda:{local}")
+gathered = [torch.empty_like(logits) for _ in range(world)]
+dist.all_gather(gathered, logits)
+same = all(bool(torch.equal(gathered[0], g)) for g in gathered)
+if rank == 0:
+    print("RCCL_OK" if same else "RCCL_DIFF", timing)
+s.close(); model.close()
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if same else 3)
+"""
+
+
+def test_two_rank_rccl_broadcast_gives_identical_replicas(tmp_path):
+    if _lib.device_count() < 2:
+        pytest.skip("needs 2 visible GPUs (the driver's multi-GPU node)")
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER)
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bench_checks_its_own_outputs_against_the_reference():
+    """bench.py replays the reference's golden decisions on the sessions it times (1-stream headline + the 8-stream
+    leg) and prints parity_checked; nothing it reports may come from unverified outputs."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-diarization"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    pc = line["parity_checked"]
+    assert pc is not None and pc["sessions"] == 9 and not pc["missing_golden"], pc
+    assert pc["mismatches"] == [], pc
+    assert pc["decisions"] > 2000
+    if not pc["tie_divergences"]:
+        assert pc["identical"] == pc["decisions"] and pc["words_identical_sessions"] == pc["sessions"], pc
+    assert line["n_gpus"] == 1 and line["eight_streams"]["streams"] == 8
+    assert line["eight_streams"]["swallowed_errors"] == 0 and line["swallowed_errors"] == 0
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "bench_from_test.json"), "w") as fh:
+        json.dump(line, fh)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    n = _lib.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)

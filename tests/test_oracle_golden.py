@@ -58,10 +58,14 @@ STREAMS = ["micro_12s", "micro_34s_evict", "micro_beam2", "micro_neverfire", "mi
            "micro_prompt", "micro_minlen_beam3"]  # a9/a10 corners: prompt context budget; min segment length, beam 3
 
 
-def replay_stream(case, make_processor):
+def replay_stream(case, make_processor, max_events=None):
     """Drive a processor exactly as scripts/gen_golden.py:run_stream drove the reference; returns
-    the list of (event, tokens, upto)."""
+    the list of (event, tokens, upto).  ``max_events`` replays only a prefix (calls and events are truncated alike)."""
     g = H.golden_json(f"stream_{case}.json")
+    if max_events is not None:
+        g["events"] = g["events"][:max_events]
+        n_calls = sum(1 for ev in g["events"] if ev.get("call") is not None)
+        g["calls"] = g["calls"][:n_calls]
     audio = H.stream_audio(case)
     proc = make_processor(g["model"], g["cfg"], g.get("seed", 0))
     t_end = 0.0
@@ -84,7 +88,7 @@ def replay_stream(case, make_processor):
     return g, proc, got
 
 
-TIE_EPS = 2e-5   # a reference decision whose winning margin is below this is a tie in fp32
+TIE_EPS = H.TIE_EPS
 
 
 def check_stream_against_golden(g, trace, got, tol=1e-4, allow_ties=False):
@@ -143,6 +147,16 @@ def test_oracle_stream_matches_reference(case):
             last = ev
     assert proc.model.context_text == last["context"]
     assert proc.model.last_attend_frame == last["last_attend_frame"]
+
+
+def test_oracle_matches_reference_on_the_benchmarked_stream_prefix():
+    """The workload bench.py times (base.en, 30 s, seed 0): the first 10 calls on the CPU oracle (the GPU suite and
+    bench.py itself compare all 60 calls x 8 seeds)."""
+    def mk(model, cfg, seed=0):
+        return wo.OracleOnlineProcessor(H.make_oracle_session(model, cfg, seed))
+    g, proc, got = replay_stream("bench_base_30s_s0", mk, max_events=10)
+    check_stream_against_golden(g, proc.model.trace, got)
+    assert sum(len(c["steps"]) for c in g["calls"]) >= 20
 
 
 # ---- a11: CIF end-of-word head, pinned by the reference's own fire_at_boundary (tests/golden/cif_kat.json) ----

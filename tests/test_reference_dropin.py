@@ -21,7 +21,7 @@ from test_oracle_golden import check_stream_against_golden, replay_stream  # noq
 from whisperlivekit_amd.dims import ALIGNMENT_HEADS, MODEL_DIMS  # noqa: E402
 
 
-def _make(model_name, cfg_over, seed=0):
+def _make(model_name, cfg_over, seed=0, model_factory=None):
     ref_stubs.install(synthetic_vocab=True)
     from whisperlivekit.simul_whisper.config import AlignAttConfig
     from whisperlivekit.timed_objects import ChangeSpeaker
@@ -36,7 +36,10 @@ def _make(model_name, cfg_over, seed=0):
     cfg = AlignAttConfig(**kw)
     if nonspeech is not None:
         cfg.nonspeech_prob = nonspeech
-    fake = FakeHipModel(MODEL_DIMS[model_name], H.oracle_sd(model_name, seed), ALIGNMENT_HEADS[model_name])
+    if model_factory is not None:         # tests/test_gpu_reference_dropin.py: a real HipWhisperModel
+        fake = model_factory(model_name, seed)
+    else:
+        fake = FakeHipModel(MODEL_DIMS[model_name], H.oracle_sd(model_name, seed), ALIGNMENT_HEADS[model_name])
     asr = types.SimpleNamespace(cfg=cfg, hip_model=fake, shared_model=fake, use_full_mlx=False, mlx_encoder=None,
                                 fw_encoder=None, tokenizer=None)
     proc = reference_online_processor_class()(asr)

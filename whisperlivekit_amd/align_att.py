@@ -35,15 +35,18 @@ TOKENS_PER_SECOND = 50
 class _Segment:
     """One inserted audio chunk as the policy sees it: something with ``.shape[0]`` samples.
     A host copy is kept so the device buffer can be rebuilt after a policy-side list edit
-    (refresh_segment slices ``state.segments`` directly, align_att_base.py:122-126)."""
+    (refresh_segment slices ``state.segments`` directly, align_att_base.py:122-126); a run of zeros
+    (a short silence, backend.py:86-90) keeps only its length."""
     __slots__ = ("data", "shape", "uid")
     _next = 0
+    _lock = __import__("threading").Lock()
 
-    def __init__(self, data: np.ndarray):
+    def __init__(self, data: Optional[np.ndarray], n_zeros: int = 0):
         self.data = data
-        self.shape = (int(data.shape[0]),)
-        self.uid = _Segment._next
-        _Segment._next += 1
+        self.shape = (int(data.shape[0]) if data is not None else int(n_zeros),)
+        with _Segment._lock:                 # sessions are created / fed from different threads
+            self.uid = _Segment._next
+            _Segment._next += 1
 
 
 class EncoderFeature:
@@ -143,6 +146,9 @@ class HipAlignAttHooks:
         self._content_mel_len = 0
         self._last_frames: Optional[np.ndarray] = None
         self.counters = {"encode": 0, "decode": 0, "prefill_tokens": 0}
+        # optional decision trace (bench.py / tests switch it on by assigning a list): one entry per infer,
+        # [content_mel_len, [(token of beam 0, attended frame of beam 0), ...]] - what a golden stream pins
+        self.decision_log: Optional[List[list]] = None
         self.state = P.StreamState()
         self.state.on_clean_cache = self._on_clean_cache
         self._init_state(cfg)
@@ -211,8 +217,10 @@ class HipAlignAttHooks:
             return np.ascontiguousarray(segment.reshape(-1))
         return np.ascontiguousarray(np.asarray(segment, dtype=np.float32).reshape(-1))
 
-    def _upload(self, data: np.ndarray) -> None:
-        if data.dtype == np.int16:
+    def _upload(self, data: Optional[np.ndarray], n_zeros: int = 0) -> None:
+        if data is None:
+            self.session.append_zeros(n_zeros)
+        elif data.dtype == np.int16:
             self.session.append_pcm16(data)
         else:
             self.session.append(data)
@@ -222,10 +230,10 @@ class HipAlignAttHooks:
         bookkeeping and moves the evicted chunk's tokens into the text context."""
         st = self.state
         if segment is not None:
-            seg = _Segment(self._to_numpy(segment))
+            seg = segment if isinstance(segment, _Segment) else _Segment(self._to_numpy(segment))
             self._sync_device_audio()
             st.segments.append(seg)
-            self._upload(seg.data)
+            self._upload(seg.data, seg.shape[0])
             self._dev_segments.append((seg.uid, seg.shape[0]))
         removed_len = 0
         total = self.segments_len()
@@ -241,6 +249,10 @@ class HipAlignAttHooks:
         self._sync_device_audio()
         return removed_len
 
+    def insert_silence(self, n_samples: int):
+        """``insert_audio(torch.zeros(n))`` of the reference's end_silence (backend.py:86-90) without the upload."""
+        return self.insert_audio(_Segment(None, int(n_samples)))
+
     def _sync_device_audio(self):
         """Make the session's audio buffer equal to ``state.segments`` (which the policy may have
         sliced or emptied behind our back, align_att_base.py:122-126)."""
@@ -254,7 +266,7 @@ class HipAlignAttHooks:
         else:                                               # anything else: rebuild from the host copies
             self.session.clear_audio()
             for seg in self.state.segments:
-                self._upload(seg.data)
+                self._upload(seg.data, seg.shape[0])
         self._dev_segments = want
 
     def _concat_segments(self):
@@ -269,6 +281,8 @@ class HipAlignAttHooks:
         self._content_mel_len = self.session.encode()
         self.counters["encode"] += 1
         self._fresh_infer = True
+        if self.decision_log is not None:
+            self.decision_log.append([self._content_mel_len, []])
         return EncoderFeature(self.session), self._content_mel_len
 
     def fire_at_boundary(self, feature):
@@ -348,6 +362,8 @@ class HipAlignAttHooks:
         self._last_frames = frames
         self.last_top = (lp, top)
         tokens, completed, sources = self._updater.update(np.asarray(current_tokens), lp, top, sum_logprobs)
+        if self.decision_log is not None:
+            self.decision_log[-1][1].append((int(tokens[0, -1]), int(frames[0])))
         if sources != list(range(len(sources))):
             self.session.kv_reorder(sources)
         return tokens, completed

@@ -181,7 +181,11 @@ class HipSimulStreamingOnlineProcessor:
         if silence_duration < MIN_DURATION_REAL_SILENCE:
             gap = int(16000 * silence_duration)
             if gap > 0:
-                self.model.insert_audio(np.zeros(gap, dtype=np.float32))
+                on_device = getattr(self.model, "insert_silence", None)
+                if on_device is not None:
+                    on_device(gap)                  # zeros are written on the device; nothing crosses PCIe
+                else:
+                    self.model.insert_audio(np.zeros(gap, dtype=np.float32))
             return
         self.model.refresh_segment(complete=True)
         self.model.global_time_offset = silence_duration + offset

@@ -376,6 +376,9 @@ int wlk_model_arena(wlk_model* m, float** arena_dev, uint64_t* n_floats) {
 
 int wlk_model_upload(wlk_model* m, const char* packed_name, const float* host, uint64_t numel) {
     if (!m || !packed_name || !host) return fail(WLK_ERR_ARG, "NULL argument");
+    // a finalized model is immutable: sessions size their alignment window from it, finalize copied the
+    // cross-attention k|v weights, and captured step graphs bake the per-layer head counts in
+    if (m->finalized) return fail(WLK_ERR_STATE, "model is finalized (immutable): upload weights before wlk_model_finalize");
     return guarded([&]() {
         auto it = m->by_name.find(packed_name);
         if (it == m->by_name.end()) return fail(WLK_ERR_ARG, std::string("unknown tensor ") + packed_name);
@@ -390,6 +393,8 @@ int wlk_model_upload(wlk_model* m, const char* packed_name, const float* host, u
 
 int wlk_model_set_alignment_heads(wlk_model* m, const int32_t* pairs, int n_pairs) {
     if (!m || (n_pairs > 0 && !pairs) || n_pairs < 0) return fail(WLK_ERR_ARG, "bad alignment head list");
+    if (m->finalized)
+        return fail(WLK_ERR_STATE, "model is finalized (immutable): set alignment heads before wlk_model_finalize");
     return guarded([&]() {
         const int L = m->D.n_text_layer, H = m->D.n_text_head;
         std::vector<int> rank((size_t)L * H, -1);
@@ -1015,7 +1020,11 @@ int wlk_select(wlk_session* s, const int32_t* adj_row, const int32_t* adj_ids, c
     if (n_adj < 0 || n_adj > wlk_session::kAdjCap) return fail(WLK_ERR_ARG, "too many logit adjustments");
     if (n_adj > 0 && (!adj_row || !adj_ids || !adj_deltas)) return fail(WLK_ERR_ARG, "NULL adjustment arrays");
     if (k < 1 || k > 8) return fail(WLK_ERR_ARG, "k must be in [1, 8]");
-    if (content_mel_len < 0 || content_mel_len > s->m->D.n_audio_ctx) return fail(WLK_ERR_ARG, "content_mel_len out of range");
+    if (content_mel_len < 0) return fail(WLK_ERR_ARG, "content_mel_len out of range");
+    // a buffer longer than 30 s yields content_mel_len > 1500; the reference only clips the attention slice
+    // (attn[..., :content_mel_len] over 1500 columns, simul_whisper.py:432) and keeps decoding, the host keeps the
+    // unclipped value for its frame-threshold test
+    if (content_mel_len > s->m->D.n_audio_ctx) content_mel_len = s->m->D.n_audio_ctx;
     return guarded([&]() {
         wlk_model* m = s->m;
         const wlk_dims& D = m->D;
@@ -1183,6 +1192,7 @@ struct wlk_melspec {
     double* twiddle = nullptr;
     int *lo = nullptr, *hi = nullptr;
     hipStream_t stream = nullptr;
+    std::mutex mu;   // one device audio/out buffer and one stream: runs from different host threads are serialised
 };
 
 int wlk_melspec_create(int device, int n_fft, int win_length, int hop, int n_mels, const float* filters,
@@ -1229,6 +1239,7 @@ int wlk_melspec_run(wlk_melspec* m, const float* pcm_host, int n, float* out_hos
     if (!m || !pcm_host || !out_host || !n_frames) return fail(WLK_ERR_ARG, "NULL argument");
     if (n < 1 || n > m->cap) return fail(WLK_ERR_CAPACITY, "chunk does not fit the extractor's buffer");
     return guarded([&]() {
+        std::lock_guard<std::mutex> lock(m->mu);
         WLK_HIP(hipSetDevice(m->device));
         // FilterbankFeatures.get_seq_len with centre padding: floor((n + 2*(n_fft/2) - n_fft) / hop) + 1
         const int frames = n / m->hop + 1;

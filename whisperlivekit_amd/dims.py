@@ -66,10 +66,14 @@ MODEL_DIMS: Dict[str, ModelDims] = {
     "small": _d(80, 768, 12, 12, 51865, 768, 12, 12),
     "medium.en": _d(80, 1024, 16, 24, 51864, 1024, 16, 24),
     "medium": _d(80, 1024, 16, 24, 51865, 1024, 16, 24),
+    "large-v1": _d(80, 1280, 20, 32, 51865, 1280, 20, 32),
     "large-v2": _d(80, 1280, 20, 32, 51865, 1280, 20, 32),
     "large-v3": _d(128, 1280, 20, 32, 51866, 1280, 20, 32),
     "large-v3-turbo": _d(128, 1280, 20, 32, 51866, 1280, 20, 4),
 }
+# the reference's aliases (whisper/__init__.py:20-35: "large" and "turbo" point at the v3 checkpoints)
+MODEL_DIMS["large"] = MODEL_DIMS["large-v3"]
+MODEL_DIMS["turbo"] = MODEL_DIMS["large-v3-turbo"]
 
 ALIGNMENT_HEADS: Dict[str, List[Tuple[int, int]]] = {
     "micro.en": [(1, 0), (1, 1)],
@@ -85,6 +89,7 @@ ALIGNMENT_HEADS: Dict[str, List[Tuple[int, int]]] = {
                   (17, 12), (17, 14), (18, 7), (18, 10), (18, 15), (20, 0), (20, 3), (20, 9),
                   (20, 14), (21, 12)],
     "medium": [(13, 15), (15, 4), (15, 15), (16, 1), (20, 0), (23, 4)],
+    "large-v1": [(9, 19), (11, 2), (11, 4), (11, 17), (22, 7), (22, 11), (22, 17), (23, 2), (23, 15)],
     "large-v2": [(10, 12), (13, 17), (16, 11), (16, 12), (16, 13), (17, 15), (17, 16), (18, 4),
                  (18, 11), (18, 19), (19, 11), (21, 2), (21, 3), (22, 3), (22, 9), (22, 12),
                  (23, 5), (23, 7), (23, 13), (25, 5), (26, 1), (26, 12), (27, 15)],
@@ -92,6 +97,8 @@ ALIGNMENT_HEADS: Dict[str, List[Tuple[int, int]]] = {
                  (24, 1), (25, 6)],
     "large-v3-turbo": [(2, 4), (2, 11), (3, 3), (3, 6), (3, 11), (3, 14)],
 }
+ALIGNMENT_HEADS["large"] = ALIGNMENT_HEADS["large-v3"]
+ALIGNMENT_HEADS["turbo"] = ALIGNMENT_HEADS["large-v3-turbo"]
 
 
 def default_alignment_heads(dims: ModelDims) -> List[Tuple[int, int]]:

@@ -550,7 +550,9 @@ def cif_fire_at_boundary(features: np.ndarray, weight: np.ndarray, bias: float) 
                 a = a * 0.5 + (0.5 * a.sum() / mask.sum()) * mask
     integ = torch.cumsum(a[:-1], dim=0)
     if integ.numel() == 0:
-        return False
+        # a 1-frame feature: the reference indexes integrate[-1] of an empty tensor and raises
+        # (eow_detection.py:70-71); process_iter turns that into an empty result for the call
+        raise IndexError("index -1 is out of bounds for dimension 0 with size 0")
     integ = integ - (integ[-1] // 0.999) * 1.0
     pos = torch.nonzero(integ >= 0).flatten()
     return bool(pos.numel() and int(pos[0]) >= t - 2)

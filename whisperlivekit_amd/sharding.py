@@ -70,9 +70,12 @@ def broadcast_arena(arena, src: int = 0):
 
 
 def replicated_model(dims: ModelDims, packed: Optional[Mapping[str, np.ndarray]],
-                     alignment_heads: Sequence[Tuple[int, int]], device: int, src: int = 0) -> HipWhisperModel:
+                     alignment_heads: Sequence[Tuple[int, int]], device: int, src: int = 0,
+                     timing: Optional[dict] = None) -> HipWhisperModel:
     """Every rank gets a full weight replica: rank ``src`` packs the arena on the host, all ranks
-    allocate it as a torch CUDA tensor, one RCCL broadcast fills it, the library adopts the pointer."""
+    allocate it as a torch CUDA tensor, one RCCL broadcast fills it, the library adopts the pointer.
+    ``timing`` (optional dict) receives ``broadcast_ms``: wall time of the collective on this rank."""
+    import time
     import torch
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -83,8 +86,13 @@ def replicated_model(dims: ModelDims, packed: Optional[Mapping[str, np.ndarray]]
         arena = torch.from_numpy(pack_arena_host(dims, packed)).to(f"cuda:{device}")
     else:
         arena = torch.empty(n, dtype=torch.float32, device=f"cuda:{device}")
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
     broadcast_arena(arena, src)
     torch.cuda.synchronize(device)
+    if timing is not None:
+        timing["broadcast_ms"] = round(1e3 * (time.perf_counter() - t0), 3)
+        timing["arena_bytes"] = int(n) * 4
     model = HipWhisperModel(dims, device, arena=arena)
     model.set_alignment_heads(alignment_heads)
     model.finalize()

@@ -11,7 +11,9 @@ Mirrors the surface the hot path consumes from the reference's ``Tokenizer``
 * :class:`SyntheticEncoding` - a deterministic stand-in vocabulary of the same size
   (256 byte tokens + generated word pieces).  Random-weight parity runs and the benchmark
   use it on machines that have no vocabulary file; token ids - the thing parity is judged
-  on - do not depend on which byte strings the ids map to.
+  on - do not depend on which byte strings the ids map to.  It is strictly OPT-IN
+  (``synthetic=True`` or ``WLK_SYNTHETIC_VOCAB=1``): a deployment with a real checkpoint and
+  no rank file must fail loudly instead of decoding ids to made-up word pieces.
 
 Special-token numbering follows whisperlivekit/whisper/tokenizer.py:335-368.
 """
@@ -86,6 +88,15 @@ class Encoding:
     def encode(self, text: str, **_kw) -> List[int]:  # pragma: no cover - abstract
         raise NotImplementedError
 
+    def _refuse_special_text(self, text: str) -> None:
+        """tiktoken's ``encode`` default (disallowed_special="all") raises when the text spells a special token;
+        the reference relies on that default everywhere on this path (whisper/tokenizer.py:161-162)."""
+        if "<|" in text:
+            import re
+            for m in re.finditer(r"<\|[^|<>]*\|>", text):
+                if m.group(0) in self.special_tokens:
+                    raise ValueError(f"Encountered text corresponding to disallowed special token {m.group(0)!r}.")
+
 
 class BpeEncoding(Encoding):
     """Rank-ordered byte-pair merges over GPT-2 style pre-split pieces."""
@@ -115,6 +126,7 @@ class BpeEncoding(Encoding):
         return [self._ranks[p] for p in parts]
 
     def encode(self, text: str, **_kw) -> List[int]:
+        self._refuse_special_text(text)
         out: List[int] = []
         for piece in self._pat.findall(text):
             out.extend(self._bpe(piece.encode("utf-8")))
@@ -152,6 +164,7 @@ class SyntheticEncoding(Encoding):
         self._max_len = max(len(b) for b in toks)
 
     def encode(self, text: str, **_kw) -> List[int]:
+        self._refuse_special_text(text)
         data = text.encode("utf-8")
         out: List[int] = []
         pos = 0
@@ -198,18 +211,29 @@ def find_vocab_file(name: str, vocab_path: Optional[str] = None) -> Optional[str
     return None
 
 
+def synthetic_vocab_requested() -> bool:
+    return os.environ.get("WLK_SYNTHETIC_VOCAB", "") not in ("", "0")
+
+
 @lru_cache(maxsize=None)
 def get_encoding(name: str = "gpt2", num_languages: int = 99, vocab_path: Optional[str] = None,
                  synthetic: Optional[bool] = None) -> Encoding:
-    """``name`` is "gpt2" (.en models, 50256 base tokens) or "multilingual" (50257)."""
+    """``name`` is "gpt2" (.en models, 50256 base tokens) or "multilingual" (50257).
+
+    ``synthetic=None`` (the default) means: the stand-in vocabulary only if ``WLK_SYNTHETIC_VOCAB=1`` is set
+    (tests, bench.py, the GPU box), otherwise the real rank file - and FileNotFoundError if there is none."""
     specials = special_token_names(num_languages)
-    path = None if synthetic else find_vocab_file(name, vocab_path)
-    if path is not None:
-        return BpeEncoding(load_tiktoken_ranks(path), specials, name=os.path.basename(path))
-    if synthetic is False:
-        raise FileNotFoundError(f"no {name}.tiktoken rank file found (set WLK_VOCAB_DIR)")
-    n_base = 50256 if name == "gpt2" else 50257
-    return SyntheticEncoding(n_base, specials, name=f"synthetic-{name}")
+    if synthetic is None:
+        synthetic = synthetic_vocab_requested()
+    if synthetic:
+        n_base = 50256 if name == "gpt2" else 50257
+        return SyntheticEncoding(n_base, specials, name=f"synthetic-{name}")
+    path = find_vocab_file(name, vocab_path)
+    if path is None:
+        raise FileNotFoundError(
+            f"no {name}.tiktoken rank file found: pass vocab_path, set WLK_VOCAB_DIR, or install WhisperLiveKit "
+            "(whisper/assets); WLK_SYNTHETIC_VOCAB=1 selects the stand-in vocabulary of random-weight test runs")
+    return BpeEncoding(load_tiktoken_ranks(path), specials, name=os.path.basename(path))
 
 
 class WhisperTokenizer:
@@ -295,11 +319,20 @@ class WhisperTokenizer:
         return words, groups
 
 
-@lru_cache(maxsize=None)
 def get_tokenizer(multilingual: bool, *, num_languages: int = 99, language: Optional[str] = None,
                   task: Optional[str] = None, vocab_path: Optional[str] = None,
                   synthetic: Optional[bool] = None) -> WhisperTokenizer:
     """Same defaulting as the reference's ``get_tokenizer`` (whisper/tokenizer.py:371-400)."""
+    if synthetic is None:
+        synthetic = synthetic_vocab_requested()
+    if vocab_path is None and not synthetic:
+        vocab_path = os.environ.get("WLK_VOCAB_DIR") or None     # part of the cache key: tests switch directories
+    return _get_tokenizer(multilingual, num_languages, language, task, vocab_path, bool(synthetic))
+
+
+@lru_cache(maxsize=None)
+def _get_tokenizer(multilingual: bool, num_languages: int, language: Optional[str], task: Optional[str],
+                   vocab_path: Optional[str], synthetic: bool) -> WhisperTokenizer:
     if language is not None:
         language = language.lower()
         if language not in LANGUAGE_CODES:
