@@ -21,6 +21,9 @@ def main(db, out, title):
     for name, calls, tot, avg, pct in rows:
         lines.append(f"| `{name[:90]}` | {calls} | {tot:.0f} | {avg:.2f} | {pct:.1f} |")
     open(out, "w").write("\n".join(lines) + "\n")
+    import json
+    js = {name: dict(calls=int(calls), total_us=float(tot), avg_us=float(avg), pct=float(pct)) for name, calls, tot, avg, pct in rows}
+    json.dump(js, open(out.rsplit(".", 1)[0] + ".json", "w"), indent=0)   # bench.py reads avg_us of the dominant kernel
     print(out, "written;", len(rows), "kernels")
 
 
