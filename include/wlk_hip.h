@@ -123,6 +123,68 @@ int wlk_kv_reorder(wlk_session* s, const int32_t* source_rows, int n_rows);
 
 int wlk_sync(wlk_session* s);
 
+/* ---- (f-next, rank 1) the AlignAtt decode loop of one infer behind ONE call -------------------------------
+ * Replaces the per-token Python loop of AlignAttBase.infer (simul_whisper/align_att_base.py:206-286) for beam 1:
+ * decoder forward, no-speech check (first step), blank / special-token suppression, DRY penalty
+ * (align_att_base.py:492-537), BeamSearchDecoder.update with beam_size 1 (whisper/decoding.py:317-376), AlignAtt
+ * read-out and the stop rules (completed / rewind / frame threshold / token budget) - no Python between tokens.
+ * The caller keeps everything before and after the loop (context trimming, word splitting, timestamps). */
+typedef struct wlk_loop_params {
+    int32_t sot_index;            /* index of <|startoftranscript|> in the fed tokens (no-speech row) */
+    int32_t is_last;
+    int32_t frame_threshold;      /* cfg.frame_threshold (4 is used when is_last) */
+    int32_t rewind_threshold;     /* cfg.rewind_threshold */
+    int32_t last_attend_frame;    /* state.last_attend_frame on entry */
+    int32_t max_text_len;         /* model.dims.n_text_ctx */
+    int32_t budget;               /* max(50, int(seconds * 15 * 1.5)): decoder forwards allowed in this infer */
+    int32_t eot;                  /* tokenizer.eot */
+    int32_t dec_pad;              /* DEC_PAD = 50257 (align_att_base.py:9) */
+    int32_t no_speech_token;      /* < 0: no check */
+    float no_speech_threshold;    /* cfg.nonspeech_prob */
+    int32_t content_mel_len;      /* from wlk_encode, unclipped */
+} wlk_loop_params;
+enum {
+    WLK_STOP_NONE = 0,
+    WLK_STOP_CONTEXT_FULL = 1,    /* tokens reached max_text_len */
+    WLK_STOP_BUDGET = 2,          /* runaway guard: every token of this infer is dropped */
+    WLK_STOP_NO_SPEECH = 3,
+    WLK_STOP_COMPLETED = 4,       /* end-of-text won: the last appended token is dropped */
+    WLK_STOP_REWIND = 5,          /* attention jumped back: every token of this infer is dropped */
+    WLK_STOP_FRAME = 6            /* attention reached the end of the audio: the last appended token is dropped */
+};
+typedef struct wlk_loop_result {
+    int32_t n_steps;              /* decode steps that selected a token (= entries of step_tokens / step_frames) */
+    int32_t n_new_tokens;         /* tokens kept (after the drops above) */
+    int32_t stop_reason;
+    int32_t last_attend_frame;    /* state.last_attend_frame on exit */
+    float no_speech_prob;
+    float sum_logprob;
+    int32_t decode_calls;         /* decoder forwards run */
+} wlk_loop_result;
+/* tokens: host int64 [n_tok] = context + prompt (what _current_tokens() returns, one row).  suppress_ids: the
+ * SuppressTokens list; blank_ids: encode(" ") + [eot].  Outputs (each of capacity `cap`, may be NULL except result):
+ * the kept new tokens, and per decode step the selected token, the attended frame and the running log-prob sum.
+ * The session must have been encoded; its beam must be 1.  Sessions attached to a batch engine (wlk_engine_attach)
+ * run their single-token steps batched with the other attached sessions of the model. */
+int wlk_decode_until_stop(wlk_session* s, const int64_t* tokens, int n_tok, const wlk_loop_params* p,
+                          const int32_t* suppress_ids, int n_suppress, const int32_t* blank_ids, int n_blank,
+                          wlk_loop_result* result, int64_t* new_tokens, int32_t* step_tokens, int32_t* step_frames,
+                          float* step_sum_logprobs, int cap);
+/* The host half of that loop without a GPU (integer logic only), for harnesses that supply the numerics themselves:
+ * begin_step -> n_feed tokens to run through the decoder (0 = loop over); no_speech (first step only); adjustments ->
+ * unique (id, additive delta) pairs to apply to the last-position logits; consume(top-2 log-probs/ids after the
+ * adjustments, attended frame) -> goes_on. */
+typedef struct wlk_decode_job wlk_decode_job;
+int wlk_job_create(const wlk_loop_params* p, const int64_t* tokens, int n_tok, const int32_t* suppress_ids, int n_suppress,
+                   const int32_t* blank_ids, int n_blank, wlk_decode_job** out);
+int wlk_job_begin_step(wlk_decode_job* j, int32_t* n_feed);
+int wlk_job_no_speech(wlk_decode_job* j, float prob, int32_t* stops);
+int wlk_job_adjustments(wlk_decode_job* j, const int32_t** ids, const float** deltas, int32_t* n);
+int wlk_job_consume(wlk_decode_job* j, const float* top_logprobs, const int32_t* top_ids, int frame, int32_t* goes_on);
+int wlk_job_result(wlk_decode_job* j, wlk_loop_result* result, int64_t* new_tokens, int32_t* step_tokens,
+                   int32_t* step_frames, float* step_sum_logprobs, int cap);
+int wlk_job_destroy(wlk_decode_job* j);
+
 /* Parity/debug exports to host memory.  what: "mel" [n_mels,3000], "enc" [1500,d],
  * "logits_last" / "logits_sot" [n_rows,V], "attn_last" [n_rows, content_mel_len] (after
  * wlk_select), "cross_qk:<layer>" [rows, H, 1500] of the latest wlk_decode (debug sessions only),

@@ -101,6 +101,58 @@ class FakeSession:
     def kv_reorder(self, src):
         self.cache.reorder(list(src))
 
+    def decode_until_stop(self, tokens, params, suppress_ids, blank_ids):
+        """wlk_decode_until_stop on CPU: the LIBRARY's own host logic of the loop (wlk_job_*: budget, DRY penalty,
+        beam-1 update, stop rules) driven with the oracle's numerics in place of the kernels."""
+        import ctypes as C
+        from whisperlivekit_amd import _lib
+        from whisperlivekit_amd.engine import LoopOutcome
+        lib = _lib.load()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        t = np.ascontiguousarray(tokens, dtype=np.int64).reshape(-1)
+        sup = np.ascontiguousarray(suppress_ids, dtype=np.int32)
+        blank = np.ascontiguousarray(blank_ids, dtype=np.int32)
+        job = C.c_void_p()
+        _lib.check(lib.wlk_job_create(C.byref(params), vp(t), t.size, vp(sup), sup.size, vp(blank), blank.size, C.byref(job)))
+        seq = [int(x) for x in t]
+        first = True                                # each call is one infer: its first decoder forward is the prefill
+        try:
+            while True:
+                n_feed = C.c_int32()
+                _lib.check(lib.wlk_job_begin_step(job, C.byref(n_feed)))
+                if n_feed.value == 0:
+                    break
+                feed = np.asarray([seq if first else seq[-1:]], dtype=np.int64)
+                self.decode(feed, first=first, sot_index=int(params.sot_index))
+                if first and params.no_speech_token >= 0:
+                    stops = C.c_int32()
+                    _lib.check(lib.wlk_job_no_speech(job, float(self.no_speech_prob(int(params.no_speech_token))[0]), C.byref(stops)))
+                    if stops.value:
+                        break
+                first = False
+                ids_p, dl_p, n = C.POINTER(C.c_int32)(), C.POINTER(C.c_float)(), C.c_int32()
+                _lib.check(lib.wlk_job_adjustments(job, C.byref(ids_p), C.byref(dl_p), C.byref(n)))
+                ids = [ids_p[i] for i in range(n.value)]
+                dls = [dl_p[i] for i in range(n.value)]
+                assert len(set(ids)) == len(ids)
+                lp, top, frames = self.select([-1] * len(ids), ids, dls, 2, int(params.content_mel_len))
+                lp = np.ascontiguousarray(lp[0], np.float32)
+                top = np.ascontiguousarray(top[0], np.int32)
+                go = C.c_int32()
+                _lib.check(lib.wlk_job_consume(job, vp(lp), vp(top), int(frames[0]), C.byref(go)))
+                nxt = int(top[1]) if int(top[0]) == int(params.eot) else int(top[0])
+                seq.append(nxt)
+                if not go.value:
+                    break
+            cap = int(params.max_text_len) + 8
+            res = _lib.LoopResult()
+            new = np.empty(cap, np.int64)
+            st, sf, ss = np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.float32)
+            _lib.check(lib.wlk_job_result(job, C.byref(res), vp(new), vp(st), vp(sf), vp(ss), cap))
+            return LoopOutcome(res, new, st, sf, ss)
+        finally:
+            lib.wlk_job_destroy(job)
+
     def export(self, what, max_floats=None):
         if what == "enc":
             return self.enc.numpy().reshape(-1)

@@ -384,6 +384,41 @@ def test_stream_matches_reference_golden(case):
         proc.close()
 
 
+def make_hip_loop_processor(model_name, cfg_over, seed=0):
+    from whisperlivekit_amd import policy as P
+    from whisperlivekit_amd.backend import HipSimulStreamingASR, HipSimulStreamingOnlineProcessor
+    asr = HipSimulStreamingASR(model_name, hip_model=hip_model(model_name, seed), **H.asr_kwargs(cfg_over))
+
+    class P2(HipSimulStreamingOnlineProcessor):
+        def new_speaker(self, speaker, start):
+            return super().new_speaker(P.ChangeSpeaker(speaker=speaker, start=start))
+
+    proc = P2(asr)
+    proc.model.decision_log = []
+    assert proc.model.device_loop_available()
+    return proc
+
+
+@pytest.mark.parametrize("case", [c for c in STREAMS + GPU_STREAMS if "beam" not in c])
+def test_stream_through_library_decode_loop(case):
+    """the same golden streams with the per-token loop inside the library (wlk_decode_until_stop):
+    identical decisions, words and end state; no Python between tokens."""
+    from test_policy_golden import check_loop_stream
+    if not H.golden_exists(f"stream_{case}.json"):
+        pytest.skip(f"golden stream {case} not generated")
+    g, proc, got = replay_stream(case, make_hip_loop_processor)
+    try:
+        emitted = [[(t.start, t.end, t.text) for t in toks] for ev, toks, _ in got if ev["kind"] == "chunk"]
+        r = H.compare_decisions(g, proc.model.decision_log, emitted)
+        report(f"loop_stream_{case}", **{k: (list(v) if isinstance(v, list) else v) for k, v in r.items()},
+               last_error=repr(getattr(proc, "last_error", None)))
+        if r["tie_divergence"] is None:
+            check_loop_stream(g, proc, got)
+        assert r["mismatch"] is None, r
+    finally:
+        proc.close()
+
+
 def test_barrier_free_single_row_gemv_is_bit_identical_to_the_staged_kernel(tmp_path):
     """gemv1_f32_kernel (beam-1 decode steps: no LDS, no barrier) keeps the staged kernel's reduction and fmaf
     order, so switching it off (WLK_NO_GEMV1, read once per process) must not change a single bit."""

@@ -18,6 +18,7 @@ class RecordingProcessor(HipSimulStreamingOnlineProcessor):
         super().__init__(asr)
         self.trace = []
         m = self.model
+        m.use_device_loop = False        # the trace below hangs on the per-token hooks
         enc0, logit0, ns0, upd0, fr0 = m._encode, m._get_logits_and_cross_attn, m._check_no_speech, \
             m._update_tokens, m._get_attended_frames
 
@@ -85,6 +86,53 @@ def test_product_host_logic_matches_reference(case):
     assert proc.model.state.context.text == last["context"]
     assert proc.model.state.last_attend_frame == last["last_attend_frame"]
     assert abs(proc.model.state.cumulative_time_offset - last["cumulative_time_offset"]) < 1e-9
+
+
+BEAM1_STREAMS = [c for c in STREAMS if "beam" not in c]
+
+
+def make_loop_processor(model_name, cfg_over, seed=0):
+    """The product's processor with the decode loop inside the library (wlk_decode_until_stop's host logic through
+    wlk_job_*; oracle numerics from the CPU fake session)."""
+    dims = MODEL_DIMS[model_name]
+    fake = FakeHipModel(dims, H.oracle_sd(model_name, seed), ALIGNMENT_HEADS[model_name])
+    asr = HipSimulStreamingASR(model_name, hip_model=fake, **H.asr_kwargs(cfg_over))
+
+    class P2(HipSimulStreamingOnlineProcessor):
+        def new_speaker(self, speaker, start):
+            return super().new_speaker(P.ChangeSpeaker(speaker=speaker, start=start))
+
+    proc = P2(asr)
+    proc.model.decision_log = []
+    assert proc.model.device_loop_available()
+    return proc
+
+
+def check_loop_stream(g, proc, got):
+    emitted = [[(t.start, t.end, t.text) for t in toks] for ev, toks, _ in got if ev["kind"] == "chunk"]
+    r = H.compare_decisions(g, proc.model.decision_log, emitted)
+    assert r["mismatch"] is None and r["tie_divergence"] is None, r
+    assert r["identical"] == r["decisions"] and r["words_identical"], r
+    for ev, toks, upto in got:                      # silence / speaker events emit words too
+        assert [(round(t.start, 2), round(t.end, 2), t.text, t.speaker) for t in toks] == \
+               [(round(s, 2), round(e, 2), x, sp) for s, e, x, sp in ev["tokens"]]
+        assert abs(upto - ev["upto"]) < 1e-9
+    last = [ev for ev, _, _ in got if ev["kind"] == "chunk"][-1]
+    assert proc.model.state.context.text == last["context"]
+    assert proc.model.state.last_attend_frame == last["last_attend_frame"]
+    assert abs(proc.model.state.cumulative_time_offset - last["cumulative_time_offset"]) < 1e-9
+    hyp = [t[0].tolist() for t in proc.model.state.tokens[1:]]
+    assert (hyp[-1] if hyp else []) == last["hypothesis"]
+    return r
+
+
+@pytest.mark.parametrize("case", BEAM1_STREAMS)
+def test_library_decode_loop_matches_reference(case):
+    """the per-token loop (budget, no-speech stop, suppression, DRY penalty, beam-1 update, rewind /
+    frame-threshold stops) runs inside the library; same decisions, words and end state as the reference."""
+    g, proc, got = replay_stream(case, make_loop_processor)
+    r = check_loop_stream(g, proc, got)
+    assert r["calls"] == len(g["calls"])
 
 
 def test_repetition_detectors():

@@ -30,6 +30,23 @@ class SfDims(C.Structure):
         ("xscale", C.c_float)]
 
 
+class LoopParams(C.Structure):
+    """wlk_loop_params (include/wlk_hip.h)"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "sot_index", "is_last", "frame_threshold", "rewind_threshold", "last_attend_frame", "max_text_len", "budget",
+        "eot", "dec_pad", "no_speech_token")] + [("no_speech_threshold", C.c_float), ("content_mel_len", C.c_int32)]
+
+
+class LoopResult(C.Structure):
+    """wlk_loop_result (include/wlk_hip.h)"""
+    _fields_ = [("n_steps", C.c_int32), ("n_new_tokens", C.c_int32), ("stop_reason", C.c_int32),
+                ("last_attend_frame", C.c_int32), ("no_speech_prob", C.c_float), ("sum_logprob", C.c_float),
+                ("decode_calls", C.c_int32)]
+
+
+STOP_NONE, STOP_CONTEXT_FULL, STOP_BUDGET, STOP_NO_SPEECH, STOP_COMPLETED, STOP_REWIND, STOP_FRAME = range(7)
+
+
 def lib_path() -> str:
     return os.environ.get("WLK_HIP_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME))
 
@@ -65,6 +82,15 @@ def _declare(lib: C.CDLL) -> None:
         "wlk_select": (cint, [p, p, p, p, cint, cint, cint, p, p, p]),
         "wlk_kv_reorder": (cint, [p, p, cint]),
         "wlk_sync": (cint, [p]),
+        "wlk_decode_until_stop": (cint, [p, p, cint, C.POINTER(LoopParams), p, cint, p, cint, C.POINTER(LoopResult),
+                                         p, p, p, p, cint]),
+        "wlk_job_create": (cint, [C.POINTER(LoopParams), p, cint, p, cint, p, cint, C.POINTER(p)]),
+        "wlk_job_begin_step": (cint, [p, C.POINTER(i32)]),
+        "wlk_job_no_speech": (cint, [p, C.c_float, C.POINTER(i32)]),
+        "wlk_job_adjustments": (cint, [p, C.POINTER(i32p), C.POINTER(f32p), C.POINTER(i32)]),
+        "wlk_job_consume": (cint, [p, p, p, cint, C.POINTER(i32)]),
+        "wlk_job_result": (cint, [p, C.POINTER(LoopResult), p, p, p, p, cint]),
+        "wlk_job_destroy": (cint, [p]),
         "wlk_export": (cint, [p, C.c_char_p, p, u64, C.POINTER(u64)]),
         "wlk_prof_begin": (cint, [p]),
         "wlk_prof_end": (cint, [p, cint, C.POINTER(C.c_char_p), p, p, p, p, C.POINTER(i32)]),
@@ -109,7 +135,9 @@ EXPORTED_SYMBOLS = (
     "wlk_model_set_alignment_heads", "wlk_model_finalize", "wlk_model_destroy", "wlk_session_create",
     "wlk_session_destroy", "wlk_session_set_debug", "wlk_audio_append", "wlk_audio_append_pcm16", "wlk_audio_append_zeros",
     "wlk_audio_drop_front", "wlk_audio_clear", "wlk_audio_len", "wlk_encode", "wlk_decode",
-    "wlk_no_speech_prob", "wlk_select", "wlk_kv_reorder", "wlk_sync", "wlk_export", "wlk_prof_begin",
+    "wlk_no_speech_prob", "wlk_select", "wlk_kv_reorder", "wlk_sync", "wlk_decode_until_stop", "wlk_job_create",
+    "wlk_job_begin_step", "wlk_job_no_speech", "wlk_job_adjustments", "wlk_job_consume", "wlk_job_result",
+    "wlk_job_destroy", "wlk_export", "wlk_prof_begin",
     "wlk_prof_end", "wlk_melspec_create", "wlk_melspec_run", "wlk_melspec_destroy",
     "wlk_sf_arena_floats", "wlk_sf_tensor_lookup", "wlk_sf_tensor_name", "wlk_sf_create", "wlk_sf_upload",
     "wlk_sf_finalize", "wlk_sf_step", "wlk_sf_export", "wlk_sf_destroy",

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import logging
 import math
+import os
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -367,6 +368,40 @@ class HipAlignAttHooks:
         if sources != list(range(len(sources))):
             self.session.kv_reorder(sources)
         return tokens, completed
+
+    # === the whole decode loop behind one call ===================================
+    def device_loop_available(self) -> bool:
+        """Beam 1 with the reference's (hard-wired) beam decoder, on a session that offers the loop; switchable
+        per object (``use_device_loop``) and globally (WLK_DEVICE_LOOP=0) so the per-token hook path stays testable."""
+        if not getattr(self, "use_device_loop", True) or os.environ.get("WLK_DEVICE_LOOP", "1") == "0":
+            return False
+        return (self.cfg.beam_size == 1 and self.state.decoder_type == "beam"
+                and hasattr(self.session, "decode_until_stop"))
+
+    def _decode_until_stop(self, tokens, content_mel_len, is_last, budget):
+        """align_att_base.py:206-286 as ONE library call: returns the loop's outcome (engine.LoopOutcome)."""
+        from . import _lib
+        tok, cfg, st = self.tokenizer, self.cfg, self.state
+        if content_mel_len != self._content_mel_len:
+            raise RuntimeError("content_mel_len changed between _encode and the decode loop")
+        if content_mel_len <= 0:
+            raise RuntimeError("attention read-out over zero content frames")
+        p = _lib.LoopParams(
+            sot_index=st.sot_index, is_last=1 if is_last else 0, frame_threshold=int(cfg.frame_threshold),
+            rewind_threshold=int(cfg.rewind_threshold), last_attend_frame=int(st.last_attend_frame),
+            max_text_len=int(self.max_text_len), budget=int(budget), eot=int(tok.eot), dec_pad=P.DEC_PAD,
+            no_speech_token=-1 if tok.no_speech is None else int(tok.no_speech),
+            no_speech_threshold=float(cfg.nonspeech_prob), content_mel_len=int(content_mel_len))
+        blank = list(tok.encode(" ")) + [tok.eot]
+        out = self.session.decode_until_stop(np.asarray(tokens)[0], p, st.suppress_ids, blank)
+        self._fresh_infer = False
+        self.counters["decode"] += out.decode_calls
+        if out.decode_calls:
+            self.counters["prefill_tokens"] += int(np.asarray(tokens).shape[1])
+        self.last_no_speech_prob = out.no_speech_prob
+        if self.decision_log is not None:
+            self.decision_log[-1][1].extend(zip(out.step_tokens, out.step_frames))
+        return out
 
     # === AlignAtt read-out (a8) =====================================================================
     def _process_cross_attention(self, accumulated_cross_attns, content_mel_len):

@@ -188,6 +188,24 @@ class HipWhisperModel:
             pass
 
 
+class LoopOutcome:
+    """What wlk_decode_until_stop / wlk_job_result hand back, as plain Python values."""
+    __slots__ = ("new_tokens", "step_tokens", "step_frames", "step_sum_logprobs", "stop_reason", "last_attend_frame",
+                 "no_speech_prob", "sum_logprob", "decode_calls")
+
+    def __init__(self, res: "_lib.LoopResult", new, step_tokens, step_frames, step_sums):
+        n, k = int(res.n_steps), int(res.n_new_tokens)
+        self.new_tokens = [int(x) for x in new[:k]]
+        self.step_tokens = [int(x) for x in step_tokens[:n]]
+        self.step_frames = [int(x) for x in step_frames[:n]]
+        self.step_sum_logprobs = [float(x) for x in step_sums[:n]]
+        self.stop_reason = int(res.stop_reason)
+        self.last_attend_frame = int(res.last_attend_frame)
+        self.no_speech_prob = float(res.no_speech_prob)
+        self.sum_logprob = float(res.sum_logprob)
+        self.decode_calls = int(res.decode_calls)
+
+
 class HipSession:
     """Per-stream device state.  One call in flight at a time (the reference's threading
     contract for a session); different sessions may be driven from different threads."""
@@ -258,6 +276,22 @@ class HipSession:
         _lib.check(self.lib.wlk_select(self._h, vp(r), vp(i), vp(dl), n, k, int(content_mel_len), vp(lp), vp(ids),
                                        vp(fr)))
         return lp, ids, fr
+
+    def decode_until_stop(self, tokens: Sequence[int], params: "_lib.LoopParams", suppress_ids: Sequence[int],
+                          blank_ids: Sequence[int]) -> "LoopOutcome":
+        """The whole AlignAtt decode loop of one infer (beam 1) in one library call (wlk_decode_until_stop)."""
+        t = np.ascontiguousarray(tokens, dtype=np.int64).reshape(-1)
+        sup = np.ascontiguousarray(suppress_ids, dtype=np.int32)
+        blank = np.ascontiguousarray(blank_ids, dtype=np.int32)
+        cap = int(params.max_text_len) + 8
+        res = _lib.LoopResult()
+        new = np.empty(cap, np.int64)
+        st, sf = np.empty(cap, np.int32), np.empty(cap, np.int32)
+        ss = np.empty(cap, np.float32)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(self.lib.wlk_decode_until_stop(self._h, vp(t), t.size, C.byref(params), vp(sup), sup.size, vp(blank),
+                                                  blank.size, C.byref(res), vp(new), vp(st), vp(sf), vp(ss), cap))
+        return LoopOutcome(res, new, st, sf, ss)
 
     def kv_reorder(self, source_rows: Sequence[int]) -> None:
         s = np.asarray(source_rows, dtype=np.int32)

@@ -284,11 +284,38 @@ class AlignAttPolicy:
         tokens = self._current_tokens()
         fire = self.fire_at_boundary(encoder_feature[:, :content_mel_len, :])
 
+        n_before = tokens.shape[1]
+        budget = max(50, int(self.segments_len() * 15 * 1.5))     # align_att_base.py:200-201
+        device_loop = getattr(self, "device_loop_available", None)
+        if device_loop is not None and device_loop():
+            # the per-token loop below runs inside the library (wlk_decode_until_stop)
+            out = self._decode_until_stop(tokens, content_mel_len, is_last, budget)
+            stamps = [f * 0.02 + st.cumulative_time_offset for f in out.step_frames]
+            st.last_attend_frame = out.last_attend_frame
+            new_ids = list(out.new_tokens)
+        else:
+            tokens, stamps = self._decode_loop(tokens, encoder_feature, content_mel_len, is_last, budget)
+            new_ids = self._tokens_to_list(tokens, n_before)
+        times = self._normalize_token_timestamps(stamps, len(new_ids))
+        if st.pending_incomplete_tokens:
+            new_ids, times = self._prepend_pending_tokens(new_ids, times)
+        hypothesis, words, groups = self._split_tokens(new_ids, fire, is_last)
+        st.tokens.append(self._make_new_tokens_tensor(hypothesis))
+        self._clean_cache()
+        if len(stamps) >= 2 and st.first_timestamp is None:
+            st.first_timestamp = stamps[0]
+        out = self._build_timestamped_words(words, groups, times)
+        self._handle_pending_tokens(words, groups, times)
+        return out
+
+    def _decode_loop(self, tokens, encoder_feature, content_mel_len, is_last, budget):
+        """The reference's per-token loop over the tensor hooks (align_att_base.py:206-286); returns the final token
+        matrix and one absolute timestamp per decode step."""
+        st, cfg = self.state, self.cfg
         sum_logprobs = self._init_sum_logprobs()
         n_before = tokens.shape[1]
         stamps: List[float] = []
         window: List[Any] = []
-        budget = max(50, int(self.segments_len() * 15 * 1.5))     # align_att_base.py:200-201
         produced = 0
         fresh = True
         done = False
@@ -334,18 +361,7 @@ class AlignAttPolicy:
                 tokens = tokens[:, :-1]
                 break
 
-        new_ids = self._tokens_to_list(tokens, n_before)
-        times = self._normalize_token_timestamps(stamps, len(new_ids))
-        if st.pending_incomplete_tokens:
-            new_ids, times = self._prepend_pending_tokens(new_ids, times)
-        hypothesis, words, groups = self._split_tokens(new_ids, fire, is_last)
-        st.tokens.append(self._make_new_tokens_tensor(hypothesis))
-        self._clean_cache()
-        if len(stamps) >= 2 and st.first_timestamp is None:
-            st.first_timestamp = stamps[0]
-        out = self._build_timestamped_words(words, groups, times)
-        self._handle_pending_tokens(words, groups, times)
-        return out
+        return tokens, stamps
 
     # -- post-decode helpers --------------------------------------------------------------------
     def _split_tokens(self, ids, fire, is_last):
