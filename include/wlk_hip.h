@@ -170,6 +170,15 @@ int wlk_decode_until_stop(wlk_session* s, const int64_t* tokens, int n_tok, cons
                           const int32_t* suppress_ids, int n_suppress, const int32_t* blank_ids, int n_blank,
                           wlk_loop_result* result, int64_t* new_tokens, int32_t* step_tokens, int32_t* step_frames,
                           float* step_sum_logprobs, int cap);
+/* Cross-session batching of those loops: the reference serves N sessions from one model on one device
+ * (whisperlivekit/core.py:246-271, audio_processor.py:543-551), each issuing its own launch chain per token.  Sessions
+ * attached here hand the single-token steps of wlk_decode_until_stop to ONE worker per GPU that advances every loop
+ * currently in its decode phase in one launch chain (rows = sessions; weights are streamed once per step for all of
+ * them; per-row arithmetic and its order are those of a session running alone).  Beam-1 sessions only. */
+int wlk_engine_attach(wlk_session* s);
+int wlk_engine_detach(wlk_session* s);
+/* engine iterations, rows advanced in them, and the batched (>= 2 rows) iterations / rows among those */
+int wlk_engine_stats(wlk_model* m, uint64_t* iterations, uint64_t* rows, uint64_t* batched_steps, uint64_t* batched_rows);
 /* The host half of that loop without a GPU (integer logic only), for harnesses that supply the numerics themselves:
  * begin_step -> n_feed tokens to run through the decoder (0 = loop over); no_speech (first step only); adjustments ->
  * unique (id, additive delta) pairs to apply to the last-position logits; consume(top-2 log-probs/ids after the

@@ -99,6 +99,12 @@ def test_eight_threads_share_one_model(model_name, cases):
             if r["tie_divergence"] is None:
                 assert r["identical"] == r["decisions"] and r["words_identical"], (cases[i], r)
             p.close()
+    stats = model.engine_stats()
+    assert stats["batched_steps"] > 0 and stats["mean_rows_per_batched_step"] >= 2.0, stats   # the loops really shared steps
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f"engine_stats_{model_name}.json"), "w") as fh:
+        json.dump(stats, fh)
     model.close()
 
 

@@ -51,6 +51,22 @@ struct KernelScope {  // RAII: brackets one launch with events when profiling is
     }
 };
 
+// ---- cross-session batched decode steps (engine.hip) ---------------------------------------------
+// One row of a batched single-token decode step = one beam-1 session.  The table lives in device memory and is
+// rewritten before every step; kernels that touch per-session state (KV-cache append, self-/cross-attention, the
+// alignment window and its read-out) index it by row instead of taking one session's pointers.
+struct StepRow {
+    float* kcache;           // the session's current self-attention K cache, layer 0 ([L][ctx][d], beam 1)
+    float* vcache;
+    const float* cross_kv;   // the session's cross-attention K|V of all layers, [T][L][2d]
+    float* ring;             // the session's alignment window [n_align][ring_rows][T]
+    int token;               // token fed in this step
+    int offset;              // self-attention cache length before this step (= position of the fed token)
+    int ring_row;            // alignment-window row this step's cross-attention rows go to
+    int prefill_rows, n_single, newest_row, content_len;   // AlignArgs of this row's read-out
+    int pad;
+};
+
 // ---- gemm_f32.hip ---------------------------------------------------------------------------
 // C[M,N] = epilogue(A[M,K] * W[N,K]^T + bias[N]); fp32 MFMA (v_mfma_f32_32x32x2_f32).
 enum GemmFlags : int {
@@ -84,6 +100,9 @@ struct GemmArgs {
     const int* kv_pos = nullptr;
     int kv_d = 0, kv_ctx = 0;
     int kv_ntok = 1;       // k-wave GEMM path: rows are [beam][kv_ntok] (decoder prefill)
+    // batched steps (GEMV path): row m appends to kv_rows[m].kcache/vcache + kv_layer_off at position kv_rows[m].offset
+    const StepRow* kv_rows = nullptr;
+    long kv_layer_off = 0;
     // single-row GEMV (beam-1 decode step) whose A row is the cross-attention output still in split form: the merge
     // of the kCrossSplit partial softmax states (cross_merge_kernel's arithmetic) is the operand load, and the last
     // `mg_side_blocks` workgroups of the launch write the alignment heads' softmax rows into the alignment window
@@ -183,6 +202,10 @@ void launch_ring_softmax(const LaunchCtx& ctx, float* ring, const int* ring_row,
 // ---- decoder.hip ----------------------------------------------------------------------------
 void launch_embed(const LaunchCtx& ctx, const int* tokens, const float* tok_emb, const float* pos_emb,
                   float* x, int n_rows, int n_tok, const int* offset_dev, int d);
+void launch_embed_rows(const LaunchCtx& ctx, const StepRow* rows, const float* tok_emb, const float* pos_emb, float* x,
+                       int n_rows, int d);
+void launch_decoder_self_attention_rows(const LaunchCtx& ctx, const float* qkv, const StepRow* rows, long layer_off,
+                                        float* out, int n_rows, int d, int n_head, int ctx_len);
 void launch_kv_append(const LaunchCtx& ctx, const float* qkv, float* kc, float* vc, int n_rows, int n_tok,
                       const int* offset_dev, int d, int ctx_len);
 void launch_decoder_self_attention(const LaunchCtx& ctx, const float* qkv, const float* kc, const float* vc,
@@ -201,6 +224,10 @@ struct CrossAttnArgs {
     const int* beam_of_row;// [rows]
     int ring_rows, n_beam;
     float* qk_debug;       // [rows][n_head][T] or nullptr
+    // batched steps: keys/values of row r are step_rows[r].cross_kv + kv_off (+ d for v), its alignment rows go to
+    // step_rows[r].ring at step_rows[r].ring_row (one beam per row)
+    const StepRow* step_rows = nullptr;
+    long kv_off = 0;
 };
 void launch_decoder_cross_attention(const LaunchCtx& ctx, const CrossAttnArgs& a);
 // decode steps: keys split over several workgroups per (row, head) + merge; scratch layout is
@@ -260,7 +287,11 @@ struct AlignArgs {
     float* z;            // scratch [n_beam][n_align][T]
     float* attn_last;    // [n_beam][T] head-mean of the median-filtered newest row
     int* frames;         // [n_beam]
+    const StepRow* rows = nullptr;   // launch_alignatt_rows
 };
 void launch_alignatt(const LaunchCtx& ctx, const AlignArgs& a);
+// batched steps: one read-out per row with the row's own window / counters (a.ring, prefill_rows, n_single, newest_row
+// and content_len are taken from rows[r]; a.n_beam is the number of rows, each row is its own beam 0)
+void launch_alignatt_rows(const LaunchCtx& ctx, const AlignArgs& a, const StepRow* rows);
 
 }  // namespace wlk

@@ -31,6 +31,22 @@ void launch_embed(const LaunchCtx& ctx, const int* tokens, const float* tok_emb,
     WLK_HIP(hipGetLastError());
 }
 
+__global__ __launch_bounds__(128) void embed_rows_kernel(const StepRow* __restrict__ rows, const float* __restrict__ tok_emb,
+                                                         const float* __restrict__ pos_emb, float* __restrict__ x, int d) {
+    const int row = blockIdx.x;
+    const StepRow sr = rows[row];
+    const float* e = tok_emb + (long)sr.token * d;
+    const float* pe = pos_emb + (long)sr.offset * d;
+    for (int c = threadIdx.x; c < d; c += 128) x[(long)row * d + c] = e[c] + pe[c];
+}
+
+void launch_embed_rows(const LaunchCtx& ctx, const StepRow* rows, const float* tok_emb, const float* pos_emb, float* x,
+                       int n_rows, int d) {
+    KernelScope ks(ctx, "dec_embed");
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(n_rows), dim3(128), 0, ctx.stream, rows, tok_emb, pos_emb, x, d);
+    WLK_HIP(hipGetLastError());
+}
+
 // qkv rows are [q | k | v] (3d floats); append k and v of every row to the per-beam caches
 __global__ __launch_bounds__(256) void kv_append_kernel(const float* __restrict__ qkv, float* __restrict__ kc,
                                                         float* __restrict__ vc, int n_tok,
@@ -67,17 +83,29 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(const float
                                                                      const float* __restrict__ vc,
                                                                      float* __restrict__ out, int n_tok,
                                                                      const int* __restrict__ offset_p, int d,
-                                                                     int ctx_len) {
+                                                                     int ctx_len,
+                                                                     const StepRow* __restrict__ step_rows,
+                                                                     long layer_off) {
     __shared__ __attribute__((aligned(16))) float qs[64];
     __shared__ float sc[448 + 64];
     __shared__ float red[8];
     __shared__ __attribute__((aligned(16))) float part[16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane & 15, kq = lane >> 4;
-    const int offset = *offset_p;
     const int row = blockIdx.x;
     const int head = blockIdx.y;
-    const int b = row / n_tok, p = row - b * n_tok;
+    int offset, b, p;
+    if (step_rows) {             // batched steps: one fed token per row, every row has its own cache
+        offset = step_rows[row].offset;
+        kc = step_rows[row].kcache + layer_off;
+        vc = step_rows[row].vcache + layer_off;
+        b = 0;
+        p = 0;
+    } else {
+        offset = *offset_p;
+        b = row / n_tok;
+        p = row - b * n_tok;
+    }
     const int n_keys = offset + p + 1;
     if (tid < 64) qs[tid] = qkv[(long)row * 3 * d + head * 64 + tid];
     __syncthreads();
@@ -167,7 +195,17 @@ void launch_decoder_self_attention(const LaunchCtx& ctx, const float* qkv, const
     if (ctx_len > 448 + 64) throw std::invalid_argument("self-attention: context too long");
     KernelScope ks(ctx, "dec_self_attention");
     hipLaunchKernelGGL(decoder_self_attention_kernel, dim3(n_rows * n_tok, n_head), dim3(256), 0, ctx.stream, qkv,
-                       kc, vc, out, n_tok, offset, d, ctx_len);
+                       kc, vc, out, n_tok, offset, d, ctx_len, (const StepRow*)nullptr, 0L);
+    WLK_HIP(hipGetLastError());
+}
+
+void launch_decoder_self_attention_rows(const LaunchCtx& ctx, const float* qkv, const StepRow* rows, long layer_off,
+                                        float* out, int n_rows, int d, int n_head, int ctx_len) {
+    if (ctx_len > 448 + 64) throw std::invalid_argument("self-attention: context too long");
+    KernelScope ks(ctx, "dec_self_attention");
+    hipLaunchKernelGGL(decoder_self_attention_kernel, dim3(n_rows, n_head), dim3(256), 0, ctx.stream, qkv,
+                       (const float*)nullptr, (const float*)nullptr, out, 1, (const int*)nullptr, d, ctx_len, rows,
+                       layer_off);
     WLK_HIP(hipGetLastError());
 }
 
@@ -336,8 +374,9 @@ __global__ __launch_bounds__(256) void cross_split_kernel(CrossAttnArgs a, float
     if (tid < 64) qs[tid] = a.q[(long)row * a.d + head * 64 + tid];
     __syncthreads();
     const float4 q4 = reinterpret_cast<const float4*>(qs)[sub];
-    const float* kb = a.k + head * 64 + sub * 4;
-    const float* vb = a.v + head * 64 + sub * 4;
+    const float* kbase = a.step_rows ? a.step_rows[row].cross_kv + a.kv_off : a.k;
+    const float* kb = kbase + head * 64 + sub * 4;
+    const float* vb = (a.step_rows ? kbase + a.d : a.v) + head * 64 + sub * 4;
     float* srow = scores + ((long)row * a.n_head + head) * a.T;
 
     float4 kk[kCrossUnroll];
@@ -435,7 +474,9 @@ __global__ __launch_bounds__(256) void cross_merge_kernel(CrossAttnArgs a, const
     }
     const int rank = a.head_rank ? a.head_rank[head] : -1;
     if (rank >= 0) {
-        float* dst = a.ring + (((long)rank * a.n_beam + a.beam_of_row[row]) * a.ring_rows + a.ring_row[row]) * a.T;
+        float* dst = a.step_rows
+                         ? a.step_rows[row].ring + ((long)rank * a.ring_rows + a.step_rows[row].ring_row) * a.T
+                         : a.ring + (((long)rank * a.n_beam + a.beam_of_row[row]) * a.ring_rows + a.ring_row[row]) * a.T;
         const float* srow = scores + ((long)row * a.n_head + head) * a.T;
         for (int j = tid; j < a.T; j += 256) dst[j] = expf(srow[j] - M) / L;
     }

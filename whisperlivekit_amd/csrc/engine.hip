@@ -1,0 +1,428 @@
+// Cross-session batched decode steps on one GPU ("continuous batching" of the AlignAtt decode loops).
+//
+// The reference serves N sessions from ONE model on ONE device (whisperlivekit/core.py:246-271 builds the shared
+// model, audio_processor.py:543-551 runs every session's process_iter on its own worker thread): each session then
+// issues its own chain of ~55 tiny launches per generated token and re-streams the same 200 MB of decoder weights.
+// Here every beam-1 session attached to the model's engine hands the single-token steps of its decode loop
+// (wlk_decode_until_stop, loop.hip) to ONE worker thread per GPU, which advances all loops that are currently in
+// their decode phase together: one launch chain per iteration with rows = sessions.  The weight-streaming GEMV
+// kernels already take up to 8 activation rows per pass over the weights (each row keeps the fmaf order of the
+// single-row kernel, so results are bit-identical to a session running alone); the kernels that touch per-session
+// state (KV-cache append, self-/cross-attention, alignment window + read-out) index a StepRow table by row.
+// Sessions join when their prefill is done and leave when their loop stops; nobody waits for anybody.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+#include "common.h"
+#include "internal.h"
+#include "loop.h"
+
+using namespace wlk;
+
+namespace {
+
+struct EngineJob {
+    wlk_session* s = nullptr;
+    DecodeJob* job = nullptr;
+    bool done = false;
+    int rc = WLK_OK;
+    std::string err;
+};
+
+constexpr int kEngineAdjCap = 8192;
+
+}  // namespace
+
+struct wlk_engine {
+    wlk_model* m = nullptr;
+    int max_rows = 1;
+    hipStream_t stream = nullptr;
+    // device workspace of one batched step
+    StepRow* rows_dev = nullptr;
+    float *x = nullptr, *qkv = nullptr, *att = nullptr, *q = nullptr, *mlp = nullptr, *logits = nullptr, *xsplit = nullptr,
+          *z = nullptr, *attn_last = nullptr;
+    float* res_dev = nullptr;      // [top log-probs R*2 | top ids R*2 | frames R]
+    void* topk_scratch = nullptr;
+    int* adj_dev = nullptr;        // [rows n | ids n | deltas n]
+    char* pinned = nullptr;
+    static constexpr size_t kPinnedBytes = 256 * 1024;
+    hipGraphExec_t step_exec[9] = {};   // captured launch chain per row count (adjustment count is a device scalar)
+    int* n_adj_dev = nullptr;
+    bool use_graph = true;
+
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<EngineJob*> submitted;
+    bool quit = false;
+    int attached = 0;
+    std::atomic<int> in_loop{0};   // sessions currently inside wlk_decode_until_stop
+    uint64_t n_iterations = 0, n_rows = 0, n_batched = 0, n_batched_rows = 0;
+
+    void run();
+    void step_single(EngineJob* j, std::vector<EngineJob*>& finished);
+    void step_batched(std::vector<EngineJob*>& group, std::vector<EngineJob*>& finished);
+    void enqueue_decoder(int R);            // embed .. logits of R rows (captured into a hipGraph per row count)
+    void enqueue_select(int R, int n_adj);  // logit adjustments + log-softmax top-2 + AlignAtt read-out per row
+};
+
+// ---- one batched step ----------------------------------------------------------------------------------------
+void wlk_engine::enqueue_decoder(int R) {
+    const wlk_dims& D = m->D;
+    const int d = D.n_text_state, T = D.n_audio_ctx, H = D.n_text_head, V = D.n_vocab, ctx_len = D.n_text_ctx;
+    const LaunchCtx c{stream, nullptr};
+    const float scale = std::pow((float)kHeadDim, -0.25f);
+    launch_embed_rows(c, rows_dev, m->w_tok_emb, m->w_dec_pos, x, R, d);
+    float* sc = xsplit;
+    float* pm = sc + (size_t)8 * H * T;
+    float* pl = pm + (size_t)8 * H * 8;
+    float* po = pl + (size_t)8 * H * 8;
+    for (int i = 0; i < D.n_text_layer; ++i) {
+        const LayerW& L = m->dec_layers[i];
+        const long layer_off = (long)i * ctx_len * d;       // beam 1: [L][ctx][d]
+        GemmArgs g;
+        g.A = x; g.lda = d; g.W = L.qkvw; g.bias = L.qkvb; g.C = qkv; g.ldc = 3 * d; g.M = R; g.N = 3 * d; g.K = d;
+        g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = 2 * d;
+        g.ln_gamma = L.ln1w; g.ln_beta = L.ln1b;
+        g.kv_rows = rows_dev; g.kv_layer_off = layer_off; g.kv_d = d; g.kv_ctx = ctx_len;
+        launch_gemv(c, g, "dec_ln1_qkv_kv");
+        launch_decoder_self_attention_rows(c, qkv, rows_dev, layer_off, att, R, d, H, ctx_len);
+        GemmArgs o;
+        o.A = att; o.lda = d; o.W = L.outw; o.bias = L.outb; o.C = x; o.ldc = d; o.M = R; o.N = d; o.K = d;
+        o.flags = kGemmResidual; o.R = x; o.ldr = d;
+        launch_gemv(c, o, "dec_out");
+        GemmArgs qq;
+        qq.A = x; qq.lda = d; qq.W = L.xqw; qq.bias = L.xqb; qq.C = q; qq.ldc = d; qq.M = R; qq.N = d; qq.K = d;
+        qq.flags = kGemmScaleCols; qq.scale = scale; qq.scale_cols = d; qq.ln_gamma = L.lnxw; qq.ln_beta = L.lnxb;
+        launch_gemv(c, qq, "dec_lnx_xq");
+        CrossAttnArgs ca{};
+        ca.q = q; ca.k = nullptr; ca.v = nullptr; ca.ldkv = (long)D.n_text_layer * 2 * d; ca.out = att;
+        ca.rows = R; ca.d = d; ca.n_head = H; ca.T = T;
+        ca.head_rank = m->n_align > 0 ? m->head_rank + (size_t)i * H : nullptr;
+        ca.ring = nullptr; ca.ring_row = nullptr; ca.beam_of_row = nullptr;
+        ca.ring_rows = ctx_len + kAlignWindow; ca.n_beam = 1; ca.qk_debug = nullptr;
+        ca.step_rows = rows_dev; ca.kv_off = (long)i * 2 * d;
+        launch_decoder_cross_attention_split(c, ca, sc, pm, pl, po, true);
+        GemmArgs xo;
+        xo.A = att; xo.lda = d; xo.W = L.xoutw; xo.bias = L.xoutb; xo.C = x; xo.ldc = d; xo.M = R; xo.N = d; xo.K = d;
+        xo.flags = kGemmResidual; xo.R = x; xo.ldr = d;
+        launch_gemv(c, xo, "dec_xout");
+        GemmArgs f1;
+        f1.A = x; f1.lda = d; f1.W = L.fc1w; f1.bias = L.fc1b; f1.C = mlp; f1.ldc = 4 * d; f1.M = R; f1.N = 4 * d; f1.K = d;
+        f1.flags = kGemmGelu; f1.ln_gamma = L.ln2w; f1.ln_beta = L.ln2b;
+        launch_gemv(c, f1, "dec_ln2_fc1");
+        GemmArgs f2;
+        f2.A = mlp; f2.lda = 4 * d; f2.W = L.fc2w; f2.bias = L.fc2b; f2.C = x; f2.ldc = d; f2.M = R; f2.N = d; f2.K = 4 * d;
+        f2.flags = kGemmResidual; f2.R = x; f2.ldr = d;
+        launch_gemv(c, f2, "dec_fc2");
+    }
+    GemmArgs lg;
+    lg.A = x; lg.lda = d; lg.W = m->w_tok_emb; lg.C = logits; lg.ldc = V; lg.M = R; lg.N = V; lg.K = d;
+    lg.ln_gamma = m->w_ln_w; lg.ln_beta = m->w_ln_b;
+    launch_gemv(c, lg, "dec_lnf_logits");
+}
+
+void wlk_engine::enqueue_select(int R, int n_adj) {
+    const wlk_dims& D = m->D;
+    const int T = D.n_audio_ctx, V = D.n_vocab, ctx_len = D.n_text_ctx;
+    const LaunchCtx c{stream, nullptr};
+    float* top_vals = res_dev;
+    int* top_ids = reinterpret_cast<int*>(res_dev) + 2 * max_rows;
+    int* frames = top_ids + 2 * max_rows;
+    launch_logsoftmax_topk(c, logits, V, R, 2, top_vals, top_ids, topk_scratch, adj_dev, adj_dev + n_adj,
+                           reinterpret_cast<float*>(adj_dev + 2 * n_adj), n_adj);
+    AlignArgs a{};
+    a.ring = nullptr; a.n_align = m->n_align; a.n_beam = R; a.ring_rows = ctx_len + kAlignWindow; a.T = T;
+    a.prefill_rows = 0; a.n_single = 0; a.newest_row = 0; a.single_base = ctx_len; a.content_len = 0;
+    a.z = z; a.attn_last = attn_last; a.frames = frames;
+    if (m->n_align > 0) launch_alignatt_rows(c, a, rows_dev);
+    else WLK_HIP(hipMemsetAsync(frames, 0, sizeof(int) * R, stream));
+}
+
+void wlk_engine::step_batched(std::vector<EngineJob*>& group, std::vector<EngineJob*>& finished) {
+    const wlk_dims& D = m->D;
+    const int R = (int)group.size();
+    const int T = D.n_audio_ctx, ctx_len = D.n_text_ctx;
+    StepRow* rows = reinterpret_cast<StepRow*>(pinned);
+    int* adj = reinterpret_cast<int*>(pinned + 4096);
+    std::vector<int32_t> ids, all_rows, all_ids;
+    std::vector<float> deltas, all_deltas;
+    for (int r = 0; r < R; ++r) {
+        wlk_session* s = group[r]->s;
+        DecodeJob& job = *group[r]->job;
+        if (s->self_len + 1 > ctx_len) throw std::runtime_error("text context exceeded");
+        if (s->n_steps < 1) throw std::runtime_error("engine step before the prefill");
+        const int after = s->n_steps + 1;
+        StepRow& sr = rows[r];
+        sr.kcache = s->kcache[s->kv_cur];
+        sr.vcache = s->vcache[s->kv_cur];
+        sr.cross_kv = s->cross_kv;
+        sr.ring = s->ring;
+        sr.token = (int)job.seq.back();
+        if (sr.token < 0 || sr.token >= D.n_vocab) throw std::invalid_argument("token id out of range");
+        sr.offset = s->self_len;
+        sr.ring_row = ctx_len + ((s->n_steps - 1) % kAlignWindow);
+        sr.prefill_rows = after <= kAlignWindow ? s->prefill_rows : 0;
+        sr.n_single = std::min(after - 1, kAlignWindow);
+        sr.newest_row = ctx_len + ((after - 2) % kAlignWindow);
+        sr.content_len = std::min(job.P.content_mel_len, T);
+        sr.pad = 0;
+        job.adjustments(ids, deltas);
+        for (size_t i = 0; i < ids.size(); ++i) {
+            all_rows.push_back(r);
+            all_ids.push_back(ids[i]);
+            all_deltas.push_back(deltas[i]);
+        }
+    }
+    const int n_adj = (int)all_ids.size();
+    if (n_adj > kEngineAdjCap) throw std::runtime_error("too many logit adjustments in one batched step");
+    std::memcpy(adj, all_rows.data(), n_adj * sizeof(int));
+    std::memcpy(adj + n_adj, all_ids.data(), n_adj * sizeof(int));
+    std::memcpy(adj + 2 * n_adj, all_deltas.data(), n_adj * sizeof(float));
+    WLK_HIP(hipMemcpyAsync(rows_dev, rows, sizeof(StepRow) * R, hipMemcpyHostToDevice, stream));
+    if (n_adj > 0) WLK_HIP(hipMemcpyAsync(adj_dev, adj, (size_t)n_adj * 12, hipMemcpyHostToDevice, stream));
+    if (use_graph) {
+        hipGraphExec_t& exec = step_exec[R];
+        if (!exec) {
+            hipGraph_t graph = nullptr;
+            WLK_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            try {
+                enqueue_decoder(R);
+            } catch (...) {
+                (void)hipStreamEndCapture(stream, &graph);
+                if (graph) (void)hipGraphDestroy(graph);
+                throw;
+            }
+            WLK_HIP(hipStreamEndCapture(stream, &graph));
+            WLK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+        }
+        WLK_HIP(hipGraphLaunch(exec, stream));
+    } else {
+        enqueue_decoder(R);
+    }
+    enqueue_select(R, n_adj);
+    float* out = reinterpret_cast<float*>(pinned + 4096 + (size_t)kEngineAdjCap * 12);
+    WLK_HIP(hipMemcpyAsync(out, res_dev, (size_t)max_rows * 5 * 4, hipMemcpyDeviceToHost, stream));
+    WLK_HIP(hipStreamSynchronize(stream));
+    const int* out_ids = reinterpret_cast<const int*>(out) + 2 * max_rows;
+    const int* out_frames = out_ids + 2 * max_rows;
+    n_batched += 1;
+    n_batched_rows += R;
+    for (int r = 0; r < R; ++r) {
+        wlk_session* s = group[r]->s;
+        s->self_len += 1;
+        s->n_steps += 1;
+        s->have_sot = false;
+        s->last_rows = 1;
+        s->last_ntok = 1;
+        if (!group[r]->job->consume(out + 2 * r, out_ids + 2 * r, out_frames[r])) finished.push_back(group[r]);
+    }
+}
+
+void wlk_engine::step_single(EngineJob* j, std::vector<EngineJob*>& finished) {
+    // a lone loop takes the session's own (graph-captured, single-row) launch chain
+    DecodeJob& job = *j->job;
+    const int64_t tok = job.seq.back();
+    int rc = wlk_decode(j->s, &tok, 1, 1, 0, job.P.sot_index);
+    std::vector<int32_t> ids, rows;
+    std::vector<float> deltas;
+    float lp[2] = {0.f, 0.f};
+    int32_t top[2] = {0, 0}, frame = 0;
+    if (rc == WLK_OK) {
+        job.adjustments(ids, deltas);
+        rows.assign(ids.size(), -1);
+        rc = wlk_select(j->s, rows.data(), ids.data(), deltas.data(), (int)ids.size(), 2, job.P.content_mel_len, lp, top,
+                        &frame);
+    }
+    if (rc != WLK_OK) {
+        j->rc = rc;
+        j->err = wlk_last_error();
+        finished.push_back(j);
+        return;
+    }
+    if (!job.consume(lp, top, frame)) finished.push_back(j);
+}
+
+void wlk_engine::run() {
+    (void)hipSetDevice(m->device);
+    std::vector<EngineJob*> active;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_work.wait(lk, [&] { return quit || !submitted.empty() || !active.empty(); });
+            if (quit && active.empty() && submitted.empty()) return;
+            while (!submitted.empty()) {
+                active.push_back(submitted.front());
+                submitted.pop_front();
+            }
+        }
+        std::vector<EngineJob*> finished;
+        for (size_t lo = 0; lo < active.size(); lo += (size_t)max_rows) {
+            std::vector<EngineJob*> group;
+            for (size_t i = lo; i < std::min(active.size(), lo + (size_t)max_rows); ++i) {
+                if (active[i]->job->begin_step()) group.push_back(active[i]);
+                else finished.push_back(active[i]);        // text context full / token budget spent
+            }
+            try {
+                if (group.size() == 1) step_single(group[0], finished);
+                else if (group.size() > 1) step_batched(group, finished);
+            } catch (const std::exception& e) {
+                for (EngineJob* j : group)
+                    if (std::find(finished.begin(), finished.end(), j) == finished.end()) {
+                        j->rc = dynamic_cast<const HipError*>(&e) ? WLK_ERR_HIP : WLK_ERR_STATE;
+                        j->err = e.what();
+                        finished.push_back(j);
+                    }
+            }
+            n_iterations += 1;
+            n_rows += group.size();
+        }
+        if (!finished.empty()) {
+            for (EngineJob* j : finished) active.erase(std::remove(active.begin(), active.end(), j), active.end());
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                for (EngineJob* j : finished) j->done = true;
+            }
+            cv_done.notify_all();
+        }
+    }
+}
+
+// ---- lifetime -----------------------------------------------------------------------------------------------
+static wlk_engine* engine_create(wlk_model* m) {
+    const wlk_dims& D = m->D;
+    auto e = std::make_unique<wlk_engine>();
+    e->m = m;
+    int rows = 8;     // the GEMV kernels stage `bucket x K` activations in <= 64 KiB of LDS (K up to 4d)
+    while (rows > 1 && !gemv_applicable(rows, 4 * D.n_text_state)) rows /= 2;
+    e->max_rows = rows;
+    if (const char* env = std::getenv("WLK_ENGINE_MAX_ROWS")) e->max_rows = std::max(1, std::min(rows, std::atoi(env)));
+    WLK_HIP(hipSetDevice(m->device));
+    WLK_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    if (const char* g = std::getenv("WLK_NO_GRAPH")) e->use_graph = !(g[0] == '1');
+    const size_t R = 8, d = D.n_text_state, T = D.n_audio_ctx, V = D.n_vocab;
+    e->rows_dev = dev_alloc<StepRow>(R);
+    e->x = dev_alloc<float>(R * d);
+    e->qkv = dev_alloc<float>(R * 3 * d);
+    e->att = dev_alloc<float>(R * d);
+    e->q = dev_alloc<float>(R * d);
+    e->mlp = dev_alloc<float>(R * 4 * d);
+    e->logits = dev_alloc<float>(R * V);
+    e->xsplit = dev_alloc<float>(cross_split_scratch_floats(8, D.n_text_head, (int)T));
+    e->z = dev_alloc<float>(R * std::max(m->n_align, 1) * T);
+    e->attn_last = dev_alloc<float>(R * T);
+    e->res_dev = dev_alloc<float>(R * 5);
+    WLK_HIP(hipMalloc(&e->topk_scratch, topk_scratch_bytes((int)R)));
+    e->adj_dev = dev_alloc<int>(3 * (size_t)kEngineAdjCap);
+    WLK_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->pinned), wlk_engine::kPinnedBytes, hipHostMallocDefault));
+    WLK_HIP(hipStreamSynchronize(e->stream));
+    wlk_engine* raw = e.release();
+    raw->worker = std::thread([raw] { raw->run(); });
+    return raw;
+}
+
+void wlk_engine_destroy_for_model(wlk_model* m) {
+    wlk_engine* e = m->engine;
+    if (!e) return;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        e->quit = true;
+    }
+    e->cv_work.notify_all();
+    if (e->worker.joinable()) e->worker.join();
+    (void)hipSetDevice(m->device);
+    float* fl[] = {e->x, e->qkv, e->att, e->q, e->mlp, e->logits, e->xsplit, e->z, e->attn_last, e->res_dev};
+    for (float* p : fl)
+        if (p) (void)hipFree(p);
+    if (e->rows_dev) (void)hipFree(e->rows_dev);
+    if (e->topk_scratch) (void)hipFree(e->topk_scratch);
+    if (e->adj_dev) (void)hipFree(e->adj_dev);
+    if (e->pinned) (void)hipHostFree(e->pinned);
+    for (auto& g : e->step_exec)
+        if (g) (void)hipGraphExecDestroy(g);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    m->engine = nullptr;
+}
+
+// the rest of a decode loop (after its prefill step) on the engine; blocks the calling thread until the loop stops
+int wlk_engine_run_job(wlk_session* s, DecodeJob* job) {
+    wlk_engine* e = s->engine;
+    EngineJob ej;
+    ej.s = s;
+    ej.job = job;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        e->submitted.push_back(&ej);
+    }
+    e->cv_work.notify_one();
+    {
+        std::unique_lock<std::mutex> lk(e->mu);
+        e->cv_done.wait(lk, [&] { return ej.done; });
+    }
+    if (ej.rc != WLK_OK) set_last_error(ej.err);
+    return ej.rc;
+}
+
+bool wlk_engine_wants(const wlk_session* s) {
+    // a loop that is alone on this GPU stays on the calling thread (nothing to batch with, no hand-off latency); it is
+    // asked again after every step, so it moves over as soon as a second loop shows up
+    return s->engine && s->engine->in_loop.load(std::memory_order_relaxed) > 1 && !s->debug && !s->prof_on && s->beam == 1;
+}
+
+void wlk_engine_loop_enter(wlk_session* s) {
+    if (s->engine) s->engine->in_loop.fetch_add(1, std::memory_order_relaxed);
+}
+void wlk_engine_loop_exit(wlk_session* s) {
+    if (s->engine) s->engine->in_loop.fetch_sub(1, std::memory_order_relaxed);
+}
+
+extern "C" {
+
+int wlk_engine_attach(wlk_session* s) {
+    if (!s) return fail(WLK_ERR_ARG, "session is NULL");
+    if (s->beam != 1) return fail(WLK_ERR_ARG, "only beam-1 sessions can share batched decode steps");
+    if (s->engine) return WLK_OK;
+    return guarded([&]() {
+        wlk_model* m = s->m;
+        std::lock_guard<std::mutex> lk(m->engine_mu);
+        if (!m->engine) m->engine = engine_create(m);
+        {
+            std::lock_guard<std::mutex> lk2(m->engine->mu);
+            m->engine->attached += 1;
+        }
+        s->engine = m->engine;
+        return WLK_OK;
+    });
+}
+
+int wlk_engine_detach(wlk_session* s) {
+    if (!s) return fail(WLK_ERR_ARG, "session is NULL");
+    if (!s->engine) return WLK_OK;
+    {
+        std::lock_guard<std::mutex> lk(s->engine->mu);
+        s->engine->attached -= 1;
+    }
+    s->engine = nullptr;
+    return WLK_OK;
+}
+
+int wlk_engine_stats(wlk_model* m, uint64_t* iterations, uint64_t* rows, uint64_t* batched_steps, uint64_t* batched_rows) {
+    if (!m) return fail(WLK_ERR_ARG, "model is NULL");
+    std::lock_guard<std::mutex> lk(m->engine_mu);
+    wlk_engine* e = m->engine;
+    if (iterations) *iterations = e ? e->n_iterations : 0;
+    if (rows) *rows = e ? e->n_rows : 0;
+    if (batched_steps) *batched_steps = e ? e->n_batched : 0;
+    if (batched_rows) *batched_rows = e ? e->n_batched_rows : 0;
+    return WLK_OK;
+}
+
+}  // extern "C"

@@ -518,7 +518,12 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
                 if (g.flags & kGemmSwish) v = v / (1.0f + expf(-v));
                 if (g.flags & kGemmResidual) v += g.R[(long)m * g.ldr + n];
                 g.C[(long)m * g.ldc + n] = v;
-                if (g.kcache && n >= g.kv_d) {
+                if (g.kv_rows && n >= g.kv_d) {          // batched steps: every row has its own cache
+                    const StepRow sr = g.kv_rows[m];
+                    const long at = g.kv_layer_off + (long)sr.offset * g.kv_d;
+                    if (n < 2 * g.kv_d) sr.kcache[at + n - g.kv_d] = v;
+                    else sr.vcache[at + n - 2 * g.kv_d] = v;
+                } else if (g.kcache && n >= g.kv_d) {
                     const long at = ((long)m * g.kv_ctx + *g.kv_pos) * g.kv_d;
                     if (n < 2 * g.kv_d) g.kcache[at + n - g.kv_d] = v;
                     else g.vcache[at + n - 2 * g.kv_d] = v;
@@ -689,7 +694,7 @@ void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     KernelScope ks(ctx, tag, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
     if (g.mg_pm && !(g.M == 1 && g.K <= 2048 && rpw <= 2 && gemv1_enabled() && !g.ln_gamma))
         throw std::invalid_argument("gemv: the merged cross-attention operand needs the single-row kernel");
-    if (g.M == 1 && g.K <= 2048 && rpw <= 2 && gemv1_enabled()) {
+    if (g.M == 1 && g.K <= 2048 && rpw <= 2 && gemv1_enabled() && !g.kv_rows) {
         const int ub = (g.K / 4 + 63) / 64;
         blocks += g.mg_pm ? g.mg_side_blocks : 0;
 #define WLK_GEMV1(UBv)                                                                                             \

@@ -1,0 +1,203 @@
+// Internal object layouts shared by the C-ABI files (api.hip, engine.hip): the model, the per-stream session and the
+// small helpers around them.  Not part of the public interface (include/wlk_hip.h keeps both types opaque).
+#pragma once
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/wlk_hip.h"
+#include "common.h"
+
+namespace wlk {
+
+const std::string& get_last_error();
+
+template <typename F>
+inline int guarded(F&& f) {
+    try {
+        return f();
+    } catch (const HipError& e) {
+        set_last_error(e.what());
+        return WLK_ERR_HIP;
+    } catch (const std::invalid_argument& e) {
+        set_last_error(e.what());
+        return WLK_ERR_ARG;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return WLK_ERR_STATE;
+    }
+}
+inline int fail(int code, const std::string& msg) {
+    set_last_error(msg);
+    return code;
+}
+
+
+// profiler: HIP events around every launch on the session stream
+struct Profiler {
+    struct Rec {
+        const char* name;
+        hipEvent_t a, b;
+        double flops, bytes;
+    };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t pending = nullptr;
+    const char* pending_name = nullptr;
+    double pending_flops = 0.0, pending_bytes = 0.0;
+    hipEvent_t get() {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        WLK_HIP(hipEventCreate(&e));
+        return e;
+    }
+};
+
+struct TensorSlot {
+    std::string name;
+    uint64_t offset, numel;
+};
+
+
+struct LayerW {
+    const float *ln1w, *ln1b, *qkvw, *qkvb, *outw, *outb, *ln2w, *ln2b, *fc1w, *fc1b, *fc2w, *fc2b;
+    const float *lnxw = nullptr, *lnxb = nullptr, *xqw = nullptr, *xqb = nullptr, *xkvw = nullptr, *xkvb = nullptr,
+                *xoutw = nullptr, *xoutb = nullptr;
+};
+
+template <typename T>
+inline T* dev_alloc(size_t n) {
+    T* p = nullptr;
+    WLK_HIP(hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));
+    return p;
+}
+template <typename T>
+inline T* dev_alloc_zero(size_t n, hipStream_t s) {
+    T* p = dev_alloc<T>(n);
+    WLK_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
+    return p;
+}
+
+}  // namespace wlk
+
+struct wlk_engine;
+
+// ------------------------------------------------------------------------------------------------
+// model
+// ------------------------------------------------------------------------------------------------
+struct wlk_model {
+    wlk_dims D{};
+    int device = 0;
+    float* arena = nullptr;
+    bool owns_arena = false;
+    uint64_t arena_floats = 0;
+    std::vector<wlk::TensorSlot> slots;
+    std::map<std::string, const wlk::TensorSlot*> by_name;
+    double* twiddle = nullptr;        // [400] fp64 cos table
+    // cross-attention k|v projections of ALL decoder layers side by side ([L*2d, d] and [L*2d]; copies of the
+    // arena's per-layer tensors made by wlk_model_finalize): one GEMM per encode instead of L
+    float* xkv_all_w = nullptr;
+    float* xkv_all_b = nullptr;
+    int* filt_lo = nullptr;           // [n_mels]
+    int* filt_hi = nullptr;
+    int* head_rank = nullptr;         // [L][H] alignment rank or -1
+    int* layer_ranks = nullptr;       // [L][H] ranks of each layer's alignment heads, compacted
+    std::vector<int> layer_rank_count;
+    std::vector<int> align_pairs;     // (layer, head)*
+    int n_align = 0;
+    bool finalized = false;
+    std::vector<wlk::LayerW> enc_layers, dec_layers;   // resolved once at finalize
+    const float *w_tok_emb = nullptr, *w_dec_pos = nullptr, *w_ln_w = nullptr, *w_ln_b = nullptr;
+    wlk_engine* engine = nullptr;     // cross-session batched decode steps (engine.hip), created on first attach
+    std::mutex engine_mu;
+
+    const float* w(const std::string& name) const {
+        auto it = by_name.find(name);
+        if (it == by_name.end()) throw std::invalid_argument("unknown tensor " + name);
+        return arena + it->second->offset;
+    }
+};
+
+
+// ------------------------------------------------------------------------------------------------
+// session
+// ------------------------------------------------------------------------------------------------
+struct wlk_session {
+    wlk_model* m = nullptr;
+    int beam = 1;
+    int audio_cap = 0;
+    hipStream_t stream = nullptr;
+    wlk::Profiler prof;
+    bool prof_on = false;
+    bool debug = false;
+    bool use_graph = true;
+    hipGraphExec_t step_exec[2] = {nullptr, nullptr};   // single-token decode step, per KV buffer
+    int enc_ksplit = 1;                                 // key split of the encoder attention (WLK_ENC_KSPLIT)
+    float* esplit = nullptr;
+    short* pcm16_dev = nullptr;                         // staging of wlk_audio_append_pcm16 (lazily allocated)
+
+    // audio (two buffers: eviction copies the tail into the other one)
+    float* audio[2] = {nullptr, nullptr};
+    int audio_cur = 0;
+    int audio_len = 0;
+
+    // mel + encoder workspaces
+    float *logmel = nullptr, *frame_max = nullptr, *mel_t = nullptr;
+    int frame_cap = 0;
+    float *x1p = nullptr, *ex = nullptr, *eh = nullptr, *eqkv = nullptr, *eatt = nullptr, *emlp = nullptr,
+          *enc_out = nullptr, *cross_kv = nullptr;
+    bool encoded = false;
+    int content_len = 0;
+
+    // decoder workspaces
+    int max_rows = 0;
+    int* tokens_dev = nullptr;
+    float *dx = nullptr, *dh = nullptr, *dqkv = nullptr, *datt = nullptr, *dq = nullptr, *dmlp = nullptr;
+    float* kcache[2] = {nullptr, nullptr};  // [L][beam][ctx][d]; second pair allocated on first reorder
+    float* vcache[2] = {nullptr, nullptr};
+    int kv_cur = 0;
+    int self_len = 0;
+    int n_steps = 0;
+    int prefill_rows = 0;
+    int last_rows = 0, last_ntok = 0;
+    float *hsel = nullptr, *logits_last = nullptr, *logits_sot = nullptr;
+    bool have_sot = false;
+    int* step_in = nullptr;      // [tokens max_rows | ring_row max_rows | beam_of_row max_rows | offset]: ONE H2D per decode
+    int *ring_row = nullptr, *beam_of_row = nullptr, *d_offset = nullptr;   // views into step_in
+    float* ring = nullptr;
+    int ring_rows = 0;
+    float *z = nullptr, *attn_last = nullptr;
+    float* qk_debug = nullptr;  // [L][max_rows][H][T]
+    float* xsplit = nullptr;    // scratch of the split cross-attention (decode steps)
+    float* fsplit = nullptr;    // scratch of the key-split flash attention (decoder prefill)
+    static constexpr int kFlashSplits = 6;
+
+    // select scratch (device) + pinned host staging
+    int *adj_row = nullptr, *src_rows = nullptr;   // adj_row: packed [rows | ids | deltas] of the current call
+    float* top_vals = nullptr;
+    void* topk_scratch = nullptr;
+    int *top_ids = nullptr, *frames = nullptr;
+    float* probs = nullptr;
+    static constexpr int kAdjCap = 4096;
+    void* pinned = nullptr;  // 1 MiB
+    static constexpr size_t kPinnedBytes = 1 << 20;
+
+    wlk::LaunchCtx ctx() { return wlk::LaunchCtx{stream, prof_on ? &prof : nullptr}; }
+    wlk_engine* engine = nullptr;   // set by wlk_engine_attach: single-token steps run batched with the other attached sessions
+};
+
+
+// engine.hip
+namespace wlk { struct DecodeJob; }
+void wlk_engine_destroy_for_model(wlk_model* m);
+bool wlk_engine_wants(const wlk_session* s);
+void wlk_engine_loop_enter(wlk_session* s);
+void wlk_engine_loop_exit(wlk_session* s);
+int wlk_engine_run_job(wlk_session* s, wlk::DecodeJob* job);   // blocks until the job's loop has stopped

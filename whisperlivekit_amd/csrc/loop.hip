@@ -16,6 +16,7 @@
 
 #include "../../include/wlk_hip.h"
 #include "common.h"
+#include "internal.h"
 #include "loop.h"
 
 namespace wlk {
@@ -243,9 +244,15 @@ int wlk_decode_until_stop(wlk_session* s, const int64_t* tokens, int n_tok, cons
                           float* step_sum_logprobs, int cap) {
     if (!s) return loop_fail(WLK_ERR_ARG, "decode loop: session is NULL");
     if (int rc = check_loop_args(p, tokens, n_tok, suppress_ids, n_suppress, blank_ids, n_blank)) return rc;
+    if (s->beam != 1) return loop_fail(WLK_ERR_ARG, "decode loop: the session's beam must be 1");
     DecodeJob job(*p, tokens, n_tok, suppress_ids, n_suppress, blank_ids, n_blank);
     std::vector<int32_t> ids, rows;
     std::vector<float> deltas;
+    struct InLoop {   // the engine counts the loops in flight on this GPU (see wlk_engine_wants)
+        wlk_session* s;
+        explicit InLoop(wlk_session* ss) : s(ss) { wlk_engine_loop_enter(s); }
+        ~InLoop() { wlk_engine_loop_exit(s); }
+    } in_loop(s);
     while (job.begin_step()) {
         const bool first = job.fresh;
         const int64_t* feed = first ? job.seq.data() : job.seq.data() + job.seq.size() - 1;
@@ -263,6 +270,12 @@ int wlk_decode_until_stop(wlk_session* s, const int64_t* tokens, int n_tok, cons
                                 &frame))
             return rc;
         if (!job.consume(lp, top, frame)) break;
+        if (wlk_engine_wants(s)) {
+            // the prefill is done: the single-token steps of this loop advance together with the loops of the other
+            // sessions of this GPU (engine.hip); returns when this loop has stopped
+            if (int rc = wlk_engine_run_job(s, &job)) return rc;
+            break;
+        }
     }
     return copy_result(job, result, new_tokens, step_tokens, step_frames, step_sum_logprobs, cap);
 }

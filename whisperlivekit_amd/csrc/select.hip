@@ -202,7 +202,14 @@ __global__ __launch_bounds__(256) void align_zscore_kernel(AlignArgs a) {
     const int f = blockIdx.x * 64 + fx;
     const int al = blockIdx.y, b = blockIdx.z;
     const bool ok = f < a.T;
-    const float* base = a.ring + ((long)(al * a.n_beam + b) * a.ring_rows) * a.T + (ok ? f : 0);
+    if (a.rows) {                // batched steps: row b is a session of its own (one beam)
+        const StepRow sr = a.rows[b];
+        a.prefill_rows = sr.prefill_rows;
+        a.n_single = sr.n_single;
+        a.newest_row = sr.newest_row;
+    }
+    const float* base = a.rows ? a.rows[b].ring + ((long)al * a.ring_rows) * a.T + (ok ? f : 0)
+                               : a.ring + ((long)(al * a.n_beam + b) * a.ring_rows) * a.T + (ok ? f : 0);
     const int n = a.prefill_rows + a.n_single;
     auto row_of = [&](int i) { return i < a.prefill_rows ? i : a.single_base + (i - a.prefill_rows); };
     double sum = 0.0;
@@ -249,6 +256,7 @@ __global__ __launch_bounds__(256) void align_argmax_kernel(AlignArgs a) {
     __shared__ int besti[256];
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
+    if (a.rows) a.content_len = a.rows[b].content_len;
     const float* zb = a.z + (long)b * a.n_align * a.T;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
@@ -292,6 +300,7 @@ __global__ __launch_bounds__(1024) void align_argmax_lds_kernel(AlignArgs a) {
     __shared__ int besti[1024];
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
+    if (a.rows) a.content_len = a.rows[b].content_len;
     const float* zb = a.z + (long)b * a.n_align * a.T;
     for (int i = tid; i < a.n_align * a.T; i += 1024) zs[i] = zb[i];
     __syncthreads();
@@ -329,6 +338,12 @@ __global__ __launch_bounds__(1024) void align_argmax_lds_kernel(AlignArgs a) {
     if (tid == 0) a.frames[b] = besti[0] == 0x7fffffff ? 0 : besti[0];
 }
 
+void launch_alignatt_rows(const LaunchCtx& ctx, const AlignArgs& a0, const StepRow* rows) {
+    AlignArgs a = a0;
+    a.rows = rows;
+    launch_alignatt(ctx, a);
+}
+
 void launch_alignatt(const LaunchCtx& ctx, const AlignArgs& a) {
     if (a.n_align <= 0) {
         WLK_HIP(hipMemsetAsync(a.frames, 0, sizeof(int) * a.n_beam, ctx.stream));
@@ -336,7 +351,7 @@ void launch_alignatt(const LaunchCtx& ctx, const AlignArgs& a) {
         return;
     }
     {
-        const int n = a.prefill_rows + a.n_single;
+        const int n = a.rows ? kAlignWindow : a.prefill_rows + a.n_single;
         KernelScope ks(ctx, "align_zscore", 0.0, 4.0 * 2.0 * n * (double)a.n_align * a.T * a.n_beam);
         hipLaunchKernelGGL(align_zscore_kernel, dim3((a.T + 63) / 64, a.n_align, a.n_beam), dim3(256), 0,
                            ctx.stream, a);

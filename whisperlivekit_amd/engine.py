@@ -4,6 +4,7 @@ weights, shared by every session on that GPU) and one :class:`HipSession` per au
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Iterable, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
@@ -173,8 +174,23 @@ class HipWhisperModel:
     def num_languages(self) -> int:
         return self.dims.num_languages
 
-    def new_session(self, beam: int = 1, max_audio_seconds: float = 64.0) -> "HipSession":
-        return HipSession(self, beam, int(max_audio_seconds * 16000))
+    def new_session(self, beam: int = 1, max_audio_seconds: float = 64.0, batched: Optional[bool] = None) -> "HipSession":
+        """``batched`` (default: on for beam 1 unless WLK_BATCH_DECODE=0): the session's decode loops share batched
+        single-token steps with the other sessions of this GPU (wlk_engine_attach)."""
+        s = HipSession(self, beam, int(max_audio_seconds * 16000))
+        if batched is None:
+            batched = beam == 1 and os.environ.get("WLK_BATCH_DECODE", "1") != "0"
+        if batched:
+            s.attach_engine()
+        return s
+
+    def engine_stats(self) -> Dict[str, int]:
+        """Iterations of this GPU's batch engine and the rows (= session steps) advanced in them."""
+        v = [C.c_uint64() for _ in range(4)]
+        _lib.check(self.lib.wlk_engine_stats(self._h, *[C.byref(x) for x in v]))
+        it, rows, bs, br = (int(x.value) for x in v)
+        return dict(iterations=it, rows=rows, batched_steps=bs, batched_rows=br,
+                    mean_rows_per_batched_step=round(br / bs, 3) if bs else None)
 
     def close(self) -> None:
         if self._h:
@@ -292,6 +308,12 @@ class HipSession:
         _lib.check(self.lib.wlk_decode_until_stop(self._h, vp(t), t.size, C.byref(params), vp(sup), sup.size, vp(blank),
                                                   blank.size, C.byref(res), vp(new), vp(st), vp(sf), vp(ss), cap))
         return LoopOutcome(res, new, st, sf, ss)
+
+    def attach_engine(self) -> None:
+        _lib.check(self.lib.wlk_engine_attach(self._h))
+
+    def detach_engine(self) -> None:
+        _lib.check(self.lib.wlk_engine_detach(self._h))
 
     def kv_reorder(self, source_rows: Sequence[int]) -> None:
         s = np.asarray(source_rows, dtype=np.int32)
