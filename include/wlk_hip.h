@@ -177,6 +177,9 @@ int wlk_decode_until_stop(wlk_session* s, const int64_t* tokens, int n_tok, cons
  * them; per-row arithmetic and its order are those of a session running alone).  Beam-1 sessions only. */
 int wlk_engine_attach(wlk_session* s);
 int wlk_engine_detach(wlk_session* s);
+/* encode launch chains run by the engine and the sessions encoded in them (concurrent wlk_encode calls of attached
+ * sessions are stacked: one launch per encoder operator with grid.y = sessions, shared weights) */
+int wlk_engine_encode_stats(wlk_model* m, uint64_t* batches, uint64_t* sessions);
 /* engine iterations, rows advanced in them, and the batched (>= 2 rows) iterations / rows among those */
 int wlk_engine_stats(wlk_model* m, uint64_t* iterations, uint64_t* rows, uint64_t* batched_steps, uint64_t* batched_rows);
 /* The host half of that loop without a GPU (integer logic only), for harnesses that supply the numerics themselves:
@@ -288,11 +291,16 @@ const char* wlk_diag_last_error(void);
 int wlk_diag_linear(const float* a, int64_t lda, int64_t a_floats, const float* w, const float* bias,
                     const float* r, int64_t ldr, int m, int n, int k, int flags, float scale, int scale_cols,
                     int force_gemv, float* c);
+/* kernel-tuning probe: average microseconds per launch over `reps` back-to-back launches of one linear layer on
+ * device-resident pseudo-random operands (same `force_gemv` meaning as wlk_diag_linear) */
+int wlk_diag_linear_time(int m, int n, int k, int flags, int force_gemv, int reps, float* us_per_launch);
 /* c[m,n] = LayerNorm(a[m,k]; gamma, beta, eps 1e-5) . w[n,k]^T + bias, m <= 8: the fused pre-LN projections
  * of the decode-step (weight-streaming) path */
 int wlk_diag_linear_ln(const float* a, const float* w, const float* bias, const float* gamma, const float* beta,
                        int m, int n, int k, int force_gemv, float* c);
 int wlk_diag_layernorm(const float* x, const float* gamma, const float* beta, int rows, int d, float* y);
+/* kernel-tuning probe: average microseconds per encoder self-attention launch (pseudo-random qkv, k_splits key ranges) */
+int wlk_diag_encoder_attention_time(int t, int d, int n_head, int k_splits, int reps, float* us_per_launch);
 /* qkv [t, 3d] with q and k pre-scaled -> softmax(q k^T) v per 64-wide head, out [t, d] */
 int wlk_diag_encoder_attention(const float* qkv, int t, int d, int n_head, float* out);
 

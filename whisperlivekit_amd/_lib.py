@@ -86,6 +86,7 @@ def _declare(lib: C.CDLL) -> None:
                                          p, p, p, p, cint]),
         "wlk_engine_attach": (cint, [p]),
         "wlk_engine_detach": (cint, [p]),
+        "wlk_engine_encode_stats": (cint, [p, C.POINTER(u64), C.POINTER(u64)]),
         "wlk_engine_stats": (cint, [p, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
         "wlk_job_create": (cint, [C.POINTER(LoopParams), p, cint, p, cint, p, cint, C.POINTER(p)]),
         "wlk_job_begin_step": (cint, [p, C.POINTER(i32)]),
@@ -122,8 +123,10 @@ def _declare(lib: C.CDLL) -> None:
         "wlk_diag_last_error": (C.c_char_p, []),
         "wlk_diag_linear": (cint, [p, C.c_int64, C.c_int64, p, p, p, C.c_int64, cint, cint, cint, cint, C.c_float,
                                    cint, cint, p]),
+        "wlk_diag_linear_time": (cint, [cint, cint, cint, cint, cint, cint, C.POINTER(C.c_float)]),
         "wlk_diag_linear_ln": (cint, [p, p, p, p, p, cint, cint, cint, cint, p]),
         "wlk_diag_layernorm": (cint, [p, p, p, cint, cint, p]),
+        "wlk_diag_encoder_attention_time": (cint, [cint, cint, cint, cint, cint, C.POINTER(C.c_float)]),
         "wlk_diag_encoder_attention": (cint, [p, cint, cint, cint, p]),
     }
     for name, (res, args) in sig.items():
@@ -139,7 +142,7 @@ EXPORTED_SYMBOLS = (
     "wlk_session_destroy", "wlk_session_set_debug", "wlk_audio_append", "wlk_audio_append_pcm16", "wlk_audio_append_zeros",
     "wlk_audio_drop_front", "wlk_audio_clear", "wlk_audio_len", "wlk_encode", "wlk_decode",
     "wlk_no_speech_prob", "wlk_select", "wlk_kv_reorder", "wlk_sync", "wlk_decode_until_stop", "wlk_engine_attach", "wlk_engine_detach",
-    "wlk_engine_stats", "wlk_job_create",
+    "wlk_engine_stats", "wlk_engine_encode_stats", "wlk_job_create",
     "wlk_job_begin_step", "wlk_job_no_speech", "wlk_job_adjustments", "wlk_job_consume", "wlk_job_result",
     "wlk_job_destroy", "wlk_export", "wlk_prof_begin",
     "wlk_prof_end", "wlk_melspec_create", "wlk_melspec_run", "wlk_melspec_destroy",
@@ -148,8 +151,8 @@ EXPORTED_SYMBOLS = (
     "wlk_vad_weights_floats", "wlk_vad_tensor_lookup", "wlk_vad_tensor_name", "wlk_vad_create", "wlk_vad_destroy",
     "wlk_vad_stream_create", "wlk_vad_stream_reset", "wlk_vad_stream_run", "wlk_vad_stream_state",
     "wlk_vad_stream_destroy",
-    "wlk_diag_last_error", "wlk_diag_linear", "wlk_diag_linear_ln", "wlk_diag_layernorm",
-    "wlk_diag_encoder_attention",
+    "wlk_diag_last_error", "wlk_diag_linear", "wlk_diag_linear_time", "wlk_diag_linear_ln", "wlk_diag_layernorm",
+    "wlk_diag_encoder_attention", "wlk_diag_encoder_attention_time",
 )
 
 

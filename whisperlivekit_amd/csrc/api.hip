@@ -552,21 +552,26 @@ static void transformer_mlp(const LaunchCtx& c, const LayerW& L, float* x, float
     launch_linear(c, g2, t_fc2);
 }
 
-int wlk_encode(wlk_session* s, int32_t* content_mel_len) {
-    if (!s) return fail(WLK_ERR_ARG, "session is NULL");
-    return guarded([&]() {
-        wlk_model* m = s->m;
-        const wlk_dims& D = m->D;
-        WLK_HIP(hipSetDevice(m->device));
-        const LaunchCtx c = s->ctx();
+// One encode of every session of `group` (1..kMaxBatch sessions of one model) as ONE launch chain: the log-mel of each
+// session (its own kernels: the frame counts differ), then every encoder operator once with grid.y = sessions - shared
+// weights, per-session activation buffers through pointer tables.  A group of one is the plain per-session encode.
+extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const LaunchCtx& c,
+                                   std::vector<int>& content_out) {
+    const int B = (int)group.size();
+    if (B < 1 || B > kMaxBatch) throw std::invalid_argument("encode: bad group size");
+    wlk_model* m = group[0]->m;
+    const wlk_dims& D = m->D;
+    const int d = D.n_audio_state, T = D.n_audio_ctx;
+    content_out.assign(B, 0);
+    for (int i = 0; i < B; ++i) {
+        wlk_session* s = group[i];
+        if (s->m != m) throw std::invalid_argument("encode: sessions of different models in one group");
         const int N = s->audio_len;
         const int n_total = (N + kPadSamples) / kHop;               // stft frames minus the dropped last one
         int n_active = N > 0 ? (N + kNFft / 2 + kHop - 1) / kHop : 0;  // frames that see a non-zero sample
         if (n_active > n_total) n_active = n_total;
-        if (n_active > s->frame_cap) return fail(WLK_ERR_CAPACITY, "audio longer than the session's frame capacity");
-        const int content = (n_total - kMelFrames) / 2;
-        const int d = D.n_audio_state, T = D.n_audio_ctx;
-
+        if (n_active > s->frame_cap) throw std::length_error("audio longer than the session's frame capacity");
+        content_out[i] = (n_total - kMelFrames) / 2;
         MelArgs ma;
         ma.audio = s->audio[s->audio_cur]; ma.n_samples = N;
         ma.window = m->w("mel.window"); ma.twiddle = m->twiddle; ma.filters = m->w("mel.filters");
@@ -574,47 +579,112 @@ int wlk_encode(wlk_session* s, int32_t* content_mel_len) {
         ma.logmel = s->logmel; ma.frame_max = s->frame_max; ma.mel_t = s->mel_t;
         ma.n_active = n_active; ma.n_total = n_total;
         launch_mel(c, ma);
-
-        {   // conv1 (k=3, pad=1) + GELU: rows of A overlap (lda = n_mels < K = 3 n_mels)
-            GemmArgs g;
-            g.A = s->mel_t; g.lda = D.n_mels; g.W = m->w("enc.conv1.w"); g.bias = m->w("enc.conv1.b");
-            g.C = s->x1p + d; g.ldc = d; g.M = kMelFrames; g.N = d; g.K = 3 * D.n_mels; g.flags = kGemmGelu;
-            launch_gemm(c, g, "enc_conv1");
+    }
+    auto table = [&](auto in, auto out, auto res) {
+        PtrTable z{};
+        for (int i = 0; i < B; ++i) {
+            z.in[i] = in(group[i]);
+            z.out[i] = out(group[i]);
+            z.res[i] = res(group[i]);
         }
-        {   // conv2 (k=3, stride=2, pad=1) + GELU + positional embedding
-            GemmArgs g;
-            g.A = s->x1p; g.lda = 2 * d; g.W = m->w("enc.conv2.w"); g.bias = m->w("enc.conv2.b");
-            g.C = s->ex; g.ldc = d; g.M = T; g.N = d; g.K = 3 * d; g.flags = kGemmGelu | kGemmResidual;
-            g.R = m->w("enc.pos"); g.ldr = d;
-            launch_gemm(c, g, "enc_conv2");
+        return z;
+    };
+    auto none = [](wlk_session*) -> const float* { return nullptr; };
+    auto gemm = [&](GemmArgs g, const PtrTable& z, const char* tag) {
+        const bool stackable = !gemm_takes_kwave(g.M, g.N, g.K) && (long)((g.N + 63) / 64) * ((g.M + 63) / 64) >= 64;
+        if (stackable) {
+            g.batch = B;
+            g.z = z;
+            launch_gemm(c, g, tag);
+        } else {                     // narrow models (test shapes): the small-grid kernels take one session at a time
+            for (int i = 0; i < B; ++i) {
+                g.A = z.in[i]; g.C = z.out[i]; g.R = z.res[i];
+                launch_gemm(c, g, tag);
+            }
         }
-        const float scale = std::pow((float)kHeadDim, -0.25f);
-        for (int i = 0; i < D.n_audio_layer; ++i) {
-            const LayerW& L = m->enc_layers[i];
-            launch_layernorm(c, s->ex, d, L.ln1w, L.ln1b, s->eh, d, T, d, "enc_ln1");
-            GemmArgs g;
-            g.A = s->eh; g.lda = d; g.W = L.qkvw; g.bias = L.qkvb; g.C = s->eqkv; g.ldc = 3 * d; g.M = T; g.N = 3 * d;
-            g.K = d; g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = 2 * d;
-            launch_gemm(c, g, "enc_qkv");
-            launch_encoder_attention(c, s->eqkv, s->eatt, T, d, D.n_audio_head, s->enc_ksplit, s->esplit);
-            GemmArgs o;
-            o.A = s->eatt; o.lda = d; o.W = L.outw; o.bias = L.outb; o.C = s->ex; o.ldc = d; o.M = T; o.N = d; o.K = d;
-            o.flags = kGemmResidual; o.R = s->ex; o.ldr = d;
-            launch_gemm(c, o, "enc_out");
-            transformer_mlp(c, L, s->ex, s->eh, s->emlp, T, d, "enc_ln2", "enc_fc1", "enc_fc2");
-        }
-        launch_layernorm(c, s->ex, d, m->w("enc.ln_post.w"), m->w("enc.ln_post.b"), s->enc_out, d, T, d, "enc_ln_post");
-        {   // cross-attention K (scaled) and V of every decoder layer in ONE GEMM: cross_kv is [T][L][k | v]
-            GemmArgs g;
-            g.A = s->enc_out; g.lda = d; g.W = m->xkv_all_w; g.bias = m->xkv_all_b; g.C = s->cross_kv;
-            g.ldc = (long)D.n_text_layer * 2 * d; g.M = T; g.N = D.n_text_layer * 2 * d; g.K = d;
-            g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = d; g.scale_period = 2 * d;
-            launch_gemm(c, g, "dec_cross_kv");
-        }
+    };
+    {   // conv1 (k=3, pad=1) + GELU: rows of A overlap (lda = n_mels < K = 3 n_mels)
+        GemmArgs g;
+        g.lda = D.n_mels; g.W = m->w("enc.conv1.w"); g.bias = m->w("enc.conv1.b");
+        g.ldc = d; g.M = kMelFrames; g.N = d; g.K = 3 * D.n_mels; g.flags = kGemmGelu;
+        gemm(g, table([](wlk_session* s) { return (const float*)s->mel_t; }, [&](wlk_session* s) { return s->x1p + d; }, none),
+             "enc_conv1");
+    }
+    {   // conv2 (k=3, stride=2, pad=1) + GELU + positional embedding
+        const float* pos = m->w("enc.pos");
+        GemmArgs g;
+        g.lda = 2 * d; g.W = m->w("enc.conv2.w"); g.bias = m->w("enc.conv2.b");
+        g.ldc = d; g.M = T; g.N = d; g.K = 3 * d; g.flags = kGemmGelu | kGemmResidual; g.ldr = d;
+        gemm(g, table([](wlk_session* s) { return (const float*)s->x1p; }, [](wlk_session* s) { return s->ex; },
+                      [&](wlk_session*) { return pos; }), "enc_conv2");
+    }
+    const float scale = std::pow((float)kHeadDim, -0.25f);
+    const PtrTable z_ex_eh = table([](wlk_session* s) { return (const float*)s->ex; }, [](wlk_session* s) { return s->eh; }, none);
+    const PtrTable z_eh_qkv = table([](wlk_session* s) { return (const float*)s->eh; }, [](wlk_session* s) { return s->eqkv; }, none);
+    const PtrTable z_qkv_att = table([](wlk_session* s) { return (const float*)s->eqkv; }, [](wlk_session* s) { return s->eatt; }, none);
+    const PtrTable z_att_ex = table([](wlk_session* s) { return (const float*)s->eatt; }, [](wlk_session* s) { return s->ex; },
+                                    [](wlk_session* s) { return (const float*)s->ex; });
+    const PtrTable z_eh_mlp = table([](wlk_session* s) { return (const float*)s->eh; }, [](wlk_session* s) { return s->emlp; }, none);
+    const PtrTable z_mlp_ex = table([](wlk_session* s) { return (const float*)s->emlp; }, [](wlk_session* s) { return s->ex; },
+                                    [](wlk_session* s) { return (const float*)s->ex; });
+    for (int i = 0; i < D.n_audio_layer; ++i) {
+        const LayerW& L = m->enc_layers[i];
+        launch_layernorm_batched(c, z_ex_eh, B, d, L.ln1w, L.ln1b, d, T, d, "enc_ln1");
+        GemmArgs g;
+        g.lda = d; g.W = L.qkvw; g.bias = L.qkvb; g.ldc = 3 * d; g.M = T; g.N = 3 * d;
+        g.K = d; g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = 2 * d;
+        gemm(g, z_eh_qkv, "enc_qkv");
+        launch_encoder_attention_batched(c, z_qkv_att, B, T, d, D.n_audio_head);
+        GemmArgs o;
+        o.lda = d; o.W = L.outw; o.bias = L.outb; o.ldc = d; o.M = T; o.N = d; o.K = d;
+        o.flags = kGemmResidual; o.ldr = d;
+        gemm(o, z_att_ex, "enc_out");
+        launch_layernorm_batched(c, z_ex_eh, B, d, L.ln2w, L.ln2b, d, T, d, "enc_ln2");
+        GemmArgs f1;
+        f1.lda = d; f1.W = L.fc1w; f1.bias = L.fc1b; f1.ldc = 4 * d; f1.M = T; f1.N = 4 * d; f1.K = d; f1.flags = kGemmGelu;
+        gemm(f1, z_eh_mlp, "enc_fc1");
+        GemmArgs f2;
+        f2.lda = 4 * d; f2.W = L.fc2w; f2.bias = L.fc2b; f2.ldc = d; f2.M = T; f2.N = d; f2.K = 4 * d;
+        f2.flags = kGemmResidual; f2.ldr = d;
+        gemm(f2, z_mlp_ex, "enc_fc2");
+    }
+    launch_layernorm_batched(c, table([](wlk_session* s) { return (const float*)s->ex; }, [](wlk_session* s) { return s->enc_out; }, none),
+                             B, d, m->w("enc.ln_post.w"), m->w("enc.ln_post.b"), d, T, d, "enc_ln_post");
+    {   // cross-attention K (scaled) and V of every decoder layer in ONE GEMM: cross_kv is [T][L][k | v]
+        GemmArgs g;
+        g.lda = d; g.W = m->xkv_all_w; g.bias = m->xkv_all_b;
+        g.ldc = (long)D.n_text_layer * 2 * d; g.M = T; g.N = D.n_text_layer * 2 * d; g.K = d;
+        g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = d; g.scale_period = 2 * d;
+        gemm(g, table([](wlk_session* s) { return (const float*)s->enc_out; }, [](wlk_session* s) { return s->cross_kv; }, none),
+             "dec_cross_kv");
+    }
+    for (int i = 0; i < B; ++i) {
+        wlk_session* s = group[i];
         s->encoded = true;
-        s->content_len = content;
+        s->content_len = content_out[i];
         s->self_len = 0;
         s->n_steps = 0;
+    }
+}
+
+int wlk_encode(wlk_session* s, int32_t* content_mel_len) {
+    if (!s) return fail(WLK_ERR_ARG, "session is NULL");
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(s->m->device));
+        int content = 0;
+        struct Busy {   // the engine counts the sessions that are inside an encode or a decode loop right now
+            wlk_session* s;
+            explicit Busy(wlk_session* ss) : s(ss) { wlk_engine_loop_enter(s); }
+            ~Busy() { wlk_engine_loop_exit(s); }
+        } busy(s);
+        if (wlk_engine_batches_encodes(s)) {
+            // concurrent encodes of the sessions of this GPU are stacked into one launch chain (engine.hip)
+            if (int rc = wlk_engine_encode(s, &content)) return rc;
+        } else {
+            std::vector<int> out;
+            wlk_encode_group({s}, s->ctx(), out);
+            content = out[0];
+        }
         if (content_mel_len) *content_mel_len = content;
         return WLK_OK;
     });

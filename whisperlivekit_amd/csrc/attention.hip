@@ -18,6 +18,9 @@
 //                                                    V fetch follows) - no shuffle, no LDS round trip.
 // With S^T (keys on rows) every lane owns ONE query column, so the softmax row reductions are
 // 15 in-lane ops + one cross-half swap, and the alpha rescale is a per-lane scalar.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace wlk {
@@ -35,6 +38,12 @@ constexpr int kAttnLdsTotal = kAttnLdsFloats + QT * K_LD;            // + Q tile
 // the [H, q, 1500] QK tensor of the reference is never formed for the other heads.
 __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // batched encodes: session blockIdx.y (locals: writing into `a` would put the argument struct into scratch memory)
+    const bool batched = a.batch > 0;
+    const float* const aq = batched ? table_at(a.z.in, blockIdx.y) : a.q;
+    const float* const ak = batched ? aq + a.z_k_off : a.k;
+    const float* const av = batched ? aq + a.z_v_off : a.v;
+    float* const aout = batched ? table_at(a.z.out, blockIdx.y) : a.out;
     const int T = a.Tk;
     const int n_head = a.n_head;
     float* Ks = lds;                            // [NWAVE][KT][K_LD]
@@ -58,7 +67,7 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
     for (int i = tid; i < QT * 16; i += 256) {
         const int qr = i >> 4, c4 = i & 15;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q0 + qr < a.Tq) v = *reinterpret_cast<const float4*>(a.q + (long)(q0 + qr) * a.ldq + head * 64 + c4 * 4);
+        if (q0 + qr < a.Tq) v = *reinterpret_cast<const float4*>(aq + (long)(q0 + qr) * a.ldq + head * 64 + c4 * 4);
         *reinterpret_cast<float4*>(&Qs[qr * K_LD + c4 * 4]) = v;
     }
     const float* Qw = Qs + lq * K_LD + half * 4;
@@ -69,8 +78,8 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
     float m_run = -INFINITY, l_run = 0.f;
 
     // staging map: per iteration 128 keys x 64 floats for K and for V = 2048 float4 each, 8 per thread
-    const float* kbase = a.k + head * 64;
-    const float* vbase = a.v + head * 64;
+    const float* kbase = ak + head * a.kv_hs;
+    const float* vbase = av + head * a.kv_hs;
     // alignment-head score dump (decoder prefill only)
     const int rank = a.head_rank ? a.head_rank[head] : -1;
     float* dump = nullptr;
@@ -228,9 +237,170 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
                 acc += e * Os[(w * QT + q) * O_LD + dd];
             }
             if (a.k_splits == 1) {
-                if (qrow < a.Tq) a.out[(long)qrow * a.ldo + head * 64 + dd] = acc / L;
+                if (qrow < a.Tq) aout[(long)qrow * a.ldo + head * 64 + dd] = acc / L;
             } else if (qrow < a.Tq) {
                 // partial state of this key range: unnormalised O (relative to M), M and L
+                const long slot = ((long)qrow * n_head + head) * a.k_splits + ks;
+                a.part_o[slot * 64 + dd] = acc;
+                if (dd == 0) { a.part_m[slot] = M; a.part_l[slot] = L; }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Encoder self-attention without LDS staging ("register-fed"): the same arithmetic as flash_attention_kernel, but
+// every wave feeds its MFMAs straight from global memory.  With S^T = K Q^T the A fragment of a QK^T step is 16
+// bytes of ONE key row per lane (two lanes share a 32-byte sector, the eight steps of a tile walk the 256-byte row),
+// the A fragment of a PV step is V[key][d = lane] (two fully coalesced 128-byte segments per instruction), and the
+// Q fragments (B operand of QK^T) are loop invariant and live in 32 registers.  No K/V tile ever enters LDS, so the
+// main loop has NO barrier: the four waves of a workgroup run their key tiles independently (the next tile's K is
+// requested at the start of the PV phase, the tile's own V at the start of its QK^T phase - a 2048-cycle head start
+// on a ~500-cycle L2 hit), ~150 VGPRs give three waves per SIMD, and LDS is touched only by the final merge of the
+// four partial softmax states.  Key tiles are dealt round-robin over the 4 x k_splits waves of a (query tile, head):
+// with k_splits = 1 the assignment, the per-wave accumulation order and the merge are those of the LDS kernel (bit
+// identical results); k_splits = 2 gives 752 workgroups of 34 KB LDS on 256 CUs (3 resident per CU), which evens out
+// the 376-tile grid that leaves a third of the chip idle in its second round.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void enc_attention_regs_kernel(FlashArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int T = a.Tk;
+    const int n_head = a.n_head;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int head = blockIdx.x % n_head;
+    const int q_tiles = (a.Tq + QT - 1) / QT;
+    const int qt_idx = (blockIdx.x / n_head) % q_tiles;
+    const int ks = blockIdx.x / (n_head * q_tiles);
+    const int q0 = qt_idx * QT;
+    const long ld = a.ldkv;
+    const int half = lane >> 5, lq = lane & 31;
+
+    // Q fragments: lane (half, lq) supplies Q[q0 + lq][8 g + 4 half .. +4] to MFMA group g
+    float4 qf[8];
+    {
+        const int qr = min(q0 + lq, a.Tq - 1);
+        const float* qp = a.q + (long)qr * a.ldq + head * 64 + half * 4;
+        const bool ok = q0 + lq < a.Tq;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(qp + g * 8);
+            qf[g] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int n_tiles = (T + KT - 1) / KT;
+    const int stride = NWAVE * a.k_splits;            // key tiles between two tiles of this wave
+    const int first = ks * NWAVE + wave;
+    const float* kbase = a.k + head * a.kv_hs + half * 4;  // + key * ld + 8 g
+    const float* vbase = a.v + head * a.kv_hs + lq;        // + key * ld (+ 32)
+
+    float4 kf[8];
+    auto load_k = [&](int tile) {
+        const int key = tile * KT + lq;
+        const bool ok = key < T;
+        const float* kp = kbase + (long)(ok ? key : 0) * ld;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(kp + g * 8);
+            kf[g] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (first < n_tiles) load_k(first);
+    for (int tile = first; tile < n_tiles; tile += stride) {
+        const int key0 = tile * KT;
+        // V of this tile: row r of the PV step pairs key (r&3)+8(r>>2) (lanes 0-31) with that key + 4 (lanes 32-63)
+        float vf0[16], vf1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const bool ok = key < T;
+            const float* vp = vbase + (long)(ok ? key : 0) * ld;
+            const float x0 = vp[0], x1 = vp[32];
+            vf0[r] = ok ? x0 : 0.f;
+            vf1[r] = ok ? x1 : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[g].x, qf[g].x, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[g].y, qf[g].y, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[g].z, qf[g].z, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[g].w, qf[g].w, s, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile + stride < n_tiles) load_k(tile + stride);     // lands during the softmax + PV phase
+        __builtin_amdgcn_sched_barrier(0);
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (key >= T) s[r] = -INFINITY;
+            mt = fmaxf(mt, s[r]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __expf(m_run - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __expf(s[r] - m_new);
+            rs += s[r];
+        }
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf0[r], s[r], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf1[r], s[r], o1, 0, 0, 0);
+        }
+    }
+
+    // merge of the four partial states: identical to flash_attention_kernel's
+    float* Os = lds;                               // [NWAVE][QT][O_LD]
+    float* Ms = lds + NWAVE * QT * O_LD;           // [NWAVE][QT]
+    float* Ls = Ms + NWAVE * QT;                   // [NWAVE][QT]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dd = (r & 3) + 8 * (r >> 2) + 4 * half;
+        Os[(wave * QT + lq) * O_LD + dd] = o0[r];
+        Os[(wave * QT + lq) * O_LD + 32 + dd] = o1[r];
+    }
+    if (half == 0) {
+        Ms[wave * QT + lq] = m_run;
+        Ls[wave * QT + lq] = l_run;
+    }
+    __syncthreads();
+    {
+        const int dd = tid & 63;
+        const int qg = tid >> 6;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = qg * 8 + i;
+            const int qrow = q0 + q;
+            float M = Ms[q];
+#pragma unroll
+            for (int w = 1; w < NWAVE; ++w) M = fmaxf(M, Ms[w * QT + q]);
+            float L = 0.f, acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) {
+                const float e = expf(Ms[w * QT + q] - M);
+                L += e * Ls[w * QT + q];
+                acc += e * Os[(w * QT + q) * O_LD + dd];
+            }
+            if (a.k_splits == 1) {
+                if (qrow < a.Tq) a.out[(long)qrow * a.ldo + head * 64 + dd] = acc / L;
+            } else if (qrow < a.Tq) {
                 const long slot = ((long)qrow * n_head + head) * a.k_splits + ks;
                 a.part_o[slot * 64 + dd] = acc;
                 if (dd == 0) { a.part_m[slot] = M; a.part_l[slot] = L; }
@@ -254,6 +424,21 @@ __global__ __launch_bounds__(64) void flash_merge_kernel(FlashArgs a) {
     a.out[(long)row * a.ldo + head * 64 + dd] = acc / L;
 }
 
+constexpr int kRegsAttnLds = (NWAVE * QT * O_LD + 2 * NWAVE * QT) * (int)sizeof(float);
+
+static void launch_enc_regs(const LaunchCtx& ctx, const FlashArgs& a, const char* tag) {
+    const int q_tiles = (a.Tq + QT - 1) / QT;
+    KernelScope ks(ctx, tag, 4.0 * a.Tq * (double)a.Tk * 64.0 * a.n_head,
+                   4.0 * 64.0 * a.n_head * (2.0 * a.Tq + 2.0 * a.Tk));
+    hipLaunchKernelGGL(enc_attention_regs_kernel, dim3(q_tiles * a.n_head * a.k_splits), dim3(256), kRegsAttnLds,
+                       ctx.stream, a);
+    WLK_HIP(hipGetLastError());
+    if (a.k_splits > 1) {
+        hipLaunchKernelGGL(flash_merge_kernel, dim3(a.Tq, a.n_head), dim3(64), 0, ctx.stream, a);
+        WLK_HIP(hipGetLastError());
+    }
+}
+
 static void launch_flash(const LaunchCtx& ctx, const FlashArgs& a, const char* tag) {
     static bool attr_set[64] = {};
     int dev = 0;
@@ -267,9 +452,12 @@ static void launch_flash(const LaunchCtx& ctx, const FlashArgs& a, const char* t
     if (a.head_rank && a.Tk % 4 != 0) throw std::invalid_argument("flash attention: score dump needs Tk % 4 == 0");
     const int q_tiles = (a.Tq + QT - 1) / QT;
     // QK^T and PV: 2 * Tq*Tk*64 MACs per head each; reads q,k,v once, writes out
-    KernelScope ks(ctx, tag, 4.0 * a.Tq * (double)a.Tk * 64.0 * a.n_head,
-                   4.0 * 64.0 * a.n_head * (2.0 * a.Tq + 2.0 * a.Tk));
-    hipLaunchKernelGGL(flash_attention_kernel, dim3(q_tiles * a.n_head * a.k_splits), dim3(256), lds, ctx.stream, a);
+    const double nb = std::max(a.batch, 1);
+    KernelScope ks(ctx, tag, nb * 4.0 * a.Tq * (double)a.Tk * 64.0 * a.n_head,
+                   nb * 4.0 * 64.0 * a.n_head * (2.0 * a.Tq + 2.0 * a.Tk));
+    if (a.batch > 0 && (a.k_splits > 1 || a.head_rank)) throw std::invalid_argument("flash attention: plain form only when batched");
+    hipLaunchKernelGGL(flash_attention_kernel, dim3(q_tiles * a.n_head * a.k_splits, std::max(a.batch, 1)), dim3(256), lds,
+                       ctx.stream, a);
     WLK_HIP(hipGetLastError());
     if (a.k_splits > 1) {
         hipLaunchKernelGGL(flash_merge_kernel, dim3(a.Tq, a.n_head), dim3(64), 0, ctx.stream, a);
@@ -282,16 +470,32 @@ size_t flash_split_scratch_floats(int rows, int n_head, int k_splits) {
 }
 
 void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out, int T, int d, int n_head,
-                              int k_splits, float* split_scratch) {
+                              int k_splits, float* split_scratch, const float* kv_head_major) {
     FlashArgs a;
     a.q = qkv; a.ldq = 3L * d; a.k = qkv + d; a.v = qkv + 2 * d; a.ldkv = 3L * d; a.out = out; a.ldo = d;
     a.Tq = T; a.Tk = T; a.n_head = n_head;
+    if (kv_head_major) {     // k: [H][T][64], v: the same right behind it
+        a.k = kv_head_major; a.v = kv_head_major + (size_t)n_head * T * 64; a.ldkv = 64; a.kv_hs = (long)T * 64;
+    }
     if (k_splits > 1 && split_scratch) {   // key ranges on separate workgroups + merge: evens out the 376-tile grid
         a.k_splits = k_splits;
         a.part_o = split_scratch;
         a.part_m = split_scratch + (size_t)T * n_head * k_splits * 64;
         a.part_l = a.part_m + (size_t)T * n_head * k_splits;
     }
+    static const int variant = [] {    // WLK_ENC_ATTN=regs selects the register-fed kernel (A/B switch; measured slower)
+        const char* e = getenv("WLK_ENC_ATTN");
+        return (e && e[0] == 'r') ? 1 : 0;
+    }();
+    if (variant == 1) launch_enc_regs(ctx, a, "enc_attention");
+    else launch_flash(ctx, a, "enc_attention");
+}
+
+void launch_encoder_attention_batched(const LaunchCtx& ctx, const PtrTable& z, int batch, int T, int d, int n_head) {
+    if (batch < 1 || batch > kMaxBatch) throw std::invalid_argument("encoder attention: bad batch");
+    FlashArgs a;
+    a.ldq = 3L * d; a.ldkv = 3L * d; a.ldo = d; a.Tq = T; a.Tk = T; a.n_head = n_head;
+    a.batch = batch; a.z = z; a.z_k_off = d; a.z_v_off = 2L * d;
     launch_flash(ctx, a, "enc_attention");
 }
 

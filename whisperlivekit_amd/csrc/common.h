@@ -67,6 +67,27 @@ struct StepRow {
     int pad;
 };
 
+// ---- batched encodes (engine.hip) ------------------------------------------------------------------
+// Concurrent encodes of several sessions run as ONE launch per operator with grid.y = sessions: the weights are
+// shared, every session keeps its own activation buffers, and operand z of a launch comes from a by-value pointer
+// table (the sessions' buffers are separate allocations, so there is no common stride).
+constexpr int kMaxBatch = 8;
+struct PtrTable {
+    const float* in[kMaxBatch];     // A / x / qkv of session z
+    float* out[kMaxBatch];          // C / y / attention output
+    const float* res[kMaxBatch];    // GEMM residual operand
+};
+// Entry z of a table that lives in kernel arguments.  A runtime index into a by-value array would make the compiler
+// copy the whole argument struct to scratch memory (measured: +50 % on the GEMM); z is wave-uniform, so a chain of
+// scalar selects costs a handful of SALU instructions instead.
+template <typename T>
+__device__ __forceinline__ T table_at(T const (&t)[kMaxBatch], unsigned z) {
+    T v = t[0];
+#pragma unroll
+    for (int i = 1; i < kMaxBatch; ++i) v = (z == (unsigned)i) ? t[i] : v;
+    return v;
+}
+
 // ---- gemm_f32.hip ---------------------------------------------------------------------------
 // C[M,N] = epilogue(A[M,K] * W[N,K]^T + bias[N]); fp32 MFMA (v_mfma_f32_32x32x2_f32).
 enum GemmFlags : int {
@@ -115,6 +136,9 @@ struct GemmArgs {
     const int* mg_ring_row = nullptr;
     const int* mg_beam_of_row = nullptr;
     int mg_heads = 0, mg_T = 0, mg_ring_rows = 0, mg_n_beam = 1, mg_side_blocks = 0;
+    // batched encodes: > 0 -> grid.y = batch, operands of z from the table (A, C, R above are ignored)
+    int batch = 0;
+    PtrTable z;
     bool force_kwave = false;
     bool gemm_plain_loop = false;   // A/B switch: LDS fragment reads right before use instead of a group ahead   // diagnostics: take the k-wave kernel (under-filled grids) whatever the shape
 };
@@ -136,6 +160,9 @@ inline void launch_linear(const LaunchCtx& ctx, const GemmArgs& g, const char* t
 // ---- layernorm.hip --------------------------------------------------------------------------
 void launch_layernorm(const LaunchCtx& ctx, const float* x, long ldx, const float* gamma, const float* beta,
                       float* y, long ldy, int rows, int d, const char* tag);
+// the same for `batch` sessions at once: x = z.in[i], y = z.out[i]
+void launch_layernorm_batched(const LaunchCtx& ctx, const PtrTable& z, int batch, long ldx, const float* gamma,
+                              const float* beta, long ldy, int rows, int d, const char* tag);
 
 // ---- mel.hip --------------------------------------------------------------------------------
 struct MelArgs {
@@ -175,7 +202,10 @@ void launch_melspec(const LaunchCtx& ctx, const MelSpecArgs& a, int n_frames);
 // flash-style fp32-MFMA attention: q rows [Tq] against k/v rows [Tk], 64-wide heads, no mask
 struct FlashArgs {
     const float* q = nullptr; long ldq = 0;      // query row r, head h at q + r*ldq + 64h (pre-scaled)
-    const float* k = nullptr; const float* v = nullptr; long ldkv = 0;  // key t at k + t*ldkv + 64h (pre-scaled)
+    const float* k = nullptr; const float* v = nullptr; long ldkv = 0;  // key t at k + t*ldkv + kv_hs*h (pre-scaled)
+    long kv_hs = 64;                             // head stride of k / v: 64 = heads side by side in a row; Tk*64 with
+                                                 // ldkv = 64 = head-major [H][Tk][64] (every key row of a head is the
+                                                 // next 256 bytes: spreads one head's traffic over all L2 channels)
     float* out = nullptr; long ldo = 0;
     int Tq = 0, Tk = 0, n_head = 0;
     // decoder prefill only: raw scores of alignment heads go to the alignment window
@@ -186,6 +216,10 @@ struct FlashArgs {
     int ring_rows = 0, n_beam = 1;
     // key-range split (few query tiles, e.g. decoder prefill): k_splits workgroups per (q tile, head) leave
     // partial softmax states in part_o/m/l [rows][n_head][k_splits][64|1|1]; a merge kernel folds them
+    // batched encodes: > 0 -> grid.y = batch; q = z.in[i], k = q + z_k_off, v = q + z_v_off, out = z.out[i]
+    int batch = 0;
+    long z_k_off = 0, z_v_off = 0;
+    PtrTable z;
     int k_splits = 1;
     float* part_o = nullptr;
     float* part_m = nullptr;
@@ -194,7 +228,9 @@ struct FlashArgs {
 size_t flash_split_scratch_floats(int rows, int n_head, int k_splits);
 // encoder self-attention over qkv[T][3d] (q and k pre-scaled), out[T][d]
 void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out, int T, int d, int n_head,
-                              int k_splits = 1, float* split_scratch = nullptr);
+                              int k_splits = 1, float* split_scratch = nullptr, const float* kv_head_major = nullptr);
+// encoder self-attention of `batch` sessions in one launch: qkv = z.in[i] ([T][3d]), out = z.out[i]
+void launch_encoder_attention_batched(const LaunchCtx& ctx, const PtrTable& z, int batch, int T, int d, int n_head);
 void launch_prefill_cross_attention(const LaunchCtx& ctx, const FlashArgs& a);
 void launch_ring_softmax(const LaunchCtx& ctx, float* ring, const int* ring_row, const int* beam_of_row,
                          const int* ranks_dev, int n_ranks, int rows, int ring_rows, int n_beam, int T);

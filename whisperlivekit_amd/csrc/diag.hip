@@ -51,6 +51,47 @@ int wlk_diag_linear(const float* a, int64_t lda, int64_t a_floats, const float* 
     });
 }
 
+/* average microseconds per launch of `reps` back-to-back launches of one linear layer (device-resident operands,
+ * HIP events around the whole train, one warm-up launch first): the kernel-tuning probe */
+int wlk_diag_linear_time(int m, int n, int k, int flags, int force, int reps, float* us_per_launch) {
+    return run([&]() {
+        std::vector<float> ha((size_t)m * k), hw((size_t)n * k);
+        unsigned seed = 12345u;
+        auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xffff) / 65536.0f - 0.5f; };
+        for (auto& v : ha) v = rnd();
+        for (auto& v : hw) v = rnd() * 0.05f;
+        DevBuf A((size_t)m * k, ha.data()), W((size_t)n * k, hw.data()), B(n), R((size_t)m * n), Cc((size_t)m * n);
+        WLK_HIP(hipMemset(B.p, 0, n * sizeof(float)));
+        WLK_HIP(hipMemset(R.p, 0, (size_t)m * n * sizeof(float)));
+        GemmArgs g;
+        g.A = A.p; g.lda = k; g.W = W.p; g.bias = B.p; g.C = Cc.p; g.ldc = n; g.R = (flags & kGemmResidual) ? R.p : nullptr;
+        g.ldr = n; g.M = m; g.N = n; g.K = k; g.flags = flags; g.scale = 0.5f; g.scale_cols = n / 2;
+        g.force_kwave = force == 2;
+        hipStream_t st;
+        WLK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        LaunchCtx ctx{st, nullptr};
+        auto go = [&]() {
+            if (force == 1) launch_gemv(ctx, g, "diag");
+            else launch_gemm(ctx, g, "diag");
+        };
+        go();
+        WLK_HIP(hipStreamSynchronize(st));
+        hipEvent_t e0, e1;
+        WLK_HIP(hipEventCreate(&e0));
+        WLK_HIP(hipEventCreate(&e1));
+        WLK_HIP(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) go();
+        WLK_HIP(hipEventRecord(e1, st));
+        WLK_HIP(hipStreamSynchronize(st));
+        float ms = 0.f;
+        WLK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *us_per_launch = 1e3f * ms / (float)reps;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipStreamDestroy(st);
+    });
+}
+
 int wlk_diag_linear_ln(const float* a, const float* w, const float* bias, const float* gamma, const float* beta, int m,
                        int n, int k, int force_gemv, float* c) {
     return run([&]() {
@@ -73,6 +114,37 @@ int wlk_diag_layernorm(const float* x, const float* gamma, const float* beta, in
         launch_layernorm(ctx, X.p, d, G.p, Bt.p, Y.p, d, rows, d, "diag_ln");
         WLK_HIP(hipDeviceSynchronize());
         WLK_HIP(hipMemcpy(y, Y.p, (size_t)rows * d * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+
+int wlk_diag_encoder_attention_time(int t, int d, int n_head, int k_splits, int reps, float* us_per_launch) {
+    const bool head_major = k_splits >= 100;     // probe switch: +100 = k / v in head-major layout
+    k_splits %= 100;
+    return run([&]() {
+        std::vector<float> h((size_t)t * 3 * d);
+        unsigned seed = 777u;
+        for (auto& v : h) { seed = seed * 1664525u + 1013904223u; v = (((seed >> 8) & 0xffff) / 65536.0f - 0.5f) * 1.5f; }
+        DevBuf Q((size_t)t * 3 * d, h.data()), O((size_t)t * d), S(flash_split_scratch_floats(t, n_head, std::max(k_splits, 1)));
+        DevBuf KV((size_t)2 * t * d, h.data());
+        hipStream_t st;
+        WLK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        LaunchCtx ctx{st, nullptr};
+        auto go = [&]() { launch_encoder_attention(ctx, Q.p, O.p, t, d, n_head, k_splits, S.p, head_major ? KV.p : nullptr); };
+        go();
+        WLK_HIP(hipStreamSynchronize(st));
+        hipEvent_t e0, e1;
+        WLK_HIP(hipEventCreate(&e0));
+        WLK_HIP(hipEventCreate(&e1));
+        WLK_HIP(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) go();
+        WLK_HIP(hipEventRecord(e1, st));
+        WLK_HIP(hipStreamSynchronize(st));
+        float ms = 0.f;
+        WLK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *us_per_launch = 1e3f * ms / (float)reps;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipStreamDestroy(st);
     });
 }
 

@@ -12,6 +12,7 @@
 // Sessions join when their prefill is done and leave when their loop stops; nobody waits for anybody.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstring>
@@ -30,6 +31,14 @@ namespace {
 struct EngineJob {
     wlk_session* s = nullptr;
     DecodeJob* job = nullptr;
+    bool done = false;
+    int rc = WLK_OK;
+    std::string err;
+};
+
+struct EncodeReq {
+    wlk_session* s = nullptr;
+    int content = 0;
     bool done = false;
     int rc = WLK_OK;
     std::string err;
@@ -62,7 +71,16 @@ struct wlk_engine {
     std::deque<EngineJob*> submitted;
     bool quit = false;
     int attached = 0;
-    std::atomic<int> in_loop{0};   // sessions currently inside wlk_decode_until_stop
+    std::atomic<int> in_loop{0};   // sessions currently inside wlk_decode_until_stop or wlk_encode
+    // encode lane: concurrent encodes of the attached sessions are stacked into one launch chain (grid.y = sessions)
+    hipStream_t enc_stream = nullptr;
+    std::thread enc_worker;
+    std::condition_variable cv_enc_work, cv_enc_done;
+    std::deque<EncodeReq*> enc_submitted;
+    bool batch_encodes = true;
+    int gather_us = 0;
+    uint64_t n_enc_batches = 0, n_enc_sessions = 0;
+    void run_encodes();
     uint64_t n_iterations = 0, n_rows = 0, n_batched = 0, n_batched_rows = 0;
 
     void run();
@@ -295,6 +313,60 @@ void wlk_engine::run() {
     }
 }
 
+void wlk_engine::run_encodes() {
+    (void)hipSetDevice(m->device);
+    for (;;) {
+        std::vector<EncodeReq*> batch;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_enc_work.wait(lk, [&] { return quit || !enc_submitted.empty(); });
+            if (quit && enc_submitted.empty()) return;
+            if (gather_us > 0) {
+                // optional gather window (WLK_ENCODE_GATHER_US, default 0 = never wait): while other sessions of this GPU
+                // are inside a decode loop, i.e. about to come back with their next chunk, hold the launch briefly so
+                // their encodes ride in the same chain.  A throughput-for-latency trade for saturated servers only.
+                const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(gather_us);
+                // target: half of the sessions that are busy on this GPU (two alternating groups keep the encode lane
+                // and the decode steps of the other group running side by side)
+                while (!quit && (int)enc_submitted.size() < std::min(kMaxBatch, (in_loop.load(std::memory_order_relaxed) + 1) / 2) &&
+                       cv_enc_work.wait_until(lk, deadline) != std::cv_status::timeout) {
+                }
+            }
+            while (!enc_submitted.empty() && (int)batch.size() < kMaxBatch) {
+                batch.push_back(enc_submitted.front());
+                enc_submitted.pop_front();
+            }
+        }
+        int rc = WLK_OK;
+        std::string err;
+        try {
+            std::vector<wlk_session*> group;
+            for (EncodeReq* r : batch) group.push_back(r->s);
+            std::vector<int> content;
+            wlk_encode_group(group, LaunchCtx{enc_stream, nullptr}, content);
+            WLK_HIP(hipStreamSynchronize(enc_stream));
+            for (size_t i = 0; i < batch.size(); ++i) batch[i]->content = content[i];
+        } catch (const std::length_error& e) {
+            rc = WLK_ERR_CAPACITY;
+            err = e.what();
+        } catch (const std::exception& e) {
+            rc = dynamic_cast<const HipError*>(&e) ? WLK_ERR_HIP : WLK_ERR_STATE;
+            err = e.what();
+        }
+        n_enc_batches += 1;
+        n_enc_sessions += batch.size();
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (EncodeReq* r : batch) {
+                r->rc = rc;
+                r->err = err;
+                r->done = true;
+            }
+        }
+        cv_enc_done.notify_all();
+    }
+}
+
 // ---- lifetime -----------------------------------------------------------------------------------------------
 static wlk_engine* engine_create(wlk_model* m) {
     const wlk_dims& D = m->D;
@@ -307,6 +379,9 @@ static wlk_engine* engine_create(wlk_model* m) {
     WLK_HIP(hipSetDevice(m->device));
     WLK_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     if (const char* g = std::getenv("WLK_NO_GRAPH")) e->use_graph = !(g[0] == '1');
+    WLK_HIP(hipStreamCreateWithFlags(&e->enc_stream, hipStreamNonBlocking));
+    if (const char* g = std::getenv("WLK_BATCH_ENCODE")) e->batch_encodes = !(g[0] == '0');
+    if (const char* g = std::getenv("WLK_ENCODE_GATHER_US")) e->gather_us = std::max(0, std::atoi(g));
     const size_t R = 8, d = D.n_text_state, T = D.n_audio_ctx, V = D.n_vocab;
     e->rows_dev = dev_alloc<StepRow>(R);
     e->x = dev_alloc<float>(R * d);
@@ -325,6 +400,7 @@ static wlk_engine* engine_create(wlk_model* m) {
     WLK_HIP(hipStreamSynchronize(e->stream));
     wlk_engine* raw = e.release();
     raw->worker = std::thread([raw] { raw->run(); });
+    raw->enc_worker = std::thread([raw] { raw->run_encodes(); });
     return raw;
 }
 
@@ -336,7 +412,10 @@ void wlk_engine_destroy_for_model(wlk_model* m) {
         e->quit = true;
     }
     e->cv_work.notify_all();
+    e->cv_enc_work.notify_all();
     if (e->worker.joinable()) e->worker.join();
+    if (e->enc_worker.joinable()) e->enc_worker.join();
+    if (e->enc_stream) (void)hipStreamDestroy(e->enc_stream);
     (void)hipSetDevice(m->device);
     float* fl[] = {e->x, e->qkv, e->att, e->q, e->mlp, e->logits, e->xsplit, e->z, e->attn_last, e->res_dev};
     for (float* p : fl)
@@ -377,6 +456,31 @@ bool wlk_engine_wants(const wlk_session* s) {
     return s->engine && s->engine->in_loop.load(std::memory_order_relaxed) > 1 && !s->debug && !s->prof_on && s->beam == 1;
 }
 
+bool wlk_engine_batches_encodes(const wlk_session* s) {
+    // only when another session of this GPU is busy (inside an encode or a decode loop) right now; a lone stream
+    // encodes on its own stream without the hand-off
+    return s->engine && s->engine->batch_encodes && !s->debug && !s->prof_on &&
+           s->engine->in_loop.load(std::memory_order_relaxed) > 1;     // the caller itself is counted (wlk_encode)
+}
+
+int wlk_engine_encode(wlk_session* s, int* content_mel_len) {
+    wlk_engine* e = s->engine;
+    EncodeReq req;
+    req.s = s;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        e->enc_submitted.push_back(&req);
+    }
+    e->cv_enc_work.notify_one();
+    {
+        std::unique_lock<std::mutex> lk(e->mu);
+        e->cv_enc_done.wait(lk, [&] { return req.done; });
+    }
+    if (req.rc != WLK_OK) set_last_error(req.err);
+    if (content_mel_len) *content_mel_len = req.content;
+    return req.rc;
+}
+
 void wlk_engine_loop_enter(wlk_session* s) {
     if (s->engine) s->engine->in_loop.fetch_add(1, std::memory_order_relaxed);
 }
@@ -411,6 +515,14 @@ int wlk_engine_detach(wlk_session* s) {
         s->engine->attached -= 1;
     }
     s->engine = nullptr;
+    return WLK_OK;
+}
+
+int wlk_engine_encode_stats(wlk_model* m, uint64_t* batches, uint64_t* sessions) {
+    if (!m) return fail(WLK_ERR_ARG, "model is NULL");
+    std::lock_guard<std::mutex> lk(m->engine_mu);
+    if (batches) *batches = m->engine ? m->engine->n_enc_batches : 0;
+    if (sessions) *sessions = m->engine ? m->engine->n_enc_sessions : 0;
     return WLK_OK;
 }
 

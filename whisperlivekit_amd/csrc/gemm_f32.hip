@@ -17,6 +17,7 @@
 // k-permutation trick: MFMA step j of k-group s takes k = 8s+j from lanes 0-31 and k = 8s+4+j
 // from lanes 32-63, for A and B alike.  A contraction is order-free, so each lane fetches its
 // four k values with ONE 16-byte LDS read instead of four strided 4-byte reads.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -56,6 +57,12 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wr = wave / (BN / 32), wc = wave % (BN / 32);
+    // batched encodes: this workgroup works on session blockIdx.y's buffers (locals, not writes into `g`: a modified
+    // argument struct would be materialised in scratch memory)
+    const bool batched = g.batch > 0;
+    const float* const gA = batched ? table_at(g.z.in, blockIdx.y) : g.A;
+    float* const gC = batched ? table_at(g.z.out, blockIdx.y) : g.C;
+    const float* const gR = batched ? table_at(g.z.res, blockIdx.y) : g.R;
     // XCD-aware tile mapping.  Workgroup b is dispatched to XCD b % 8 (observed; used for speed only) and
     // each XCD has a private 4 MiB L2 that starts cold at every launch.  With the plain (x = N tile,
     // y = M tile) order every XCD touches ALL of A, so 8 copies of A cross the fabric (TCC miss rate 50 %
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
     // count outstanding loads exactly (counted vmcnt keeps the second prefetch stage in flight).
     constexpr unsigned kOob = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(g.A), 0, (int)((((long)g.M - 1) * g.lda + g.K) * 4), 0x00020000);
+        const_cast<float*>(gA), 0, (int)((((long)g.M - 1) * g.lda + g.K) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(g.W), 0, (int)((long)g.N * g.K * 4), 0x00020000);
     unsigned a_byte[NA], w_byte[NW];
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row_base + (r & 3) + 8 * (r >> 2);
-                res[r] = g.R[(long)min(row, g.M - 1) * g.ldr + col];
+                res[r] = gR[(long)min(row, g.M - 1) * g.ldr + col];
             }
         } else {
 #pragma unroll
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
             if (relu) v = fmaxf(v, 0.f);
             if (swish) v = v / (1.0f + expf(-v));
             v += res[r];
-            if (row < g.M) g.C[(long)row * g.ldc + col] = v;
+            if (row < g.M) gC[(long)row * g.ldc + col] = v;
         }
     }
 }
@@ -375,7 +382,12 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (g.K % 4 != 0 || g.lda % 4 != 0) throw std::invalid_argument("gemm: K and lda must be multiples of 4");
     if ((((long)g.M - 1) * g.lda + g.K) * 4 >= (1L << 31) || (long)g.N * g.K * 4 >= (1L << 31))
         throw std::invalid_argument("gemm: operand larger than 2 GiB");
-    KernelScope ks(ctx, tag, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    const double nb = std::max(g.batch, 1);
+    KernelScope ks(ctx, tag, nb * 2.0 * g.M * g.N * g.K,
+                   4.0 * (nb * (double)g.M * g.K + (double)g.N * g.K + nb * (double)g.M * g.N));
+    if (g.batch > 0 && (gemm_takes_kwave(g.M, g.N, g.K) || g.force_kwave || (long)((g.N + 63) / 64) * ((g.M + 63) / 64) < 64))
+        throw std::invalid_argument("gemm: batched launches are only available on the 64x64 path");
+    if (g.batch > kMaxBatch) throw std::invalid_argument("gemm: batch too large");
     const long tiles64 = (long)((g.N + 63) / 64) * ((g.M + 63) / 64);
     const int tiles_n = (g.N + 63) / 64;
     const long tiles32 = (long)((g.N + 31) / 32) * ((g.M + 31) / 32);
@@ -386,7 +398,7 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     } else if (tiles64 >= 64) {
         const int tiles_m = (g.M + 63) / 64;
         const int blocks = tiles_m >= 8 ? 8 * ((tiles_m + 3) / 4) * ((tiles_n + 1) / 2) : tiles_m * tiles_n;
-        hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64>), dim3(blocks), dim3(256), 0, ctx.stream, g);
+        hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64>), dim3(blocks, std::max(g.batch, 1)), dim3(256), 0, ctx.stream, g);
     } else {  // few tiles (decoder prefill): halve the tile height so that more CUs get a workgroup
         const int tiles_m = (g.M + 31) / 32;
         const int blocks = tiles_m >= 8 ? 8 * ((tiles_m + 3) / 4) * ((tiles_n + 1) / 2) : tiles_m * tiles_n;

@@ -22,6 +22,9 @@ inline int guarded(F&& f) {
     } catch (const HipError& e) {
         set_last_error(e.what());
         return WLK_ERR_HIP;
+    } catch (const std::length_error& e) {
+        set_last_error(e.what());
+        return WLK_ERR_CAPACITY;
     } catch (const std::invalid_argument& e) {
         set_last_error(e.what());
         return WLK_ERR_ARG;
@@ -194,7 +197,12 @@ struct wlk_session {
 };
 
 
+// api.hip
+void wlk_encode_group(const std::vector<wlk_session*>& group, const wlk::LaunchCtx& c, std::vector<int>& content_out);
+
 // engine.hip
+bool wlk_engine_batches_encodes(const wlk_session* s);
+int wlk_engine_encode(wlk_session* s, int* content_mel_len);      // blocks until this session's encode is done
 namespace wlk { struct DecodeJob; }
 void wlk_engine_destroy_for_model(wlk_model* m);
 bool wlk_engine_wants(const wlk_session* s);

@@ -10,10 +10,14 @@ constexpr int kLnMaxPerLane = 24;  // supports d <= 1536
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
-                                                        long ldy, int rows, int d) {
+                                                        long ldy, int rows, int d, PtrTable z, int batch) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    if (batch > 0) {
+        x = table_at(z.in, blockIdx.y);
+        y = table_at(z.out, blockIdx.y);
+    }
     const float* xr = x + (long)row * ldx;
     float v[kLnMaxPerLane];
     float sum = 0.f;
@@ -50,7 +54,17 @@ void launch_layernorm(const LaunchCtx& ctx, const float* x, long ldx, const floa
     if (d > 64 * kLnMaxPerLane) throw std::invalid_argument("layernorm: d too large");
     KernelScope ks(ctx, tag);
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, ctx.stream, x, ldx, gamma, beta, y,
-                       ldy, rows, d);
+                       ldy, rows, d, PtrTable{}, 0);
+    WLK_HIP(hipGetLastError());
+}
+
+void launch_layernorm_batched(const LaunchCtx& ctx, const PtrTable& z, int batch, long ldx, const float* gamma,
+                              const float* beta, long ldy, int rows, int d, const char* tag) {
+    if (rows <= 0 || batch <= 0) return;
+    if (d > 64 * kLnMaxPerLane || batch > kMaxBatch) throw std::invalid_argument("layernorm: d or batch too large");
+    KernelScope ks(ctx, tag);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4, batch), dim3(256), 0, ctx.stream, (const float*)nullptr, ldx,
+                       gamma, beta, (float*)nullptr, ldy, rows, d, z, batch);
     WLK_HIP(hipGetLastError());
 }
 

@@ -189,8 +189,12 @@ class HipWhisperModel:
         v = [C.c_uint64() for _ in range(4)]
         _lib.check(self.lib.wlk_engine_stats(self._h, *[C.byref(x) for x in v]))
         it, rows, bs, br = (int(x.value) for x in v)
+        eb, es = C.c_uint64(), C.c_uint64()
+        _lib.check(self.lib.wlk_engine_encode_stats(self._h, C.byref(eb), C.byref(es)))
         return dict(iterations=it, rows=rows, batched_steps=bs, batched_rows=br,
-                    mean_rows_per_batched_step=round(br / bs, 3) if bs else None)
+                    mean_rows_per_batched_step=round(br / bs, 3) if bs else None,
+                    encode_batches=int(eb.value), encoded_sessions=int(es.value),
+                    mean_sessions_per_encode_batch=round(es.value / eb.value, 3) if eb.value else None)
 
     def close(self) -> None:
         if self._h:
