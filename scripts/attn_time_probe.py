@@ -13,12 +13,12 @@ lib = _lib.load()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 vp = lambda a: a.ctypes.data_as(C.c_void_p)
 for (T, d, H) in ((1500, 512, 8), (1500, 1280, 20)):
-    for ks in (1, 2, 101, 102):
+    for ks in (1,):
         us = C.c_float()
         rc = lib.wlk_diag_encoder_attention_time(T, d, H, ks, reps, C.byref(us))
         assert rc == 0, lib.wlk_diag_last_error()
         fl = 4.0 * T * T * 64 * H
-        print(f"{os.environ.get('WLK_ENC_ATTN', 'regs'):5s} T={T} d={d} H={H} ksplit={ks}: {us.value:8.2f} us  {fl / us.value / 1e6:6.1f} TFLOP/s")
+        print(f"{os.environ.get('WLK_ENC_ATTN', 'regs'):5s} T={T} d={d} H={H} ksplit={os.environ.get('WLK_ENC_KSPLIT', 'auto')}: {us.value:8.2f} us  {fl / us.value / 1e6:6.1f} TFLOP/s")
 # numerics: regs kernel vs fp64 reference on a small case
 rng = np.random.default_rng(0)
 T, d, H = 333, 128, 2

@@ -369,11 +369,8 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         if (m->n_align > 0) s->ring = dev_alloc<float>((size_t)m->n_align * beam * s->ring_rows * T);
         s->xsplit = dev_alloc<float>(cross_split_scratch_floats(8, D.n_text_head, (int)T));
         s->fsplit = dev_alloc<float>(flash_split_scratch_floats(s->max_rows, D.n_text_head, wlk_session::kFlashSplits));
-        if (const char* e = getenv("WLK_ENC_KSPLIT")) {
-            s->enc_ksplit = std::max(1, std::min(8, atoi(e)));
-            if (s->enc_ksplit > 1)
-                s->esplit = dev_alloc<float>(flash_split_scratch_floats(D.n_audio_ctx, D.n_audio_head, s->enc_ksplit));
-        }
+        // partial softmax states of the encoder attention's key splits (<= 8 per (query, head))
+        s->esplit = dev_alloc<float>(flash_split_scratch_floats(D.n_audio_ctx, D.n_audio_head, 8));
         s->z = dev_alloc<float>((size_t)beam * std::max(m->n_align, 1) * T);
         s->attn_last = dev_alloc_zero<float>((size_t)beam * T, st);
         s->adj_row = dev_alloc<int>(3 * wlk_session::kAdjCap);   // [rows n | ids n | deltas n] packed per call
@@ -621,7 +618,8 @@ extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const
     const float scale = std::pow((float)kHeadDim, -0.25f);
     const PtrTable z_ex_eh = table([](wlk_session* s) { return (const float*)s->ex; }, [](wlk_session* s) { return s->eh; }, none);
     const PtrTable z_eh_qkv = table([](wlk_session* s) { return (const float*)s->eh; }, [](wlk_session* s) { return s->eqkv; }, none);
-    const PtrTable z_qkv_att = table([](wlk_session* s) { return (const float*)s->eqkv; }, [](wlk_session* s) { return s->eatt; }, none);
+    const PtrTable z_qkv_att = table([](wlk_session* s) { return (const float*)s->eqkv; }, [](wlk_session* s) { return s->eatt; },
+                                     [](wlk_session* s) { return (const float*)s->esplit; });
     const PtrTable z_att_ex = table([](wlk_session* s) { return (const float*)s->eatt; }, [](wlk_session* s) { return s->ex; },
                                     [](wlk_session* s) { return (const float*)s->ex; });
     const PtrTable z_eh_mlp = table([](wlk_session* s) { return (const float*)s->eh; }, [](wlk_session* s) { return s->emlp; }, none);

@@ -19,6 +19,8 @@
 // With S^T (keys on rows) every lane owns ONE query column, so the softmax row reductions are
 // 15 in-lane ops + one cross-half swap, and the alpha rescale is a per-lane scalar.
 #include <algorithm>
+#include <atomic>
+#include <cmath>
 #include <cstdlib>
 
 #include "common.h"
@@ -409,19 +411,225 @@ __global__ __launch_bounds__(256) void enc_attention_regs_kernel(FlashArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Encoder self-attention, second form: 64 queries per workgroup, K/V tiles shared by two waves, balanced key splits.
+//
+// Where the 32-query kernel above loses its time on the 1500 x 1500 x 8-head problem (scripts/probes/attn_ablation.hip,
+// MI355X): of 97 us, 32 us are the global -> LDS traffic of K and V (every one of the 376 workgroups re-reads the
+// 768 KB of its head: 289 MB per launch, 16 flops per byte), 11 us are grid quantisation (376 workgroups of 76 KB LDS
+// = 2 per CU on 120 CUs and 1 on the rest: the loaded CUs take twice as long), 9 us the softmax arithmetic that a
+// second wave per SIMD would cover, 11 us prologue / epilogue.  Here
+//   * a workgroup owns 64 queries: wave (qs, kt) multiplies query sub-tile qs with key tile kt of the staged PAIR of
+//     key tiles, so every K/V byte that reaches LDS feeds two waves (half the traffic), Q fragments stay in registers;
+//   * LDS per workgroup is 34 KB (two K tiles + two V tiles; the merge area overlays them), ~150 VGPRs: 3 workgroups
+//     per CU, 3 waves per SIMD - softmax and staging of one wave hide behind the MFMAs of the other two;
+//   * the key-tile pairs of a (query tile, head) are dealt round-robin over k_splits workgroups so that the grid is a
+//     whole number of "3 per CU" rounds (base: 24 x 8 x 4 = 768 = 3 x 256); the k_splits partial softmax states are
+//     folded by flash_merge_kernel in a fixed order (deterministic).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int QT2 = 64;
+constexpr int kAttn2Stage = 2 * KT * K_LD + 2 * KT * 64;                 // floats: K pair + V pair
+constexpr int kAttn2Merge = NWAVE * QT * O_LD + 2 * NWAVE * QT;          // floats: O, m, l of the four waves
+constexpr int kAttn2LdsFloats = kAttn2Stage > kAttn2Merge ? kAttn2Stage : kAttn2Merge;
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void enc_attention_q64_kernel(FlashArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const bool batched = a.batch > 0;
+    const float* const aq = batched ? table_at(a.z.in, blockIdx.y) : a.q;
+    const float* const ak = batched ? aq + a.z_k_off : a.k;
+    const float* const av = batched ? aq + a.z_v_off : a.v;
+    float* const aout = batched ? table_at(a.z.out, blockIdx.y) : a.out;
+    float* const part = batched ? const_cast<float*>(table_at(a.z.res, blockIdx.y)) : a.part_o;
+    const int T = a.Tk, n_head = a.n_head;
+    float* Ks = lds;                          // [2][KT][K_LD]
+    float* Vs = lds + 2 * KT * K_LD;          // [2][KT][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qs = wave & 1, kt = wave >> 1;
+    const int head = blockIdx.x % n_head;
+    const int q_tiles = (a.Tq + QT2 - 1) / QT2;
+    const int qt_idx = (blockIdx.x / n_head) % q_tiles;
+    const int ks = blockIdx.x / (n_head * q_tiles);
+    const int q0 = qt_idx * QT2 + qs * QT;    // first query of this wave's sub-tile
+    const long ld = a.ldkv;
+    const int half = lane >> 5, lq = lane & 31;
+
+    float4 qf[8];                             // Q[q0 + lq][8 g + 4 half .. +4]: B operand of QK^T group g
+    {
+        const int qr = min(q0 + lq, a.Tq - 1);
+        const float* qp = aq + (long)qr * a.ldq + head * 64 + half * 4;
+        const bool ok = q0 + lq < a.Tq;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(qp + g * 8);
+            qf[g] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const float* kbase = ak + head * a.kv_hs;
+    const float* vbase = av + head * a.kv_hs;
+    // staging map: a pair = 64 keys x 64 floats for K and for V = 1024 float4 each, 4 + 4 per thread
+    float4 rk[4], rv[4];
+    auto fetch = [&](int pair) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int key = pair * (2 * KT) + (idx >> 4);
+            const int c4 = idx & 15;
+            const bool ok = key < T;
+            const long off = (long)(ok ? key : 0) * ld + c4 * 4;
+            const float4 k4 = *reinterpret_cast<const float4*>(kbase + off);
+            const float4 v4 = *reinterpret_cast<const float4*>(vbase + off);
+            rk[i] = ok ? k4 : make_float4(0.f, 0.f, 0.f, 0.f);
+            rv[i] = ok ? v4 : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int kl = idx >> 4;          // 0..63: tile = kl >> 5, row = kl & 31
+            const int c4 = idx & 15;
+            *reinterpret_cast<float4*>(&Ks[(kl >> 5) * (KT * K_LD) + (kl & 31) * K_LD + c4 * 4]) = rk[i];
+            *reinterpret_cast<float4*>(&Vs[kl * 64 + c4 * 4]) = rv[i];
+        }
+    };
+    const int n_pairs = (T + 2 * KT - 1) / (2 * KT);
+    const float* Kw = Ks + kt * (KT * K_LD) + lq * K_LD + half * 4;
+    const float* Vw = Vs + kt * (KT * 64) + lq;
+    if (ks < n_pairs) fetch(ks);
+    for (int pair = ks; pair < n_pairs; pair += a.k_splits) {
+        __syncthreads();                      // the previous pair's LDS reads are done
+        stash();
+        __syncthreads();
+        if (pair + a.k_splits < n_pairs) fetch(pair + a.k_splits);
+        const int key0 = pair * (2 * KT) + kt * KT;
+        if (key0 < T) {                       // wave-uniform
+            f32x16 s;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = 0.f;
+            float4 k4 = *reinterpret_cast<const float4*>(Kw);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, qf[g].x, s, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                float4 kn = k4;
+                if (g + 1 < 8) kn = *reinterpret_cast<const float4*>(Kw + (g + 1) * 8);
+                __builtin_amdgcn_sched_barrier(0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, qf[g].y, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, qf[g].z, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, qf[g].w, s, 0, 0, 0);
+                k4 = kn;
+            }
+            float mt = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (key >= T) s[r] = -INFINITY;
+                mt = fmaxf(mt, s[r]);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = __expf(m_run - m_new);
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = __expf(s[r] - m_new);
+                rs += s[r];
+            }
+            rs += __shfl_xor(rs, 32, 64);
+            l_run = l_run * alpha + rs;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            float v0 = Vw[(4 * half) * 64], v1 = Vw[(4 * half) * 64 + 32];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v0n = v0, v1n = v1;
+                if (r + 1 < 16) {
+                    const int kn = ((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * half;
+                    v0n = Vw[kn * 64];
+                    v1n = Vw[kn * 64 + 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[r], o1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                v0 = v0n;
+                v1 = v1n;
+            }
+        }
+    }
+
+    // merge the two key streams of each query sub-tile through LDS (overlaying the staging area)
+    __syncthreads();
+    float* Os = lds;                               // [NWAVE][QT][O_LD]
+    float* Ms = lds + NWAVE * QT * O_LD;           // [NWAVE][QT]
+    float* Ls = Ms + NWAVE * QT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dd = (r & 3) + 8 * (r >> 2) + 4 * half;
+        Os[(wave * QT + lq) * O_LD + dd] = o0[r];
+        Os[(wave * QT + lq) * O_LD + 32 + dd] = o1[r];
+    }
+    if (half == 0) {
+        Ms[wave * QT + lq] = m_run;
+        Ls[wave * QT + lq] = l_run;
+    }
+    __syncthreads();
+    {
+        const int dd = tid & 63;
+        const int qg = tid >> 6;                   // 16 queries per thread group
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int q = qg * 16 + i;             // 0..63 within the workgroup's tile
+            const int sub = q >> 5, ql = q & 31;
+            const int w0 = sub, w1 = sub + 2;      // the two key streams of this sub-tile
+            const int qrow = qt_idx * QT2 + q;
+            const float m0 = Ms[w0 * QT + ql], m1 = Ms[w1 * QT + ql];
+            const float M = fmaxf(m0, m1);
+            // a stream that saw no key keeps m = -inf, l = 0, o = 0 and must contribute nothing (exp(-inf - M) = 0,
+            // but -inf - (-inf) would be NaN when BOTH streams are empty: then the row is outside this split's keys)
+            const float e0 = m0 == -INFINITY ? 0.f : expf(m0 - M), e1 = m1 == -INFINITY ? 0.f : expf(m1 - M);
+            const float L = e0 * Ls[w0 * QT + ql] + e1 * Ls[w1 * QT + ql];
+            const float acc = e0 * Os[(w0 * QT + ql) * O_LD + dd] + e1 * Os[(w1 * QT + ql) * O_LD + dd];
+            if (qrow < a.Tq) {
+                if (a.k_splits == 1) {
+                    aout[(long)qrow * a.ldo + head * 64 + dd] = acc / L;
+                } else {
+                    const long slot = ((long)qrow * n_head + head) * a.k_splits + ks;
+                    float* pm = part + (size_t)a.Tq * n_head * a.k_splits * 64;
+                    float* pl = pm + (size_t)a.Tq * n_head * a.k_splits;
+                    part[slot * 64 + dd] = acc;
+                    if (dd == 0) { pm[slot] = M; pl[slot] = L; }
+                }
+            }
+        }
+    }
+}
+
 // folds the k_splits partial softmax states of every (query row, head): out = sum_s e^{m_s-M} O_s / sum_s e^{m_s-M} l_s
 __global__ __launch_bounds__(64) void flash_merge_kernel(FlashArgs a) {
     const int row = blockIdx.x, head = blockIdx.y, dd = threadIdx.x;
+    const bool batched = a.batch > 0;
+    float* const aout = batched ? table_at(a.z.out, blockIdx.z) : a.out;
+    const float* const part_o = batched ? table_at(a.z.res, blockIdx.z) : a.part_o;
+    const float* const part_m = batched ? part_o + (size_t)a.Tq * a.n_head * a.k_splits * 64 : a.part_m;
+    const float* const part_l = batched ? part_m + (size_t)a.Tq * a.n_head * a.k_splits : a.part_l;
     const long base = ((long)row * a.n_head + head) * a.k_splits;
     float M = -INFINITY;
-    for (int s = 0; s < a.k_splits; ++s) M = fmaxf(M, a.part_m[base + s]);
+    for (int s = 0; s < a.k_splits; ++s) M = fmaxf(M, part_m[base + s]);
     float L = 0.f, acc = 0.f;
     for (int s = 0; s < a.k_splits; ++s) {
-        const float f = expf(a.part_m[base + s] - M);
-        L += a.part_l[base + s] * f;
-        acc += a.part_o[(base + s) * 64 + dd] * f;
+        const float ms = part_m[base + s];
+        const float f = ms == -INFINITY ? 0.f : expf(ms - M);
+        L += part_l[base + s] * f;
+        acc += part_o[(base + s) * 64 + dd] * f;
     }
-    a.out[(long)row * a.ldo + head * 64 + dd] = acc / L;
+    aout[(long)row * a.ldo + head * 64 + dd] = acc / L;
 }
 
 constexpr int kRegsAttnLds = (NWAVE * QT * O_LD + 2 * NWAVE * QT) * (int)sizeof(float);
@@ -439,15 +647,55 @@ static void launch_enc_regs(const LaunchCtx& ctx, const FlashArgs& a, const char
     }
 }
 
+// key splits of the 64-query kernel: the split count whose grid is closest to whole rounds of 3 workgroups per CU
+int enc_attention_q64_splits(int T, int n_head, int batch) {
+    static const int forced = [] {
+        const char* e = getenv("WLK_ENC_KSPLIT");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced > 0) return std::min(forced, 8);
+    const long units = (long)((T + QT2 - 1) / QT2) * n_head * std::max(batch, 1);
+    const int n_pairs = (T + 2 * KT - 1) / (2 * KT);
+    // measured on MI355X (T = 1500): 192 units (8 heads) 88 us unsplit, 70 us with 4 splits (768 workgroups = three
+    // per CU) incl. the merge kernel; 480 units (20 heads) 139 us unsplit vs 151-197 us split - once the grid already
+    // fills the chip about twice over, the partial-state traffic and the merge launch cost more than the balance wins
+    if (units >= 400) return 1;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int ks = 1; ks <= 6 && ks <= n_pairs; ++ks) {
+        const double rounds = (double)units * ks / 768.0;
+        const double eff = rounds / std::ceil(rounds) - 0.03 * (ks - 1);     // each extra split costs merge traffic
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = ks; }
+    }
+    return best;
+}
+
+static void launch_enc_q64(const LaunchCtx& ctx, FlashArgs a, const char* tag) {
+    const size_t lds = kAttn2LdsFloats * sizeof(float);     // 34 KB: below the 64 KB default limit, no attribute needed
+    const int q_tiles = (a.Tq + QT2 - 1) / QT2;
+    const double nb = std::max(a.batch, 1);
+    KernelScope ks(ctx, tag, nb * 4.0 * a.Tq * (double)a.Tk * 64.0 * a.n_head,
+                   nb * 4.0 * 64.0 * a.n_head * (2.0 * a.Tq + 2.0 * a.Tk));
+    hipLaunchKernelGGL(enc_attention_q64_kernel, dim3(q_tiles * a.n_head * a.k_splits, std::max(a.batch, 1)), dim3(256), lds,
+                       ctx.stream, a);
+    WLK_HIP(hipGetLastError());
+    if (a.k_splits > 1) {
+        hipLaunchKernelGGL(flash_merge_kernel, dim3(a.Tq, a.n_head, std::max(a.batch, 1)), dim3(64), 0, ctx.stream, a);
+        WLK_HIP(hipGetLastError());
+    }
+}
+
 static void launch_flash(const LaunchCtx& ctx, const FlashArgs& a, const char* tag) {
-    static bool attr_set[64] = {};
+    // sessions launch from different host threads: the per-device "attribute set" marks are atomics (the call itself
+    // is idempotent, so a benign double set is all a race can cause)
+    static std::atomic<bool> attr_set[64];
     int dev = 0;
     WLK_HIP(hipGetDevice(&dev));
     const size_t lds = kAttnLdsTotal * sizeof(float);
-    if (dev < 64 && !attr_set[dev]) {
+    if (dev < 64 && !attr_set[dev].load(std::memory_order_acquire)) {
         WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attention_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     if (a.head_rank && a.Tk % 4 != 0) throw std::invalid_argument("flash attention: score dump needs Tk % 4 == 0");
     const int q_tiles = (a.Tq + QT - 1) / QT;
@@ -469,6 +717,18 @@ size_t flash_split_scratch_floats(int rows, int n_head, int k_splits) {
     return (size_t)rows * n_head * k_splits * (64 + 2);
 }
 
+// WLK_ENC_ATTN: "q64" (default) = 64-query kernel with balanced key splits, "lds" = the 32-query kernel,
+// "regs" = the register-fed variant (A/B switches; lds and regs measured slower on the encoder shapes)
+static int enc_attention_variant() {
+    static const int v = [] {
+        const char* e = getenv("WLK_ENC_ATTN");
+        if (e && e[0] == 'r') return 1;
+        if (e && e[0] == 'l') return 0;
+        return 2;
+    }();
+    return v;
+}
+
 void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out, int T, int d, int n_head,
                               int k_splits, float* split_scratch, const float* kv_head_major) {
     FlashArgs a;
@@ -483,12 +743,18 @@ void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out
         a.part_m = split_scratch + (size_t)T * n_head * k_splits * 64;
         a.part_l = a.part_m + (size_t)T * n_head * k_splits;
     }
-    static const int variant = [] {    // WLK_ENC_ATTN=regs selects the register-fed kernel (A/B switch; measured slower)
-        const char* e = getenv("WLK_ENC_ATTN");
-        return (e && e[0] == 'r') ? 1 : 0;
-    }();
-    if (variant == 1) launch_enc_regs(ctx, a, "enc_attention");
-    else launch_flash(ctx, a, "enc_attention");
+    const int variant = enc_attention_variant();
+    if (variant == 2 && split_scratch && !kv_head_major) {
+        a.k_splits = enc_attention_q64_splits(T, n_head, 1);
+        a.part_o = split_scratch;
+        a.part_m = split_scratch + (size_t)T * n_head * a.k_splits * 64;
+        a.part_l = a.part_m + (size_t)T * n_head * a.k_splits;
+        launch_enc_q64(ctx, a, "enc_attention");
+    } else if (variant == 1) {
+        launch_enc_regs(ctx, a, "enc_attention");
+    } else {
+        launch_flash(ctx, a, "enc_attention");
+    }
 }
 
 void launch_encoder_attention_batched(const LaunchCtx& ctx, const PtrTable& z, int batch, int T, int d, int n_head) {
@@ -496,7 +762,16 @@ void launch_encoder_attention_batched(const LaunchCtx& ctx, const PtrTable& z, i
     FlashArgs a;
     a.ldq = 3L * d; a.ldkv = 3L * d; a.ldo = d; a.Tq = T; a.Tk = T; a.n_head = n_head;
     a.batch = batch; a.z = z; a.z_k_off = d; a.z_v_off = 2L * d;
-    launch_flash(ctx, a, "enc_attention");
+    bool have_scratch = true;            // z.res[i] = the session's split scratch (flash_split_scratch_floats(T, H, 6))
+    for (int i = 0; i < batch; ++i) have_scratch &= z.res[i] != nullptr;
+    if (enc_attention_variant() == 2 && have_scratch) {
+        // the split count of ONE session, whatever the batch: a session's arithmetic (and its rounding) must not depend
+        // on who else encodes at the same time; B sessions are B whole copies of a balanced grid anyway
+        a.k_splits = enc_attention_q64_splits(T, n_head, 1);
+        launch_enc_q64(ctx, a, "enc_attention");
+    } else {
+        launch_flash(ctx, a, "enc_attention");
+    }
 }
 
 void launch_prefill_cross_attention(const LaunchCtx& ctx, const FlashArgs& a) { launch_flash(ctx, a, "dec_cross_attention_prefill"); }

@@ -124,7 +124,7 @@ int wlk_diag_encoder_attention_time(int t, int d, int n_head, int k_splits, int 
         std::vector<float> h((size_t)t * 3 * d);
         unsigned seed = 777u;
         for (auto& v : h) { seed = seed * 1664525u + 1013904223u; v = (((seed >> 8) & 0xffff) / 65536.0f - 0.5f) * 1.5f; }
-        DevBuf Q((size_t)t * 3 * d, h.data()), O((size_t)t * d), S(flash_split_scratch_floats(t, n_head, std::max(k_splits, 1)));
+        DevBuf Q((size_t)t * 3 * d, h.data()), O((size_t)t * d), S(flash_split_scratch_floats(t, n_head, 8));
         DevBuf KV((size_t)2 * t * d, h.data());
         hipStream_t st;
         WLK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -150,9 +150,9 @@ int wlk_diag_encoder_attention_time(int t, int d, int n_head, int k_splits, int 
 
 int wlk_diag_encoder_attention(const float* qkv, int t, int d, int n_head, float* out) {
     return run([&]() {
-        DevBuf Q((size_t)t * 3 * d, qkv), O((size_t)t * d);
+        DevBuf Q((size_t)t * 3 * d, qkv), O((size_t)t * d), S(flash_split_scratch_floats(t, n_head, 8));
         LaunchCtx ctx;
-        launch_encoder_attention(ctx, Q.p, O.p, t, d, n_head);
+        launch_encoder_attention(ctx, Q.p, O.p, t, d, n_head, 1, S.p);
         WLK_HIP(hipDeviceSynchronize());
         WLK_HIP(hipMemcpy(out, O.p, (size_t)t * d * sizeof(float), hipMemcpyDeviceToHost));
     });

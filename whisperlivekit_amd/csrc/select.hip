@@ -8,6 +8,8 @@
 // Reference: whisper/decoding.py:317-338,427-432; simul_whisper/simul_whisper.py:370-437;
 // whisper/timing.py:19-54.  Everything here is a small HBM/L2-bound reduction; wavefront
 // shuffles do the folding and nothing is copied to the host except k+1 numbers per beam row.
+#include <atomic>
+
 #include "common.h"
 
 namespace wlk {
@@ -360,13 +362,13 @@ void launch_alignatt(const LaunchCtx& ctx, const AlignArgs& a) {
     const size_t lds = (size_t)a.n_align * a.T * sizeof(float);
     KernelScope ks(ctx, "align_argmax");
     if (lds + 8192 + 1024 <= 150 * 1024) {
-        static bool attr_set[64] = {};
+        static std::atomic<bool> attr_set[64];   // launches come from several host threads
         int dev = 0;
         WLK_HIP(hipGetDevice(&dev));
-        if (dev < 64 && !attr_set[dev]) {
+        if (dev < 64 && !attr_set[dev].load(std::memory_order_acquire)) {
             WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(align_argmax_lds_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            attr_set[dev] = true;
+            attr_set[dev].store(true, std::memory_order_release);
         }
         hipLaunchKernelGGL(align_argmax_lds_kernel, dim3(a.n_beam), dim3(1024), lds, ctx.stream, a);
     } else {
