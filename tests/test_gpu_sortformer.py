@@ -2,6 +2,7 @@
 oracle/sortformer_oracle.py on the same seeded weights and inputs.  PARITY UNPINNED with respect to NeMo itself
 (no NeMo / checkpoint offline) - what is checked here is HIP path == oracle, fp32 tolerance stated per test."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -140,3 +141,53 @@ def test_full_depth_streaming_session_teacher_forced(full):
     assert segs and all(s.end >= s.start for s in segs)
     assert abs(segs[-1].end - 18.0) < 0.05 and segs[0].start == 0.0
     assert all(abs(a.end - b.start) < 1e-6 for a, b in zip(segs, segs[1:]))
+
+
+NEMO_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sortformer_nemo.npz")
+
+
+@pytest.mark.skipif(not (os.path.exists(NEMO_GOLDEN) and os.environ.get("WLK_SORTFORMER_MODEL_PATH")),
+                    reason="needs tests/golden/sortformer_nemo.npz (scripts/gen_golden_sortformer.py, run where NeMo is "
+                           "installed) and the same .nemo checkpoint in WLK_SORTFORMER_MODEL_PATH")
+def test_against_nemo_golden():
+    """a12 PINNED: the HIP diarizer on the real diar_streaming_sortformer_4spk-v2 weights against what NeMo itself
+    computed (dither 0) for the reference's two-speaker fixture signal - features, pre-encode, Conformer / Transformer
+    outputs and speaker activities of every streaming step, and the emitted segments."""
+    g = np.load(NEMO_GOLDEN, allow_pickle=True)
+    model = sf.HipSortformerModel.from_checkpoint(os.environ["WLK_SORTFORMER_MODEL_PATH"])
+    online = HipSortformerDiarizationOnline(model)
+    signal = g["signal"]
+    seen = []
+    inner = model.step
+
+    def step(feats, ctx):
+        out = inner(feats, ctx)
+        seen.append(dict(feats=feats, chunk=out[0], preds=out[1], fc=model.export("fc_out"), tf=model.export("tf_out")))
+        return out
+
+    model.step = step
+    segments = []
+    for lo in range(0, len(signal), 8000):
+        online.insert_audio_chunk(signal[lo:lo + 8000])
+        segments += online.diarize_sync()
+    n = int(g["n_calls"])
+    assert len(seen) == n
+    worst = dict(feats=0.0, pre=0.0, fc=0.0, tf=0.0)
+    for i in range(n):
+        worst["feats"] = max(worst["feats"], float(np.abs(seen[i]["feats"] - g[f"c{i}_feats"]).max()))
+        worst["pre"] = max(worst["pre"], float(np.abs(seen[i]["chunk"] - g[f"c{i}_pre_encode"][0]).max()))
+        fc = g[f"c{i}_fc_out"]
+        fc = fc[0].T if fc.ndim == 3 and fc.shape[1] == model.dims.fc_d_model else fc.reshape(-1, model.dims.fc_d_model)
+        worst["fc"] = max(worst["fc"], float(np.abs(seen[i]["fc"][: fc.shape[0]] - fc).max()))
+        tf = g[f"c{i}_tf_out"].reshape(-1, model.dims.tf_d_model)
+        worst["tf"] = max(worst["tf"], float(np.abs(seen[i]["tf"][: tf.shape[0]] - tf).max()))
+        assert online.streaming_state.spkcache_len >= 0
+    got_preds = np.asarray(online.total_preds)
+    ref_preds = g[f"c{n - 1}_total_preds"]
+    assert got_preds.shape == ref_preds.shape
+    assert np.abs(got_preds - ref_preds).max() <= 2e-3
+    assert worst["feats"] <= 1e-3 and worst["pre"] <= 2e-3 and worst["fc"] <= 5e-3 and worst["tf"] <= 5e-3, worst
+    want = g["segments"]
+    assert [(round(s.start, 2), round(s.end, 2), int(s.speaker)) for s in segments] == \
+           [(round(a, 2), round(b, 2), int(c)) for a, b, c in want]
+    model.close()

@@ -246,3 +246,38 @@ def test_product_module_does_not_import_the_oracle():
     import whisperlivekit_amd.sortformer as mod
     src = open(mod.__file__).read()
     assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_load_nemo_checkpoint_from_a_nemo_archive(tmp_path):
+    """``.nemo`` = tar with model_weights.ckpt (a torch state dict) + model_config.yaml: the loader must find the
+    weights whatever prefix the archive uses, recover the geometry from the tensor shapes, and the packer must place
+    every tensor (what HipSortformerModel.from_checkpoint does before it touches the GPU)."""
+    import io
+    import tarfile
+
+    import torch
+
+    from whisperlivekit_amd import sortformer as sf
+    dims = sf.SortformerDims(fc_layers=2, tf_layers=3)
+    sd = sf.synth_sortformer_state_dict(dims, 5)
+    blob = io.BytesIO()
+    state = {k: torch.from_numpy(np.asarray(v)).half() if i % 7 == 0 else torch.from_numpy(np.asarray(v))
+             for i, (k, v) in enumerate(sd.items())}          # a few fp16 tensors: the loader widens to fp32
+    state["some.int.buffer"] = torch.arange(4)                # non-float entries are skipped
+    torch.save(state, blob)
+    path = tmp_path / "diar_test.nemo"
+    with tarfile.open(path, "w") as tar:
+        for name, data in (("./model_config.yaml", b"sample_rate: 16000\n"), ("./abc123_model_weights.ckpt", blob.getvalue())):
+            info = tarfile.TarInfo(name)
+            info.size = len(data)
+            tar.addfile(info, io.BytesIO(data))
+    got = sf.load_nemo_checkpoint(str(path))
+    assert set(got) == set(sd) and all(v.dtype == np.float32 for v in got.values())
+    for k in sd:
+        tol = 2e-3 if state[k].dtype == torch.float16 else 0.0
+        assert np.abs(got[k] - sd[k]).max() <= tol * max(1.0, float(np.abs(sd[k]).max())), k
+    d2 = sf.dims_from_state_dict(got)
+    assert (d2.fc_layers, d2.tf_layers, d2.fc_d_model, d2.tf_d_model, d2.n_spk, d2.n_mels) == \
+           (2, 3, dims.fc_d_model, dims.tf_d_model, dims.n_spk, dims.n_mels)
+    packed = sf.pack_sortformer_state_dict(d2, got, max_frames=64)
+    assert all(np.isfinite(v).all() for v in packed.values()) and "pre.out.w" in packed
