@@ -377,9 +377,16 @@ static wlk_engine* engine_create(wlk_model* m) {
     e->max_rows = rows;
     if (const char* env = std::getenv("WLK_ENGINE_MAX_ROWS")) e->max_rows = std::max(1, std::min(rows, std::atoi(env)));
     WLK_HIP(hipSetDevice(m->device));
-    WLK_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    // the batched decode steps are chains of tiny latency-bound kernels, the encodes are GPU-filling GEMMs: the step
+    // stream gets the highest priority so its workgroups are dispatched ahead of queued encoder workgroups
+    // (WLK_ENGINE_PRIORITY=0 switches that off)
+    int prio_lo = 0, prio_hi = 0;
+    WLK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    const char* pe = std::getenv("WLK_ENGINE_PRIORITY");
+    const bool prio = !(pe && pe[0] == '0');
+    WLK_HIP(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio ? prio_hi : prio_lo));
     if (const char* g = std::getenv("WLK_NO_GRAPH")) e->use_graph = !(g[0] == '1');
-    WLK_HIP(hipStreamCreateWithFlags(&e->enc_stream, hipStreamNonBlocking));
+    WLK_HIP(hipStreamCreateWithPriority(&e->enc_stream, hipStreamNonBlocking, prio_lo));
     if (const char* g = std::getenv("WLK_BATCH_ENCODE")) e->batch_encodes = !(g[0] == '0');
     if (const char* g = std::getenv("WLK_ENCODE_GATHER_US")) e->gather_us = std::max(0, std::atoi(g));
     const size_t R = 8, d = D.n_text_state, T = D.n_audio_ctx, V = D.n_vocab;
