@@ -30,3 +30,13 @@ s = q @ k.transpose(0, 2, 1)
 p = np.exp(s - s.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
 ref = (p @ v).transpose(1, 0, 2).reshape(T, d)
 print("max abs err vs fp64:", float(np.abs(out - ref).max()))
+# full-size output (T = 1500, 8 heads) saved for a bitwise comparison between kernel variants
+T, d, H = 1500, 512, 8
+qkv = (rng.standard_normal((T, 3 * d)) * 0.5).astype(np.float32)
+out = np.empty((T, d), np.float32)
+assert lib.wlk_diag_encoder_attention(vp(qkv), T, d, H, vp(out)) == 0
+tag = os.environ.get("WLK_ENC_ATTN", "default")
+np.save(f"/tmp/attn_out_{tag}.npy", out)
+if tag != "lds" and os.path.exists("/tmp/attn_out_lds.npy"):
+    ref = np.load("/tmp/attn_out_lds.npy")
+    print(f"{tag} vs lds: bitwise equal = {bool(np.array_equal(out, ref))}, max abs diff = {float(np.abs(out - ref).max()):.3e}")
