@@ -1,9 +1,6 @@
-mkdir -p gpurun_out; R=$PWD; export TMPDIR=/tmp; cd /tmp
-for cfg in "batch:" "nobatch:WLK_BATCH_ENCODE=0 WLK_BATCH_DECODE=0"; do
-  n=${cfg%%:*}; e=${cfg#*:}
-  env $e timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/trace8_$n -o t -- python $R/scripts/eight_stream_probe.py 8 > $R/gpurun_out/trace8_$n.log 2>&1
-  grep "^pass\|^{" $R/gpurun_out/trace8_$n.log
-  DB=$(find $R/gpurun_out/trace8_$n -name "*.db" | head -1)
-  [ -n "$DB" ] && python $R/scripts/trace_busy.py $DB 900
-done
-rm -rf $R/gpurun_out/trace8_*/
+# rocprofv3 kernel trace of the 8-stream workload on one GPU: how busy is the GPU, and with what (profiles/r02_trace8_*.txt)
+mkdir -p gpurun_out/r02; R=$PWD; export TMPDIR=/tmp; cd /tmp
+timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/trace8_batch -o t -- python $R/scripts/eight_stream_probe.py 8 > $R/gpurun_out/trace8_batch.log 2>&1
+( grep "^pass\|^{" $R/gpurun_out/trace8_batch.log; python $R/scripts/trace_busy.py $(find $R/gpurun_out/trace8_batch -name "*.db" | head -1) 900 ) > $R/gpurun_out/r02/trace8_busy.txt
+cat $R/gpurun_out/r02/trace8_busy.txt
+rm -rf $R/gpurun_out/trace8_batch/

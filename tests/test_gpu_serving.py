@@ -200,6 +200,35 @@ def test_bench_checks_its_own_outputs_against_the_reference():
         json.dump(line, fh)
 
 
+def test_bench_multi_rank_code_path_rehearsal():
+    """The N > 1 path of bench.py end to end on ONE GPU: `--gpus 2` re-executes itself under torch.distributed.run, both
+    ranks share device 0 and talk over gloo (WLK_BENCH_REHEARSAL=1; RCCL refuses two ranks per device).  Exercises the
+    arena broadcast + adoption, barriers, max-over-ranks timing, stream sharding (i mod N) of the 8-stream leg, the
+    object gathers and the merged parity report - what the driver's 2/4/8-GPU runs go through."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["WLK_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-diarization"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and len(line["per_rank_audio_s_per_s"]) == 2
+    assert line["weight_broadcast_ms"] is not None and "rehearsal" in line
+    e = line["eight_streams"]
+    assert e["gpus"] == 2 and len(e["per_rank_audio_s_per_s"]) == 2 and e["swallowed_errors"] == 0
+    pc = line["parity_checked"]
+    assert pc["sessions"] == 2 + 8 and pc["mismatches"] == [] and not pc["missing_golden"], pc
+    if not pc["tie_divergences"]:
+        assert pc["identical"] == pc["decisions"], pc
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "8", "--steps", "1",
+                         "--warmup", "0", "--no-cpu-baseline", "--no-diarization", "--no-eight-streams"],
+                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    strong = json.loads([l for l in r2.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert strong["scaling"] == "strong" and strong["config"]["streams_total"] == 8 and strong["config"]["streams_this_rank"] == 4
+    assert strong["parity_checked"]["sessions"] == 8 and strong["parity_checked"]["mismatches"] == []
+
+
 def test_bench_refuses_more_gpus_than_visible():
     n = _lib.device_count() + 1
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}

@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
     float m_run = -INFINITY, l_run = 0.f;
 
     // staging map: per iteration 128 keys x 64 floats for K and for V = 2048 float4 each, 8 per thread
-    const float* kbase = ak + head * a.kv_hs;
-    const float* vbase = av + head * a.kv_hs;
+    const float* kbase = ak + head * 64;
+    const float* vbase = av + head * 64;
     // alignment-head score dump (decoder prefill only)
     const int rank = a.head_rank ? a.head_rank[head] : -1;
     float* dump = nullptr;
@@ -252,167 +252,6 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Encoder self-attention without LDS staging ("register-fed"): the same arithmetic as flash_attention_kernel, but
-// every wave feeds its MFMAs straight from global memory.  With S^T = K Q^T the A fragment of a QK^T step is 16
-// bytes of ONE key row per lane (two lanes share a 32-byte sector, the eight steps of a tile walk the 256-byte row),
-// the A fragment of a PV step is V[key][d = lane] (two fully coalesced 128-byte segments per instruction), and the
-// Q fragments (B operand of QK^T) are loop invariant and live in 32 registers.  No K/V tile ever enters LDS, so the
-// main loop has NO barrier: the four waves of a workgroup run their key tiles independently (the next tile's K is
-// requested at the start of the PV phase, the tile's own V at the start of its QK^T phase - a 2048-cycle head start
-// on a ~500-cycle L2 hit), ~150 VGPRs give three waves per SIMD, and LDS is touched only by the final merge of the
-// four partial softmax states.  Key tiles are dealt round-robin over the 4 x k_splits waves of a (query tile, head):
-// with k_splits = 1 the assignment, the per-wave accumulation order and the merge are those of the LDS kernel (bit
-// identical results); k_splits = 2 gives 752 workgroups of 34 KB LDS on 256 CUs (3 resident per CU), which evens out
-// the 376-tile grid that leaves a third of the chip idle in its second round.
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void enc_attention_regs_kernel(FlashArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int T = a.Tk;
-    const int n_head = a.n_head;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int head = blockIdx.x % n_head;
-    const int q_tiles = (a.Tq + QT - 1) / QT;
-    const int qt_idx = (blockIdx.x / n_head) % q_tiles;
-    const int ks = blockIdx.x / (n_head * q_tiles);
-    const int q0 = qt_idx * QT;
-    const long ld = a.ldkv;
-    const int half = lane >> 5, lq = lane & 31;
-
-    // Q fragments: lane (half, lq) supplies Q[q0 + lq][8 g + 4 half .. +4] to MFMA group g
-    float4 qf[8];
-    {
-        const int qr = min(q0 + lq, a.Tq - 1);
-        const float* qp = a.q + (long)qr * a.ldq + head * 64 + half * 4;
-        const bool ok = q0 + lq < a.Tq;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const float4 v = *reinterpret_cast<const float4*>(qp + g * 8);
-            qf[g] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    f32x16 o0, o1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
-
-    const int n_tiles = (T + KT - 1) / KT;
-    const int stride = NWAVE * a.k_splits;            // key tiles between two tiles of this wave
-    const int first = ks * NWAVE + wave;
-    const float* kbase = a.k + head * a.kv_hs + half * 4;  // + key * ld + 8 g
-    const float* vbase = a.v + head * a.kv_hs + lq;        // + key * ld (+ 32)
-
-    float4 kf[8];
-    auto load_k = [&](int tile) {
-        const int key = tile * KT + lq;
-        const bool ok = key < T;
-        const float* kp = kbase + (long)(ok ? key : 0) * ld;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const float4 v = *reinterpret_cast<const float4*>(kp + g * 8);
-            kf[g] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    if (first < n_tiles) load_k(first);
-    for (int tile = first; tile < n_tiles; tile += stride) {
-        const int key0 = tile * KT;
-        // V of this tile: row r of the PV step pairs key (r&3)+8(r>>2) (lanes 0-31) with that key + 4 (lanes 32-63)
-        float vf0[16], vf1[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const bool ok = key < T;
-            const float* vp = vbase + (long)(ok ? key : 0) * ld;
-            const float x0 = vp[0], x1 = vp[32];
-            vf0[r] = ok ? x0 : 0.f;
-            vf1[r] = ok ? x1 : 0.f;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        f32x16 s;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = 0.f;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[g].x, qf[g].x, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[g].y, qf[g].y, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[g].z, qf[g].z, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[g].w, qf[g].w, s, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (tile + stride < n_tiles) load_k(tile + stride);     // lands during the softmax + PV phase
-        __builtin_amdgcn_sched_barrier(0);
-        float mt = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (key >= T) s[r] = -INFINITY;
-            mt = fmaxf(mt, s[r]);
-        }
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = __expf(m_run - m_new);
-        float rs = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = __expf(s[r] - m_new);
-            rs += s[r];
-        }
-        rs += __shfl_xor(rs, 32, 64);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf0[r], s[r], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf1[r], s[r], o1, 0, 0, 0);
-        }
-    }
-
-    // merge of the four partial states: identical to flash_attention_kernel's
-    float* Os = lds;                               // [NWAVE][QT][O_LD]
-    float* Ms = lds + NWAVE * QT * O_LD;           // [NWAVE][QT]
-    float* Ls = Ms + NWAVE * QT;                   // [NWAVE][QT]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int dd = (r & 3) + 8 * (r >> 2) + 4 * half;
-        Os[(wave * QT + lq) * O_LD + dd] = o0[r];
-        Os[(wave * QT + lq) * O_LD + 32 + dd] = o1[r];
-    }
-    if (half == 0) {
-        Ms[wave * QT + lq] = m_run;
-        Ls[wave * QT + lq] = l_run;
-    }
-    __syncthreads();
-    {
-        const int dd = tid & 63;
-        const int qg = tid >> 6;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int q = qg * 8 + i;
-            const int qrow = q0 + q;
-            float M = Ms[q];
-#pragma unroll
-            for (int w = 1; w < NWAVE; ++w) M = fmaxf(M, Ms[w * QT + q]);
-            float L = 0.f, acc = 0.f;
-#pragma unroll
-            for (int w = 0; w < NWAVE; ++w) {
-                const float e = expf(Ms[w * QT + q] - M);
-                L += e * Ls[w * QT + q];
-                acc += e * Os[(w * QT + q) * O_LD + dd];
-            }
-            if (a.k_splits == 1) {
-                if (qrow < a.Tq) a.out[(long)qrow * a.ldo + head * 64 + dd] = acc / L;
-            } else if (qrow < a.Tq) {
-                const long slot = ((long)qrow * n_head + head) * a.k_splits + ks;
-                a.part_o[slot * 64 + dd] = acc;
-                if (dd == 0) { a.part_m[slot] = M; a.part_l[slot] = L; }
-            }
-        }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------
 // Encoder self-attention, 64 queries per workgroup WITH the 32-query kernel's arithmetic ("q64x"): eight waves =
 // two query sub-tiles x the same four key streams (stream w = key tiles w, w+4, w+8, ...), the four K/V tiles of an
 // iteration staged once in LDS and read by both sub-tiles (half the global -> LDS traffic per MFMA, which
@@ -453,8 +292,8 @@ __global__ __launch_bounds__(512) void enc_attention_q64x_kernel(FlashArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
-    const float* kbase = ak + head * a.kv_hs;
-    const float* vbase = av + head * a.kv_hs;
+    const float* kbase = ak + head * 64;
+    const float* vbase = av + head * 64;
     float4 rk[4], rv[4];                        // 128 keys x 16 float4 for K and for V over 512 threads
     auto fetch = [&](int it) {
 #pragma unroll
@@ -644,8 +483,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
-    const float* kbase = ak + head * a.kv_hs;
-    const float* vbase = av + head * a.kv_hs;
+    const float* kbase = ak + head * 64;
+    const float* vbase = av + head * 64;
     // staging map: a pair = 64 keys x 64 floats for K and for V = 1024 float4 each, 4 + 4 per thread
     float4 rk[4], rv[4];
     auto fetch = [&](int pair) {
@@ -807,21 +646,6 @@ __global__ __launch_bounds__(64) void flash_merge_kernel(FlashArgs a) {
     aout[(long)row * a.ldo + head * 64 + dd] = acc / L;
 }
 
-constexpr int kRegsAttnLds = (NWAVE * QT * O_LD + 2 * NWAVE * QT) * (int)sizeof(float);
-
-static void launch_enc_regs(const LaunchCtx& ctx, const FlashArgs& a, const char* tag) {
-    const int q_tiles = (a.Tq + QT - 1) / QT;
-    KernelScope ks(ctx, tag, 4.0 * a.Tq * (double)a.Tk * 64.0 * a.n_head,
-                   4.0 * 64.0 * a.n_head * (2.0 * a.Tq + 2.0 * a.Tk));
-    hipLaunchKernelGGL(enc_attention_regs_kernel, dim3(q_tiles * a.n_head * a.k_splits), dim3(256), kRegsAttnLds,
-                       ctx.stream, a);
-    WLK_HIP(hipGetLastError());
-    if (a.k_splits > 1) {
-        hipLaunchKernelGGL(flash_merge_kernel, dim3(a.Tq, a.n_head), dim3(64), 0, ctx.stream, a);
-        WLK_HIP(hipGetLastError());
-    }
-}
-
 // key splits of the 64-query kernel: the split count whose grid is closest to whole rounds of 3 workgroups per CU
 int enc_attention_q64_splits(int T, int n_head, int batch) {
     static const int forced = [] {
@@ -918,12 +742,10 @@ size_t flash_split_scratch_floats(int rows, int n_head, int k_splits) {
 // "lds" = the 32-query kernel, "q64" = the 64-query kernel with balanced key splits
 // (13 % faster per launch on base.en and large-v3, but it sums the keys in different groups: on the 8 reference-pinned
 // benchmark streams one AlignAtt arg-max whose reference margin is 1.8e-7 - an exact tie in fp32 - then goes to the
-// other frame, so it is opt-in until a form with the 32-query kernel's key grouping exists), "regs" = the
-// register-fed variant (measured slower)
+// other frame, so it is opt-in).  A register-fed variant without LDS staging was measured and dropped.
 static int enc_attention_variant() {
     static const int v = [] {
         const char* e = getenv("WLK_ENC_ATTN");
-        if (e && e[0] == 'r') return 1;
         if (e && e[0] == 'q') return 2;
         if (e && e[0] == 'l') return 0;
         return 3;                       // q64x: 64 queries per workgroup, the 32-query kernel's arithmetic
@@ -932,13 +754,10 @@ static int enc_attention_variant() {
 }
 
 void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out, int T, int d, int n_head,
-                              int k_splits, float* split_scratch, const float* kv_head_major) {
+                              int k_splits, float* split_scratch) {
     FlashArgs a;
     a.q = qkv; a.ldq = 3L * d; a.k = qkv + d; a.v = qkv + 2 * d; a.ldkv = 3L * d; a.out = out; a.ldo = d;
     a.Tq = T; a.Tk = T; a.n_head = n_head;
-    if (kv_head_major) {     // k: [H][T][64], v: the same right behind it
-        a.k = kv_head_major; a.v = kv_head_major + (size_t)n_head * T * 64; a.ldkv = 64; a.kv_hs = (long)T * 64;
-    }
     if (k_splits > 1 && split_scratch) {   // key ranges on separate workgroups + merge: evens out the 376-tile grid
         a.k_splits = k_splits;
         a.part_o = split_scratch;
@@ -946,15 +765,13 @@ void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out
         a.part_l = a.part_m + (size_t)T * n_head * k_splits;
     }
     const int variant = enc_attention_variant();
-    if (variant == 2 && split_scratch && !kv_head_major) {
+    if (variant == 2 && split_scratch) {
         a.k_splits = enc_attention_q64_splits(T, n_head, 1);
         a.part_o = split_scratch;
         a.part_m = split_scratch + (size_t)T * n_head * a.k_splits * 64;
         a.part_l = a.part_m + (size_t)T * n_head * a.k_splits;
         launch_enc_q64(ctx, a, "enc_attention");
-    } else if (variant == 1) {
-        launch_enc_regs(ctx, a, "enc_attention");
-    } else if (variant == 3 && !kv_head_major) {
+    } else if (variant == 3) {
         launch_enc_q64x(ctx, a, "enc_attention");
     } else {
         launch_flash(ctx, a, "enc_attention");

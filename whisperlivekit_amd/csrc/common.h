@@ -202,10 +202,7 @@ void launch_melspec(const LaunchCtx& ctx, const MelSpecArgs& a, int n_frames);
 // flash-style fp32-MFMA attention: q rows [Tq] against k/v rows [Tk], 64-wide heads, no mask
 struct FlashArgs {
     const float* q = nullptr; long ldq = 0;      // query row r, head h at q + r*ldq + 64h (pre-scaled)
-    const float* k = nullptr; const float* v = nullptr; long ldkv = 0;  // key t at k + t*ldkv + kv_hs*h (pre-scaled)
-    long kv_hs = 64;                             // head stride of k / v: 64 = heads side by side in a row; Tk*64 with
-                                                 // ldkv = 64 = head-major [H][Tk][64] (every key row of a head is the
-                                                 // next 256 bytes: spreads one head's traffic over all L2 channels)
+    const float* k = nullptr; const float* v = nullptr; long ldkv = 0;  // key t at k + t*ldkv + 64h (pre-scaled)
     float* out = nullptr; long ldo = 0;
     int Tq = 0, Tk = 0, n_head = 0;
     // decoder prefill only: raw scores of alignment heads go to the alignment window
@@ -228,7 +225,7 @@ struct FlashArgs {
 size_t flash_split_scratch_floats(int rows, int n_head, int k_splits);
 // encoder self-attention over qkv[T][3d] (q and k pre-scaled), out[T][d]
 void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out, int T, int d, int n_head,
-                              int k_splits = 1, float* split_scratch = nullptr, const float* kv_head_major = nullptr);
+                              int k_splits = 1, float* split_scratch = nullptr);
 // encoder self-attention of `batch` sessions in one launch: qkv = z.in[i] ([T][3d]), out = z.out[i]
 void launch_encoder_attention_batched(const LaunchCtx& ctx, const PtrTable& z, int batch, int T, int d, int n_head);
 void launch_prefill_cross_attention(const LaunchCtx& ctx, const FlashArgs& a);

@@ -118,18 +118,17 @@ int wlk_diag_layernorm(const float* x, const float* gamma, const float* beta, in
 }
 
 int wlk_diag_encoder_attention_time(int t, int d, int n_head, int k_splits, int reps, float* us_per_launch) {
-    const bool head_major = k_splits >= 100;     // probe switch: +100 = k / v in head-major layout
-    k_splits %= 100;
+
     return run([&]() {
         std::vector<float> h((size_t)t * 3 * d);
         unsigned seed = 777u;
         for (auto& v : h) { seed = seed * 1664525u + 1013904223u; v = (((seed >> 8) & 0xffff) / 65536.0f - 0.5f) * 1.5f; }
         DevBuf Q((size_t)t * 3 * d, h.data()), O((size_t)t * d), S(flash_split_scratch_floats(t, n_head, 8));
-        DevBuf KV((size_t)2 * t * d, h.data());
+
         hipStream_t st;
         WLK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         LaunchCtx ctx{st, nullptr};
-        auto go = [&]() { launch_encoder_attention(ctx, Q.p, O.p, t, d, n_head, k_splits, S.p, head_major ? KV.p : nullptr); };
+        auto go = [&]() { launch_encoder_attention(ctx, Q.p, O.p, t, d, n_head, k_splits, S.p); };
         go();
         WLK_HIP(hipStreamSynchronize(st));
         hipEvent_t e0, e1;
