@@ -738,17 +738,18 @@ size_t flash_split_scratch_floats(int rows, int n_head, int k_splits) {
     return (size_t)rows * n_head * k_splits * (64 + 2);
 }
 
-// WLK_ENC_ATTN: default = "q64x" (64 queries per workgroup with the 32-query kernel's arithmetic: bit-identical to it),
-// "lds" = the 32-query kernel, "q64" = the 64-query kernel with balanced key splits
-// (13 % faster per launch on base.en and large-v3, but it sums the keys in different groups: on the 8 reference-pinned
-// benchmark streams one AlignAtt arg-max whose reference margin is 1.8e-7 - an exact tie in fp32 - then goes to the
-// other frame, so it is opt-in).  A register-fed variant without LDS staging was measured and dropped.
+// WLK_ENC_ATTN selects the encoder self-attention kernel.  Default "lds" = the 32-query kernel.  Two 64-query forms are
+// kept as opt-in A/B variants: "q64x" (eight waves, the 32-query kernel's arithmetic, bit-identical output: 80.2 -> 74.5
+// us per launch back to back) and "q64" (balanced key splits + merge: 70 us, but it regroups the key sums - one exact-tie
+// AlignAtt arg-max of the 8 pinned bench streams then falls the other way).  Inside the real launch chain neither beats
+// the default (same box, alternating runs: 135.0 / 134.1 audio-s/s for one stream, 273 / 268 / 262 for 8 streams with
+// lds / q64x / q64): their wins are L2-warm effects of timing one kernel in a loop.  A register-fed variant without
+// LDS staging was slower everywhere and is gone.
 static int enc_attention_variant() {
     static const int v = [] {
         const char* e = getenv("WLK_ENC_ATTN");
-        if (e && e[0] == 'q') return 2;
-        if (e && e[0] == 'l') return 0;
-        return 3;                       // q64x: 64 queries per workgroup, the 32-query kernel's arithmetic
+        if (e && e[0] == 'q') return (e[1] == '6' && e[2] == '4' && e[3] == 'x') ? 3 : 2;
+        return 0;
     }();
     return v;
 }
