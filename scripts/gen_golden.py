@@ -344,6 +344,11 @@ def gen_streams():
                                                                             max_context_tokens=12)),
         "micro_minlen_beam3": lambda: run_stream("micro.en", a12[:112000], cfg_over=dict(audio_min_len=1.0, frame_threshold=10,
                                                                                            beam_size=3)),
+        # one segment LONGER than the 30 s window (insert_audio only evicts while more than one segment is buffered):
+        # content_mel_len = 1750 > 1500 encoder positions - the reference clips the attention slice, keeps the unclipped
+        # value in its frame-threshold test and keeps decoding (simul_whisper.py:432, align_att_base.py:280-286)
+        "micro_single_35s": lambda: run_stream("micro.en", synth.to_pcm16_roundtrip(synth.speech_like(36.0, 8)),
+                                               chunks=[(0, 560000), (560000, 568000), (568000, 576000)]),
     }
     # the workload bench.py times (BASELINE.json configs[1] and the 8-stream half of the metric): base.en, 30 s
     # speech-like streams seeds 0..7, 60 x 0.5 s chunks, engine defaults.  bench.py replays these on the timed

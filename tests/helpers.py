@@ -136,6 +136,7 @@ def stream_audio(case_name):
         "micro_minlen_beam3": lambda: a12()[:112000],
         "micromulti_auto": lambda: a12()[:128000],
         "large_v3_2s": lambda: synth.to_pcm16_roundtrip(synth.speech_like(2.0, 5)),
+        "micro_single_35s": lambda: synth.to_pcm16_roundtrip(synth.speech_like(36.0, 8)),
         "micro_realvocab": lambda: synth.to_pcm16_roundtrip(synth.speech_like(16.0, 6)),
         "micro_realvocab_beam2": lambda: synth.to_pcm16_roundtrip(synth.speech_like(10.0, 7)),
     }

@@ -27,7 +27,7 @@ def _hip_model(name, seed):
     return _models[(name, seed)]
 
 
-@pytest.mark.parametrize("case", ["micro_12s", "micro_34s_evict", "micro_beam2", "micro_events", "micro_minlen_beam3",
+@pytest.mark.parametrize("case", ["micro_12s", "micro_34s_evict", "micro_beam2", "micro_events", "micro_minlen_beam3", "micro_single_35s",
                                   "micromulti_auto", "tiny_6s", "base_4s", "bench_base_30s_s0"])
 def test_reference_processor_and_policy_over_real_hip_hooks(case):
     from test_oracle_golden import check_stream_against_golden, replay_stream

@@ -55,7 +55,8 @@ def test_oracle_encoder_decoder_match_reference(name):
 STREAMS = ["micro_12s", "micro_34s_evict", "micro_beam2", "micro_neverfire", "micro_nospeech",
            "micro_events", "micro_noise_ragged", "tiny_6s", "base_4s",
            "micro_cif", "micromulti_auto",      # a11: CIF end-of-word head, language auto-detect
-           "micro_prompt", "micro_minlen_beam3"]  # a9/a10 corners: prompt context budget; min segment length, beam 3
+           "micro_prompt", "micro_minlen_beam3",  # a9/a10 corners: prompt context budget; min segment length, beam 3
+           "micro_single_35s"]                    # one segment longer than the 30 s window: content_mel_len > 1500
 
 
 def replay_stream(case, make_processor, max_events=None):

@@ -87,7 +87,7 @@ def _make(model_name, cfg_over, seed=0, model_factory=None):
 
 
 @pytest.mark.parametrize("case", ["micro_12s", "micro_34s_evict", "micro_beam2", "micro_neverfire", "micro_events",
-                                  "micro_cif", "micromulti_auto", "micro_prompt", "micro_minlen_beam3"])
+                                  "micro_cif", "micromulti_auto", "micro_prompt", "micro_minlen_beam3", "micro_single_35s"])
 def test_reference_policy_runs_unmodified_on_hip_hooks(case):
     g, proc, got = replay_stream(case, _make)
     from whisperlivekit.simul_whisper.align_att_base import AlignAttBase
