@@ -235,3 +235,23 @@ def test_bench_refuses_more_gpus_than_visible():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1"],
                        capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+
+
+def test_finalized_model_is_immutable():
+    """include/wlk_hip.h: a wlk_model is immutable after wlk_model_finalize - sessions size their alignment window from
+    it and captured step graphs bake the per-layer head counts in.  Late uploads / head changes must be refused."""
+    import ctypes as C
+    from whisperlivekit_amd.engine import HipWhisperModel
+    m = HipWhisperModel.synthetic("micro.en", 0)
+    lib = _lib.load()
+    w = np.zeros(128, np.float32)
+    rc = lib.wlk_model_upload(m._h, b"enc.conv1.b", w.ctypes.data_as(C.c_void_p), w.size)
+    assert rc == -3 and b"finalized" in lib.wlk_last_error()
+    pairs = np.asarray([1, 0], np.int32)
+    rc = lib.wlk_model_set_alignment_heads(m._h, pairs.ctypes.data_as(C.c_void_p), 1)
+    assert rc == -3 and b"finalized" in lib.wlk_last_error()
+    s = m.new_session()
+    s.append(synth.to_pcm16_roundtrip(synth.speech_like(1.0, 0)))
+    assert s.encode() == 50
+    s.close()
+    m.close()
