@@ -4,7 +4,7 @@ This file restates, in plain fp32 PyTorch-CPU tensor ops, the arithmetic of the 
 WhisperLiveKit path  log-mel -> Whisper encoder -> decoder with cross-attention QK ->
 AlignAtt post-processing -> beam/greedy token update -> AlignAtt streaming policy.
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
-it; the product package ``whisperlivekit_amd`` never does (tests/test_layout.py enforces that).
+it; the product package ``whisperlivekit_amd`` never does (tests/test_abi_cpu.py::test_product_never_imports_the_oracle enforces that).
 
 Pinning: the reference ships no numeric golden vectors for this path, so the
 oracle is pinned against OUTPUTS OF THE REFERENCE ITSELF, produced in the build container by
