@@ -230,7 +230,7 @@ def test_mel_matches_reference_golden(key):
     assert worst <= 1e-3 and tail_err <= 1e-6          # north star: mel within 1e-3
 
 
-@pytest.mark.parametrize("name", ["micro.en", "tiny.en", "base.en", "large-v3"])
+@pytest.mark.parametrize("name", ["micro.en", "tiny.en", "base.en", "small.en", "medium.en", "large-v3"])
 def test_encoder_decoder_match_reference_golden(name):
     if not os.path.exists(os.path.join(H.GOLDEN, f"numerics_{name}.npz")):
         pytest.skip(f"numerics_{name}.npz not generated")

@@ -29,7 +29,7 @@ def test_oracle_mel_matches_reference(key):
         assert np.abs(mel[:, :meta["keep"]].mean(axis=0) - gold[key + "_colmean"]).max() <= 1e-6
 
 
-@pytest.mark.parametrize("name", ["micro.en", "tiny.en", "base.en"])
+@pytest.mark.parametrize("name", ["micro.en", "tiny.en", "base.en", "small.en"])
 def test_oracle_encoder_decoder_match_reference(name):
     gold = H.golden_npz(f"numerics_{name}.npz")
     dims = MODEL_DIMS[name]
