@@ -595,3 +595,44 @@ def test_large_v3_shapes_smoke():
     report("large_v3_widths", enc_err=e_enc, logits_err=worst)
     sess.close(); model.close()
     assert cml == rcml and e_enc <= 1e-3 and worst <= 1e-3
+
+
+def test_incremental_mel_is_bit_identical_to_full_recompute(monkeypatch):
+    """SURVEY 8f rank 2 (mel half): per-frame log-mel results stay in the session and only the frames the new chunk
+    touches are recomputed (+ the two reflect-padded head frames after an eviction of whole frames; anything else
+    invalidates the cache).  Against a session that recomputes everything (WLK_MEL_INCREMENTAL=0): identical mel and
+    encoder output, bit for bit, through appends of ragged sizes, zero runs, frame-aligned and unaligned evictions,
+    a clear, and a buffer longer than 30 s."""
+    m = hip_model("micro.en")
+    rng = np.random.default_rng(3)
+    audio = synth.to_pcm16_roundtrip(synth.speech_like(70.0, 9))
+    monkeypatch.setenv("WLK_MEL_INCREMENTAL", "1")
+    inc = m.new_session(beam=1, max_audio_seconds=64.0, batched=False)
+    monkeypatch.setenv("WLK_MEL_INCREMENTAL", "0")
+    full = m.new_session(beam=1, max_audio_seconds=64.0, batched=False)
+    pos = 0
+    script = [("a", 8000), ("a", 8000), ("a", 123), ("a", 1), ("z", 4000), ("a", 16000), ("d", 8000), ("a", 8000), ("d", 160),
+              ("a", 333), ("d", 777), ("a", 8000), ("a", 480000), ("d", 16000), ("a", 8000), ("d", 8000), ("a", 8000),
+              ("c", 0), ("a", 5000), ("a", 8000), ("d", 3200), ("a", 8000)]
+    n_enc = 0
+    for op, n in script:
+        for s in (inc, full):
+            if op == "a":
+                s.append(audio[pos:pos + n])
+            elif op == "z":
+                s.append_zeros(n)
+            elif op == "d":
+                s.drop_front(n)
+            else:
+                s.clear_audio()
+        if op == "a":
+            pos += n
+        if inc.audio_len == 0:
+            continue
+        c1, c2 = inc.encode(), full.encode()
+        assert c1 == c2
+        assert np.array_equal(inc.export("mel"), full.export("mel")), (op, n, inc.audio_len)
+        n_enc += 1
+    assert np.array_equal(inc.export("enc"), full.export("enc"))
+    assert n_enc >= 20
+    inc.close(); full.close()

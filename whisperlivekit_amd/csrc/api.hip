@@ -336,6 +336,9 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         s->frame_cap = s->audio_cap / kHop + 4;
         s->logmel = dev_alloc<float>((size_t)s->frame_cap * D.n_mels);
         s->frame_max = dev_alloc<float>(s->frame_cap);
+        s->logmel_alt = dev_alloc<float>((size_t)s->frame_cap * D.n_mels);
+        s->frame_max_alt = dev_alloc<float>(s->frame_cap);
+        if (const char* e = std::getenv("WLK_MEL_INCREMENTAL")) s->mel_incremental = !(e[0] == '0');
         s->mel_t = dev_alloc_zero<float>((size_t)(kMelFrames + 2) * D.n_mels, st);
         s->x1p = dev_alloc_zero<float>((size_t)(kMelFrames + 1) * d, st);
         s->ex = dev_alloc<float>(T * d);
@@ -392,7 +395,7 @@ int wlk_session_destroy(wlk_session* s) {
     (void)wlk_engine_detach(s);
     (void)hipSetDevice(s->m->device);
     (void)hipStreamSynchronize(s->stream);
-    float* fl[] = {s->audio[0], s->audio[1], s->logmel, s->frame_max, s->mel_t, s->x1p, s->ex, s->eh, s->eqkv,
+    float* fl[] = {s->audio[0], s->audio[1], s->logmel, s->frame_max, s->logmel_alt, s->frame_max_alt, s->mel_t, s->x1p, s->ex, s->eh, s->eqkv,
                    s->eatt, s->emlp, s->enc_out, s->cross_kv, s->dx, s->dh, s->dqkv, s->datt, s->dq, s->dmlp,
                    s->kcache[0], s->kcache[1], s->vcache[0], s->vcache[1], s->hsel, s->logits_last, s->logits_sot,
                    s->ring, s->z, s->attn_last, s->qk_debug, s->xsplit, s->fsplit, s->top_vals, s->probs};
@@ -509,6 +512,24 @@ int wlk_audio_drop_front(wlk_session* s, int n) {
         s->audio_cur ^= 1;
         s->audio_len = keep;
         s->encoded = false;
+        // mel cache: whole evicted frames shift the cached rows; the two head frames (reflect padding at the new
+        // start) are redone by the next encode.  Anything else invalidates the cache.
+        const int shift = n / kHop;
+        if (s->mel_incremental && n % kHop == 0 && s->mel_cached_samples > n && shift < s->mel_cached_frames) {
+            const int rows = s->mel_cached_frames - shift;
+            const int nm = s->m->D.n_mels;
+            WLK_HIP(hipMemcpyAsync(s->logmel_alt, s->logmel + (size_t)shift * nm, (size_t)rows * nm * sizeof(float),
+                                   hipMemcpyDeviceToDevice, s->stream));
+            WLK_HIP(hipMemcpyAsync(s->frame_max_alt, s->frame_max + shift, (size_t)rows * sizeof(float),
+                                   hipMemcpyDeviceToDevice, s->stream));
+            std::swap(s->logmel, s->logmel_alt);
+            std::swap(s->frame_max, s->frame_max_alt);
+            s->mel_cached_samples -= n;
+            s->mel_cached_frames = rows;
+            s->mel_dirty_head = 2;
+        } else {
+            s->mel_cached_samples = 0;
+        }
         return WLK_OK;
     });
 }
@@ -517,6 +538,7 @@ int wlk_audio_clear(wlk_session* s) {
     if (!s) return fail(WLK_ERR_ARG, "session is NULL");
     s->audio_len = 0;
     s->encoded = false;
+    s->mel_cached_samples = 0;
     return WLK_OK;
 }
 
@@ -575,7 +597,17 @@ extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const
         ma.filt_lo = m->filt_lo; ma.filt_hi = m->filt_hi; ma.n_mels = D.n_mels;
         ma.logmel = s->logmel; ma.frame_max = s->frame_max; ma.mel_t = s->mel_t;
         ma.n_active = n_active; ma.n_total = n_total;
+        if (s->mel_incremental && s->mel_cached_samples > 0 && s->mel_cached_samples <= N && s->mel_cached_frames <= n_active) {
+            // frame t reads samples [160 t - 200, 160 t + 200): untouched by the new samples iff 160 t + 199 < cached
+            int first = s->mel_cached_samples >= kNFft / 2 ? (s->mel_cached_samples - kNFft / 2) / kHop + 1 : 0;
+            first = std::min(first, s->mel_cached_frames);
+            ma.first = first;
+            ma.head = std::min(s->mel_dirty_head, first);
+        }
         launch_mel(c, ma);
+        s->mel_cached_samples = N;
+        s->mel_cached_frames = n_active;
+        s->mel_dirty_head = 0;
     }
     auto table = [&](auto in, auto out, auto res) {
         PtrTable z{};

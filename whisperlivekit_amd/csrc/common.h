@@ -179,6 +179,11 @@ struct MelArgs {
     float* mel_t;          // [(3000+2)][n_mels] time-major, row 0 and row 3001 stay zero (conv padding)
     int n_active;          // frames that can see a non-zero sample (computed by the caller)
     int n_total;           // frames the reference's STFT yields before trimming to 3000
+    // incremental form (mel half): logmel / frame_max of frames [head, first) are still valid from
+    // the previous call (their 400-sample windows saw no new sample); only frames [0, head) and [first, n_active) are
+    // computed.  head = first = 0: everything.
+    int head = 0;
+    int first = 0;
 };
 void launch_mel(const LaunchCtx& ctx, const MelArgs& a);
 void launch_pcm16_to_float(const LaunchCtx& ctx, const short* in, float* out, int n);

@@ -153,6 +153,12 @@ struct wlk_session {
 
     // mel + encoder workspaces
     float *logmel = nullptr, *frame_max = nullptr, *mel_t = nullptr;
+    // per-frame mel cache (incremental mel): logmel/frame_max reflect the first mel_cached_samples samples of the
+    // current audio buffer for frames [mel_dirty_head, mel_cached_frames); the alternates take the shifted copy when
+    // whole frames are evicted
+    float *logmel_alt = nullptr, *frame_max_alt = nullptr;
+    int mel_cached_samples = 0, mel_cached_frames = 0, mel_dirty_head = 0;
+    bool mel_incremental = true;
     int frame_cap = 0;
     float *x1p = nullptr, *ex = nullptr, *eh = nullptr, *eqkv = nullptr, *eatt = nullptr, *emlp = nullptr,
           *enc_out = nullptr, *cross_kv = nullptr;

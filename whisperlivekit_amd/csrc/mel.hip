@@ -6,6 +6,11 @@
 //   mel[m] = sum_k F[m][k] |X[k]|^2 ;  L = log10(max(mel, 1e-10))
 //   out    = (max(L, max(L over ALL frames) - 8) + 4) / 4, first 3000 frames
 //
+// Per-frame results before the normalisation (log10 of the clamped mel energies, the frame maximum) stay in the
+// session between calls: a frame whose 400-sample window saw no new sample is bit for bit what it was, so a call
+// computes only the frames the appended chunk touches (+ the two reflect-padded head frames after an eviction);
+// the global maximum and the normalised output are redone every call by the finishing kernel.
+//
 // Only frames that can see a non-zero sample (t < ceil((N + 200) / 160)) are computed; every
 // other frame of the 30 s zero pad is exactly log10(1e-10) = -10 and is filled by the finishing
 // kernel.  The audio never leaves HBM: the session keeps the rolling buffer resident and this
@@ -25,7 +30,7 @@ __global__ __launch_bounds__(256) void mel_frame_kernel(MelArgs a) {
     __shared__ float power[kNFreq + 3];
     __shared__ float red[256];
 
-    const int t = blockIdx.x;
+    const int t = (int)blockIdx.x < a.head ? (int)blockIdx.x : a.first + ((int)blockIdx.x - a.head);
     const int tid = threadIdx.x;
     for (int n = tid; n < kNFft; n += 256) {
         tw[n] = a.twiddle[n];
@@ -92,9 +97,10 @@ __global__ __launch_bounds__(256) void mel_finish_kernel(MelArgs a) {
 }
 
 void launch_mel(const LaunchCtx& ctx, const MelArgs& a) {
-    if (a.n_active > 0) {
+    const int n_frames = a.head + (a.n_active - a.first);
+    if (n_frames > 0) {
         KernelScope ks(ctx, "mel_frames");
-        hipLaunchKernelGGL(mel_frame_kernel, dim3(a.n_active), dim3(256), 0, ctx.stream, a);
+        hipLaunchKernelGGL(mel_frame_kernel, dim3(n_frames), dim3(256), 0, ctx.stream, a);
         WLK_HIP(hipGetLastError());
     }
     {
