@@ -363,8 +363,10 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         s->kcache[0] = dev_alloc<float>(cache);
         s->vcache[0] = dev_alloc<float>(cache);
         s->hsel = dev_alloc<float>((size_t)2 * beam * d);
-        s->logits_last = dev_alloc<float>((size_t)beam * V);
-        s->logits_sot = dev_alloc<float>((size_t)beam * V);
+        // one allocation: the sot-row logits follow the last-row logits, so a beam-1 prefill projects both rows
+        // in a single pass over the vocabulary weights
+        s->logits_last = dev_alloc<float>((size_t)2 * beam * V);
+        s->logits_sot = s->logits_last + (size_t)beam * V;
         s->ring_row = s->step_in + R;
         s->beam_of_row = s->step_in + 2 * R;
         s->d_offset = s->step_in + 3 * R;
@@ -397,7 +399,7 @@ int wlk_session_destroy(wlk_session* s) {
     (void)hipStreamSynchronize(s->stream);
     float* fl[] = {s->audio[0], s->audio[1], s->logmel, s->frame_max, s->logmel_alt, s->frame_max_alt, s->mel_t, s->x1p, s->ex, s->eh, s->eqkv,
                    s->eatt, s->emlp, s->enc_out, s->cross_kv, s->dx, s->dh, s->dqkv, s->datt, s->dq, s->dmlp,
-                   s->kcache[0], s->kcache[1], s->vcache[0], s->vcache[1], s->hsel, s->logits_last, s->logits_sot,
+                   s->kcache[0], s->kcache[1], s->vcache[0], s->vcache[1], s->hsel, s->logits_last,
                    s->ring, s->z, s->attn_last, s->qk_debug, s->xsplit, s->fsplit, s->top_vals, s->probs};
     for (float* p : fl)
         if (p) (void)hipFree(p);
@@ -846,6 +848,15 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
     if (fused) {   // n_tok == 1: the last row of beam b is row b
         lg.A = s->dx; lg.ln_gamma = m->w_ln_w; lg.ln_beta = m->w_ln_b;
         launch_gemv(c, lg, "dec_lnf_logits");
+    } else if (first && n_rows == 1 && gemv_applicable(2, d) && getenv("WLK_NO_PREFILL_MERGE") == nullptr) {
+        // beam-1 prefill: the last row and the sot row (no-speech probability) normalised by one launch (a negative
+        // row stride walks from the last row back to the sot row) and projected by one M = 2 pass over the 51864 x d
+        // weights; per-row arithmetic of both kernels does not depend on the row count
+        launch_layernorm(c, s->dx + (size_t)(n_tok - 1) * d, (long)(sot_index - (n_tok - 1)) * d, m->w_ln_w, m->w_ln_b,
+                         s->hsel, d, 2, d, "dec_ln_f");
+        lg.A = s->hsel; lg.M = 2;   // C row 1 = logits_sot (same allocation, V floats further)
+        launch_linear(c, lg, "dec_logits");
+        return;
     } else {
         launch_layernorm(c, s->dx + (size_t)(n_tok - 1) * d, (long)n_tok * d, m->w_ln_w, m->w_ln_b, s->hsel, d,
                          n_rows, d, "dec_ln_f");
@@ -981,9 +992,6 @@ int wlk_select(wlk_session* s, const int32_t* adj_row, const int32_t* adj_ids, c
             std::memcpy(st + n_adj * 8, adj_deltas, n_adj * sizeof(float));
             WLK_HIP(hipMemcpyAsync(s->adj_row, st, (size_t)n_adj * 12, hipMemcpyHostToDevice, s->stream));
         }
-        launch_logsoftmax_topk(c, s->logits_last, V, B, k, s->top_vals, s->top_ids, s->topk_scratch, adj_rows_d,
-                               adj_ids_d, adj_deltas_d, n_adj);
-
         AlignArgs a;
         a.ring = s->ring; a.n_align = m->n_align; a.n_beam = B; a.ring_rows = s->ring_rows; a.T = D.n_audio_ctx;
         a.prefill_rows = s->n_steps <= kAlignWindow ? s->prefill_rows : 0;
@@ -992,7 +1000,12 @@ int wlk_select(wlk_session* s, const int32_t* adj_row, const int32_t* adj_ids, c
         a.newest_row = s->n_steps == 1 ? s->prefill_rows - 1 : D.n_text_ctx + ((s->n_steps - 2) % kAlignWindow);
         a.content_len = content_mel_len;
         a.z = s->z; a.attn_last = s->attn_last; a.frames = s->frames;
-        launch_alignatt(c, a);
+        if (!launch_select_fused(c, s->logits_last, V, B, k, s->top_vals, s->top_ids, s->topk_scratch, adj_rows_d,
+                                 adj_ids_d, adj_deltas_d, n_adj, a)) {
+            launch_logsoftmax_topk(c, s->logits_last, V, B, k, s->top_vals, s->top_ids, s->topk_scratch, adj_rows_d,
+                                   adj_ids_d, adj_deltas_d, n_adj);
+            launch_alignatt(c, a);
+        }
 
         // one readback of the packed result block [log-probs B*8 | ids B*8 | frames B]
         char* out = static_cast<char*>(s->pinned) + 65536;

@@ -153,13 +153,16 @@ void wlk_engine::enqueue_select(int R, int n_adj) {
     float* top_vals = res_dev;
     int* top_ids = reinterpret_cast<int*>(res_dev) + 2 * max_rows;
     int* frames = top_ids + 2 * max_rows;
-    launch_logsoftmax_topk(c, logits, V, R, 2, top_vals, top_ids, topk_scratch, adj_dev, adj_dev + n_adj,
-                           reinterpret_cast<float*>(adj_dev + 2 * n_adj), n_adj);
     AlignArgs a{};
     a.ring = nullptr; a.n_align = m->n_align; a.n_beam = R; a.ring_rows = ctx_len + kAlignWindow; a.T = T;
     a.prefill_rows = 0; a.n_single = 0; a.newest_row = 0; a.single_base = ctx_len; a.content_len = 0;
     a.z = z; a.attn_last = attn_last; a.frames = frames;
-    if (m->n_align > 0) launch_alignatt_rows(c, a, rows_dev);
+    a.rows = rows_dev;
+    int* adj_ids = adj_dev + n_adj;
+    float* adj_deltas = reinterpret_cast<float*>(adj_dev + 2 * n_adj);
+    if (launch_select_fused(c, logits, V, R, 2, top_vals, top_ids, topk_scratch, adj_dev, adj_ids, adj_deltas, n_adj, a)) return;
+    launch_logsoftmax_topk(c, logits, V, R, 2, top_vals, top_ids, topk_scratch, adj_dev, adj_ids, adj_deltas, n_adj);
+    if (m->n_align > 0) launch_alignatt(c, a);
     else WLK_HIP(hipMemsetAsync(frames, 0, sizeof(int) * R, stream));
 }
 

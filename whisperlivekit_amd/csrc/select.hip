@@ -9,6 +9,7 @@
 // whisper/timing.py:19-54.  Everything here is a small HBM/L2-bound reduction; wavefront
 // shuffles do the folding and nothing is copied to the host except k+1 numbers per beam row.
 #include <atomic>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -51,18 +52,29 @@ struct SelPartial {
     int i[kMaxTopK];
 };
 
-__global__ __launch_bounds__(256) void topk_stage1_kernel(float* __restrict__ logits, int n_vocab, int k,
-                                                          SelPartial* __restrict__ parts, const int* __restrict__ adj_row,
-                                                          const int* __restrict__ adj_ids,
-                                                          const float* __restrict__ adj_deltas, int n_adj) {
+struct TopkArgs {
+    float* logits;
+    int n_vocab, k, n_rows;
+    SelPartial* parts;
+    const int* adj_row;
+    const int* adj_ids;
+    const float* adj_deltas;
+    int n_adj;
+    float* top_vals;
+    int* top_ids;
+};
+
+__device__ __forceinline__ void topk_stage1_body(float* __restrict__ logits, int n_vocab, int k,
+                                                 SelPartial* __restrict__ parts, const int* __restrict__ adj_row,
+                                                 const int* __restrict__ adj_ids, const float* __restrict__ adj_deltas,
+                                                 int n_adj, int slice, int row) {
     __shared__ float red[16];
     __shared__ float cand_v[4];
     __shared__ int cand_i[4];
     __shared__ int taken[kMaxTopK];
     const int tid = threadIdx.x;
-    const int row = blockIdx.y;
     const int per = (n_vocab + kSelBlocks - 1) / kSelBlocks;
-    const int lo = blockIdx.x * per;
+    const int lo = slice * per;
     const int hi = min(n_vocab, lo + per);
     float* x = logits + (long)row * n_vocab;
     // logit adjustments that fall into this slice are applied here (each slice is owned by one
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(256) void topk_stage1_kernel(float* __restrict__ lo
     if (mx > -INFINITY)
         for (int i = lo + tid; i < hi; i += 256) sum += expf(x[i] - mx);
     sum = block_sum(sum, red);
-    SelPartial* out = parts + (long)row * kSelBlocks + blockIdx.x;
+    SelPartial* out = parts + (long)row * kSelBlocks + slice;
     if (tid == 0) { out->mx = mx; out->sum = sum; }
     for (int round = 0; round < k; ++round) {
         float bv = -INFINITY;
@@ -111,10 +123,16 @@ __global__ __launch_bounds__(256) void topk_stage1_kernel(float* __restrict__ lo
     }
 }
 
-__global__ __launch_bounds__(64) void topk_stage2_kernel(const SelPartial* __restrict__ parts, int k,
-                                                         float* __restrict__ top_vals, int* __restrict__ top_ids) {
-    const int lane = threadIdx.x;   // one lane per slice
-    const int row = blockIdx.x;
+__global__ __launch_bounds__(256) void topk_stage1_kernel(float* __restrict__ logits, int n_vocab, int k,
+                                                          SelPartial* __restrict__ parts, const int* __restrict__ adj_row,
+                                                          const int* __restrict__ adj_ids,
+                                                          const float* __restrict__ adj_deltas, int n_adj) {
+    topk_stage1_body(logits, n_vocab, k, parts, adj_row, adj_ids, adj_deltas, n_adj, blockIdx.x, blockIdx.y);
+}
+
+__device__ __forceinline__ void topk_stage2_body(const SelPartial* __restrict__ parts, int k,
+                                                 float* __restrict__ top_vals, int* __restrict__ top_ids, int row) {
+    const int lane = threadIdx.x;   // one lane per slice (the first wave of the workgroup)
     const SelPartial p = parts[(long)row * kSelBlocks + lane];
     float mx = p.mx;
 #pragma unroll
@@ -145,6 +163,11 @@ __global__ __launch_bounds__(64) void topk_stage2_kernel(const SelPartial* __res
             top_vals[row * k + round] = (wv - mx) - lse;
         }
     }
+}
+
+__global__ __launch_bounds__(64) void topk_stage2_kernel(const SelPartial* __restrict__ parts, int k,
+                                                         float* __restrict__ top_vals, int* __restrict__ top_ids) {
+    topk_stage2_body(parts, k, top_vals, top_ids, blockIdx.x);
 }
 
 void launch_logsoftmax_topk(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, int k,
@@ -195,14 +218,13 @@ void launch_token_prob(const LaunchCtx& ctx, const float* logits, int n_vocab, i
 // Step 1 (this kernel): per frame column, mean and population std over the window rows in fp64
 // (torch.std_mean(unbiased=False) accumulates in double on CPU), then the z-score of the newest row.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void align_zscore_kernel(AlignArgs a) {
+__device__ __forceinline__ void align_zscore_body(AlignArgs a, int fblock, int al, int b) {
     // 64 frame columns x 4 row groups per workgroup: the window rows (up to 448 + 15) are walked by
     // four threads per column in parallel and folded through LDS - the loop is latency-bound, so
     // parallel rows matter more than anything else here
     __shared__ double red[4][64];
     const int fx = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int f = blockIdx.x * 64 + fx;
-    const int al = blockIdx.y, b = blockIdx.z;
+    const int f = fblock * 64 + fx;
     const bool ok = f < a.T;
     if (a.rows) {                // batched steps: row b is a session of its own (one beam)
         const StepRow sr = a.rows[b];
@@ -234,6 +256,10 @@ __global__ __launch_bounds__(256) void align_zscore_kernel(AlignArgs a) {
         const float w = base[(long)a.newest_row * a.T];
         a.z[((long)b * a.n_align + al) * a.T + f] = (w - (float)mean) / (stdv + 1e-8f);
     }
+}
+
+__global__ __launch_bounds__(256) void align_zscore_kernel(AlignArgs a) {
+    align_zscore_body(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 __device__ __forceinline__ float median7(float v0, float v1, float v2, float v3, float v4, float v5, float v6) {
@@ -296,12 +322,11 @@ __global__ __launch_bounds__(256) void align_argmax_kernel(AlignArgs a) {
 
 // Step 2 variant for the common case (z of all alignment heads fits LDS): 1024 threads stage z with
 // coalesced loads once, then medians / head mean / arg-max run out of LDS.
-__global__ __launch_bounds__(1024) void align_argmax_lds_kernel(AlignArgs a) {
+__device__ __forceinline__ void align_argmax_lds_body(AlignArgs a, int b) {
     extern __shared__ __attribute__((aligned(16))) float zs[];   // [n_align][T]
     __shared__ float bestv[1024];
     __shared__ int besti[1024];
     const int tid = threadIdx.x;
-    const int b = blockIdx.x;
     if (a.rows) a.content_len = a.rows[b].content_len;
     const float* zb = a.z + (long)b * a.n_align * a.T;
     for (int i = tid; i < a.n_align * a.T; i += 1024) zs[i] = zb[i];
@@ -338,6 +363,67 @@ __global__ __launch_bounds__(1024) void align_argmax_lds_kernel(AlignArgs a) {
         __syncthreads();
     }
     if (tid == 0) a.frames[b] = besti[0] == 0x7fffffff ? 0 : besti[0];
+}
+
+__global__ __launch_bounds__(1024) void align_argmax_lds_kernel(AlignArgs a) { align_argmax_lds_body(a, blockIdx.x); }
+
+// ---------------------------------------------------------------------------------------------
+// The tail of a decode step in TWO launches instead of four: the slice pass of the top-k and the z-score of the
+// alignment window are independent (logits vs cross-attention rows), and so are their second stages; each pair shares a
+// launch, workgroups pick their role from the block index.  Same device functions, same arithmetic as the four
+// separate kernels above (which remain for the configurations the fused form does not cover).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void select_stage1_kernel(TopkArgs t, AlignArgs a, int zf_blocks) {
+    const int n_topk = kSelBlocks * t.n_rows;
+    if ((int)blockIdx.x < n_topk) {
+        topk_stage1_body(t.logits, t.n_vocab, t.k, t.parts, t.adj_row, t.adj_ids, t.adj_deltas, t.n_adj,
+                         blockIdx.x % kSelBlocks, blockIdx.x / kSelBlocks);
+    } else {
+        const int i = blockIdx.x - n_topk;
+        const int fblock = i % zf_blocks, rest = i / zf_blocks;
+        align_zscore_body(a, fblock, rest % a.n_align, rest / a.n_align);
+    }
+}
+
+__global__ __launch_bounds__(1024) void select_stage2_kernel(TopkArgs t, AlignArgs a) {
+    if ((int)blockIdx.x < a.n_beam) {
+        align_argmax_lds_body(a, blockIdx.x);
+    } else if (threadIdx.x < 64) {
+        topk_stage2_body(t.parts, t.k, t.top_vals, t.top_ids, blockIdx.x - a.n_beam);
+    }
+}
+
+bool launch_select_fused(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, int k, float* top_vals, int* top_ids,
+                         void* scratch, const int* adj_row, const int* adj_ids, const float* adj_deltas, int n_adj,
+                         const AlignArgs& a) {
+    static const bool enabled = [] {
+        const char* e = getenv("WLK_SELECT_FUSED");
+        return !(e && e[0] == '0');
+    }();
+    const size_t lds = (size_t)a.n_align * a.T * sizeof(float);
+    if (!enabled || a.n_align <= 0 || a.n_beam != n_rows || lds + 8192 + 1024 > 150 * 1024 || k < 1 || k > kMaxTopK) return false;
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    WLK_HIP(hipGetDevice(&dev));
+    if (dev < 64 && !attr_set[dev].load(std::memory_order_acquire)) {
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_stage2_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    TopkArgs t{logits, n_vocab, k, n_rows, static_cast<SelPartial*>(scratch), adj_row, adj_ids, adj_deltas, n_adj, top_vals, top_ids};
+    const int zf = (a.T + 63) / 64;
+    {
+        KernelScope ks(ctx, "sel_stage1", 0.0, 4.0 * 3.0 * n_rows * (double)n_vocab);
+        hipLaunchKernelGGL(select_stage1_kernel, dim3(kSelBlocks * n_rows + zf * a.n_align * a.n_beam), dim3(256), 0,
+                           ctx.stream, t, a, zf);
+        WLK_HIP(hipGetLastError());
+    }
+    {
+        KernelScope ks(ctx, "sel_stage2");
+        hipLaunchKernelGGL(select_stage2_kernel, dim3(a.n_beam + n_rows), dim3(1024), lds, ctx.stream, t, a);
+        WLK_HIP(hipGetLastError());
+    }
+    return true;
 }
 
 void launch_alignatt_rows(const LaunchCtx& ctx, const AlignArgs& a0, const StepRow* rows) {
