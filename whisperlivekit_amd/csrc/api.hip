@@ -3,6 +3,7 @@
 // the kernel files next to this one.
 #include <cmath>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -380,12 +381,24 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         s->attn_last = dev_alloc_zero<float>((size_t)beam * T, st);
         s->adj_row = dev_alloc<int>(3 * wlk_session::kAdjCap);   // [rows n | ids n | deltas n] packed per call
         s->src_rows = dev_alloc<int>(8);
-        s->top_vals = dev_alloc<float>((size_t)beam * 17);       // [log-probs B*8 | ids B*8 | frames B]: ONE D2H
+        s->top_vals = dev_alloc<float>((size_t)beam * 18);       // [log-probs B*8 | ids B*8 | frames B | no-speech B]: ONE D2H
         s->top_ids = reinterpret_cast<int*>(s->top_vals) + (size_t)beam * 8;
         s->frames = s->top_ids + (size_t)beam * 8;
         WLK_HIP(hipMalloc(&s->topk_scratch, topk_scratch_bytes(beam)));
         s->probs = dev_alloc<float>(beam);
         WLK_HIP(hipHostMalloc(&s->pinned, wlk_session::kPinnedBytes, hipHostMallocDefault));
+        if (beam == 1) {
+            void* hp = nullptr;
+            WLK_HIP(hipHostMalloc(&hp, 4096, hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(hp, 0, 4096);
+            s->step_host = static_cast<StepBlock*>(hp);
+            s->result_host = reinterpret_cast<StepResult*>(static_cast<char*>(hp) + 2048);
+            void* dp = nullptr;
+            WLK_HIP(hipHostGetDevicePointer(&dp, hp, 0));
+            s->step_host_dev = static_cast<StepBlock*>(dp);
+            s->result_host_dev = reinterpret_cast<StepResult*>(static_cast<char*>(dp) + 2048);
+            s->step_dev = reinterpret_cast<StepBlock*>(dev_alloc<int>(sizeof(StepBlock) / 4));
+        }
         WLK_HIP(hipStreamSynchronize(st));
         *out = s.release();
         return WLK_OK;
@@ -412,6 +425,10 @@ int wlk_session_destroy(wlk_session* s) {
     if (s->pcm16_dev) (void)hipFree(s->pcm16_dev);
     if (s->esplit) (void)hipFree(s->esplit);
     if (s->pinned) (void)hipHostFree(s->pinned);
+    if (s->step_host) (void)hipHostFree(s->step_host);
+    if (s->step_dev) (void)hipFree(s->step_dev);
+    for (auto& e : s->fstep_exec)
+        if (e) (void)hipGraphExecDestroy(e);
     for (auto& r : s->prof.recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -727,20 +744,27 @@ int wlk_encode(wlk_session* s, int32_t* content_mel_len) {
 // (tokens, alignment-window row map, cache offset) is read from the pinned staging block through
 // memcpy nodes / device scalars, so the single-token form of this sequence can be captured once
 // into a hipGraph and replayed.
-static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n_tok, bool first, int sot_index) {
+static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n_tok, bool first, int sot_index,
+                           bool step_block = false) {
     wlk_model* m = s->m;
     const wlk_dims& D = m->D;
     const int ctx_len = D.n_text_ctx;
     const int R = n_rows * n_tok;
     const int d = D.n_text_state, T = D.n_audio_ctx, H = D.n_text_head, V = D.n_vocab;
     // one host->device copy: [tokens | alignment-window row | beam of row | cache offset]
-    WLK_HIP(hipMemcpyAsync(s->step_in, s->pinned, (size_t)(3 * s->max_rows + 1) * sizeof(int), hipMemcpyHostToDevice,
-                           s->stream));
+    // (wlk_step_select: the embedding kernel reads the step's inputs from the host-coherent block itself)
+    if (!step_block)
+        WLK_HIP(hipMemcpyAsync(s->step_in, s->pinned, (size_t)(3 * s->max_rows + 1) * sizeof(int), hipMemcpyHostToDevice,
+                               s->stream));
     // decode steps (<= 8 rows): LayerNorm and the KV-cache append are fused into the weight-streaming
     // GEMV launches; prefill keeps them as separate kernels in front of the MFMA GEMMs
     const bool fused = gemv_applicable(R, d) && n_tok == 1;
 
-    launch_embed(c, s->tokens_dev, m->w_tok_emb, m->w_dec_pos, s->dx, n_rows, n_tok, s->d_offset, d);
+    if (step_block)
+        launch_embed_step(c, s->step_host_dev, s->step_dev, s->tokens_dev, s->ring_row, s->beam_of_row, s->d_offset,
+                          m->w_tok_emb, m->w_dec_pos, s->dx, d);
+    else
+        launch_embed(c, s->tokens_dev, m->w_tok_emb, m->w_dec_pos, s->dx, n_rows, n_tok, s->d_offset, d);
     const float scale = std::pow((float)kHeadDim, -0.25f);
     const size_t cache_layer = (size_t)s->beam * ctx_len * d;
     for (int i = 0; i < D.n_text_layer; ++i) {
@@ -962,8 +986,11 @@ int wlk_no_speech_prob(wlk_session* s, int no_speech_token, float* probs_host) {
     });
 }
 
-int wlk_select(wlk_session* s, const int32_t* adj_row, const int32_t* adj_ids, const float* adj_deltas, int n_adj,
-               int k, int content_mel_len, float* top_logprobs_host, int32_t* top_ids_host, int32_t* frames_host) {
+// wlk_select, optionally with the no-speech probability of the sot row in the same read-back (first step of the
+// library's decode loop: one synchronisation instead of two)
+static int select_impl(wlk_session* s, const int32_t* adj_row, const int32_t* adj_ids, const float* adj_deltas, int n_adj,
+                       int k, int content_mel_len, float* top_logprobs_host, int32_t* top_ids_host, int32_t* frames_host,
+                       int no_speech_token, float* no_speech_host) {
     if (!s || !top_logprobs_host || !top_ids_host || !frames_host) return fail(WLK_ERR_ARG, "NULL argument");
     if (s->n_steps == 0) return fail(WLK_ERR_STATE, "wlk_select before wlk_decode");
     if (n_adj < 0 || n_adj > wlk_session::kAdjCap) return fail(WLK_ERR_ARG, "too many logit adjustments");
@@ -1000,6 +1027,8 @@ int wlk_select(wlk_session* s, const int32_t* adj_row, const int32_t* adj_ids, c
         a.newest_row = s->n_steps == 1 ? s->prefill_rows - 1 : D.n_text_ctx + ((s->n_steps - 2) % kAlignWindow);
         a.content_len = content_mel_len;
         a.z = s->z; a.attn_last = s->attn_last; a.frames = s->frames;
+        float* ns_dev = s->top_vals + (size_t)B * 17;
+        if (no_speech_host) launch_token_prob(c, s->logits_sot, V, B, no_speech_token, ns_dev);
         if (!launch_select_fused(c, s->logits_last, V, B, k, s->top_vals, s->top_ids, s->topk_scratch, adj_rows_d,
                                  adj_ids_d, adj_deltas_d, n_adj, a)) {
             launch_logsoftmax_topk(c, s->logits_last, V, B, k, s->top_vals, s->top_ids, s->topk_scratch, adj_rows_d,
@@ -1007,15 +1036,139 @@ int wlk_select(wlk_session* s, const int32_t* adj_row, const int32_t* adj_ids, c
             launch_alignatt(c, a);
         }
 
-        // one readback of the packed result block [log-probs B*8 | ids B*8 | frames B]
+        // one readback of the packed result block [log-probs B*8 | ids B*8 | frames B (| no-speech B)]
         char* out = static_cast<char*>(s->pinned) + 65536;
-        WLK_HIP(hipMemcpyAsync(out, s->top_vals, (size_t)B * 17 * 4, hipMemcpyDeviceToHost, s->stream));
+        WLK_HIP(hipMemcpyAsync(out, s->top_vals, (size_t)B * (no_speech_host ? 18 : 17) * 4, hipMemcpyDeviceToHost, s->stream));
         WLK_HIP(hipStreamSynchronize(s->stream));
+        if (no_speech_host) std::memcpy(no_speech_host, out + (size_t)B * 68, B * sizeof(float));
         for (int b = 0; b < B; ++b) {
             std::memcpy(top_logprobs_host + (size_t)b * k, out + (size_t)b * k * 4, k * sizeof(float));
             std::memcpy(top_ids_host + (size_t)b * k, out + (size_t)B * 32 + (size_t)b * k * 4, k * sizeof(int));
         }
         std::memcpy(frames_host, out + (size_t)B * 64, B * sizeof(int));
+        return WLK_OK;
+    });
+}
+
+int wlk_select(wlk_session* s, const int32_t* adj_row, const int32_t* adj_ids, const float* adj_deltas, int n_adj, int k,
+               int content_mel_len, float* top_logprobs_host, int32_t* top_ids_host, int32_t* frames_host) {
+    return select_impl(s, adj_row, adj_ids, adj_deltas, n_adj, k, content_mel_len, top_logprobs_host, top_ids_host,
+                       frames_host, -1, nullptr);
+}
+
+extern "C++" int wlk_select_first(wlk_session* s, int no_speech_token, const int32_t* adj_row, const int32_t* adj_ids,
+                                  const float* adj_deltas, int n_adj, int k, int content_mel_len, float* no_speech_host,
+                                  float* top_logprobs_host, int32_t* top_ids_host, int32_t* frames_host) {
+    if (!s || !no_speech_host) return fail(WLK_ERR_ARG, "NULL argument");
+    if (!s->have_sot) return fail(WLK_ERR_STATE, "no sot-row logits: call after the first decode of an infer");
+    if (no_speech_token < 0 || no_speech_token >= s->m->D.n_vocab) return fail(WLK_ERR_ARG, "token out of range");
+    return select_impl(s, adj_row, adj_ids, adj_deltas, n_adj, k, content_mel_len, top_logprobs_host, top_ids_host,
+                       frames_host, no_speech_token, no_speech_host);
+}
+
+// One single-token step + read-out of a beam-1 session as ONE graph replay: [embed (reads the host block)] [decoder
+// layers] [logits] [top-k stage 1 + z-score] [top-k stage 2 + AlignAtt argmax (write the host result)].  Against
+// wlk_decode + wlk_select this drops the two staging copies, the result copy and the hand-over between a graph replay
+// and eagerly enqueued kernels; the arithmetic is the same kernels on the same data.
+extern "C++" int wlk_step_select(wlk_session* s, int64_t token, const int32_t* adj_ids, const float* adj_deltas, int n_adj,
+                                 int content_mel_len, float* top_logprobs2, int32_t* top_ids2, int32_t* frame) {
+    static const bool enabled = [] {
+        const char* e = getenv("WLK_FUSED_STEP");
+        return !(e && e[0] == '0');
+    }();
+    wlk_model* m = s->m;
+    const wlk_dims& D = m->D;
+    if (!enabled || s->beam != 1 || !s->step_host || s->debug || s->prof_on || !s->use_graph || s->n_steps < 1 ||
+        n_adj > kStepMaxAdj || !gemv_applicable(1, D.n_text_state) || !s->encoded)
+        return 1;
+    AlignArgs a;
+    a.ring = nullptr; a.n_align = m->n_align; a.n_beam = 1; a.ring_rows = s->ring_rows; a.T = D.n_audio_ctx;
+    a.prefill_rows = 0; a.n_single = 0; a.newest_row = 0; a.single_base = D.n_text_ctx; a.content_len = 0;
+    a.z = s->z; a.attn_last = s->attn_last; a.frames = s->frames;
+    if (!select_fused_applicable(1, 2, a)) return 1;
+    if (token < 0 || token >= D.n_vocab) return fail(WLK_ERR_ARG, "token id out of range");
+    if (s->self_len + 1 > D.n_text_ctx) return fail(WLK_ERR_CAPACITY, "text context exceeded");
+    if (content_mel_len < 0) return fail(WLK_ERR_ARG, "content_mel_len out of range");
+    if (content_mel_len > D.n_audio_ctx) content_mel_len = D.n_audio_ctx;
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(m->device));
+        const LaunchCtx c = s->ctx();
+        const int ctx_len = D.n_text_ctx;
+        // the step's inputs (wlk_decode's staging block + wlk_select's arguments); the previous replay has delivered
+        // its result, so its first kernel is long past reading this block
+        StepBlock& b = *s->step_host;
+        const int steps_after = s->n_steps + 1;
+        b.row.kcache = s->kcache[s->kv_cur]; b.row.vcache = s->vcache[s->kv_cur];
+        b.row.cross_kv = s->cross_kv; b.row.ring = s->ring;
+        b.row.token = (int)token;
+        b.row.offset = s->self_len;
+        b.row.ring_row = ctx_len + ((s->n_steps - 1) % kAlignWindow);
+        b.row.prefill_rows = steps_after <= kAlignWindow ? s->prefill_rows : 0;
+        b.row.n_single = std::min(steps_after - 1, kAlignWindow);
+        b.row.newest_row = ctx_len + ((steps_after - 2) % kAlignWindow);
+        b.row.content_len = content_mel_len;
+        b.n_adj = n_adj;
+        for (int i = 0; i < n_adj; ++i) {
+            b.adj_row[i] = -1;
+            b.adj_ids[i] = adj_ids[i];
+            b.adj_deltas[i] = adj_deltas[i];
+        }
+        const unsigned seq = ++s->step_seq ? s->step_seq : ++s->step_seq;   // never 0 (the blocks start zeroed)
+        b.seq = seq;
+        std::atomic_thread_fence(std::memory_order_release);
+
+        hipGraphExec_t& exec = s->fstep_exec[s->kv_cur];
+        if (!exec) {
+            hipGraph_t graph = nullptr;
+            WLK_HIP(hipStreamSynchronize(s->stream));
+            WLK_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+            try {
+                enqueue_decode(s, c, 1, 1, false, 0, true);
+                a.rows = &s->step_dev->row;
+                StepHostOut ho;
+                ho.result = s->result_host_dev;
+                ho.block = s->step_dev;
+                if (!launch_select_fused(c, s->logits_last, D.n_vocab, 1, 2, s->top_vals, s->top_ids, s->topk_scratch,
+                                         s->step_dev->adj_row, s->step_dev->adj_ids, s->step_dev->adj_deltas, 0, a, ho))
+                    throw std::runtime_error("fused step: read-out not available");
+            } catch (...) {
+                (void)hipStreamEndCapture(s->stream, &graph);
+                if (graph) (void)hipGraphDestroy(graph);
+                throw;
+            }
+            WLK_HIP(hipStreamEndCapture(s->stream, &graph));
+            WLK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+        }
+        WLK_HIP(hipGraphLaunch(exec, s->stream));
+        s->have_sot = false;
+        s->self_len += 1;
+        s->n_steps += 1;
+        s->last_rows = 1;
+        s->last_ntok = 1;
+
+        // the last kernel stores the two flags after the fields; spin on them, and look at the stream now and then so
+        // that a failed launch cannot hang the caller
+        volatile StepResult* r = s->result_host;
+        for (unsigned spins = 0;; ++spins) {
+            const unsigned f1 = __atomic_load_n(&s->result_host->flag_topk, __ATOMIC_ACQUIRE);
+            const unsigned f2 = __atomic_load_n(&s->result_host->flag_align, __ATOMIC_ACQUIRE);
+            if (f1 == seq && f2 == seq) break;
+            if ((spins & 0x3ff) == 0x3ff) {
+                const hipError_t q = hipStreamQuery(s->stream);
+                if (q == hipSuccess) {
+                    if (__atomic_load_n(&s->result_host->flag_topk, __ATOMIC_ACQUIRE) == seq &&
+                        __atomic_load_n(&s->result_host->flag_align, __ATOMIC_ACQUIRE) == seq)
+                        break;
+                    throw std::runtime_error("fused step: the graph finished without delivering its result");
+                }
+                if (q != hipErrorNotReady) WLK_HIP(q);
+            }
+            __builtin_ia32_pause();
+        }
+        top_logprobs2[0] = r->top_vals[0]; top_logprobs2[1] = r->top_vals[1];
+        top_ids2[0] = r->top_ids[0]; top_ids2[1] = r->top_ids[1];
+        *frame = r->frame;
         return WLK_OK;
     });
 }

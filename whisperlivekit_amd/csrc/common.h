@@ -67,6 +67,35 @@ struct StepRow {
     int pad;
 };
 
+// ---- single-token step of one beam-1 session as ONE graph replay (api.hip: wlk_step_select) -----------
+// The host writes a StepBlock into pinned (host-coherent) memory and replays the graph; the graph's first kernel reads
+// the block over the bus, spreads it into device memory for the kernels behind it, and the last kernel writes a
+// StepResult back into pinned memory, flags last.  No copy nodes, nothing between the decoder and the read-out.
+constexpr int kStepMaxAdj = 160;   // multilingual models suppress ~110 ids on every step
+struct StepBlock {
+    StepRow row;                  // this step's scalars (+ the session's pointers, used by the alignment read-out)
+    int n_adj;
+    unsigned seq;                 // echoed in StepResult's flags
+    int pad[2];
+    int adj_row[kStepMaxAdj];     // logit adjustments applied before the top-k (wlk_select's contract)
+    int adj_ids[kStepMaxAdj];
+    float adj_deltas[kStepMaxAdj];
+};
+struct StepResult {
+    float top_vals[2];
+    int top_ids[2];
+    int frame;
+    unsigned flag_topk, flag_align;   // = StepBlock::seq once the fields above are visible to the host
+    int pad;
+};
+struct StepHostOut {              // by-value kernel argument of the read-out kernels
+    StepResult* result = nullptr; // pinned; nullptr = device-only results
+    const StepBlock* block = nullptr;   // device copy (n_adj, seq)
+};
+void launch_embed_step(const LaunchCtx& ctx, const StepBlock* host_block, StepBlock* dev_block, int* tokens_dev,
+                       int* ring_row, int* beam_of_row, int* d_offset, const float* tok_emb, const float* pos_emb, float* x,
+                       int d);
+
 // ---- batched encodes (engine.hip) ------------------------------------------------------------------
 // Concurrent encodes of several sessions run as ONE launch per operator with grid.y = sessions: the weights are
 // shared, every session keeps its own activation buffers, and operand z of a launch comes from a by-value pointer
@@ -332,7 +361,8 @@ void launch_alignatt(const LaunchCtx& ctx, const AlignArgs& a);
 // the configuration needs the separate kernels (no alignment heads, window too large for LDS, WLK_SELECT_FUSED=0)
 bool launch_select_fused(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, int k, float* top_vals, int* top_ids,
                          void* scratch, const int* adj_row, const int* adj_ids, const float* adj_deltas, int n_adj,
-                         const AlignArgs& a);
+                         const AlignArgs& a, const StepHostOut& host = StepHostOut{});
+bool select_fused_applicable(int n_rows, int k, const AlignArgs& a);
 // batched steps: one read-out per row with the row's own window / counters (a.ring, prefill_rows, n_single, newest_row
 // and content_len are taken from rows[r]; a.n_beam is the number of rows, each row is its own beam 0)
 void launch_alignatt_rows(const LaunchCtx& ctx, const AlignArgs& a, const StepRow* rows);

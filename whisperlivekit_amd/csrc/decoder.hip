@@ -47,6 +47,48 @@ void launch_embed_rows(const LaunchCtx& ctx, const StepRow* rows, const float* t
     WLK_HIP(hipGetLastError());
 }
 
+// First kernel of a single-session graph step: the step's inputs are read straight from the pinned host block (one
+// uncached read per lane, all in flight together), spread into device memory for the kernels behind this one, and the
+// token + position embedding of the fed token is written as in embed_kernel.
+__global__ __launch_bounds__(256) void embed_step_kernel(const StepBlock* __restrict__ host_block, StepBlock* __restrict__ dev_block,
+                                                         int* __restrict__ tokens_dev, int* __restrict__ ring_row,
+                                                         int* __restrict__ beam_of_row, int* __restrict__ d_offset,
+                                                         const float* __restrict__ tok_emb, const float* __restrict__ pos_emb,
+                                                         float* __restrict__ x, int d) {
+    constexpr int kWords = sizeof(StepBlock) / 4, kHead = sizeof(StepRow) / 4;
+    static_assert(kWords <= 512 && sizeof(StepBlock) <= 2048, "two words of the step block per thread");
+    __shared__ unsigned head[kHead];
+    const int tid = threadIdx.x;
+    const unsigned* src = reinterpret_cast<const unsigned*>(host_block);
+    unsigned w0 = 0, w1 = 0;
+    if (tid < kWords) w0 = __hip_atomic_load(src + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid + 256 < kWords) w1 = __hip_atomic_load(src + tid + 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid < kWords) reinterpret_cast<unsigned*>(dev_block)[tid] = w0;
+    if (tid + 256 < kWords) reinterpret_cast<unsigned*>(dev_block)[tid + 256] = w1;
+    if (tid < kHead) head[tid] = w0;
+    __syncthreads();
+    const StepRow* row = reinterpret_cast<const StepRow*>(head);
+    const int token = row->token, offset = row->offset;
+    if (tid == 0) {
+        tokens_dev[0] = token;
+        ring_row[0] = row->ring_row;
+        beam_of_row[0] = 0;
+        d_offset[0] = offset;
+    }
+    const float* e = tok_emb + (long)token * d;
+    const float* pe = pos_emb + (long)offset * d;
+    for (int c = tid; c < d; c += 256) x[c] = e[c] + pe[c];
+}
+
+void launch_embed_step(const LaunchCtx& ctx, const StepBlock* host_block, StepBlock* dev_block, int* tokens_dev,
+                       int* ring_row, int* beam_of_row, int* d_offset, const float* tok_emb, const float* pos_emb, float* x,
+                       int d) {
+    KernelScope ks(ctx, "dec_embed");
+    hipLaunchKernelGGL(embed_step_kernel, dim3(1), dim3(256), 0, ctx.stream, host_block, dev_block, tokens_dev, ring_row,
+                       beam_of_row, d_offset, tok_emb, pos_emb, x, d);
+    WLK_HIP(hipGetLastError());
+}
+
 // qkv rows are [q | k | v] (3d floats); append k and v of every row to the per-beam caches
 __global__ __launch_bounds__(256) void kv_append_kernel(const float* __restrict__ qkv, float* __restrict__ kc,
                                                         float* __restrict__ vc, int n_tok,

@@ -251,16 +251,19 @@ void wlk_engine::step_single(EngineJob* j, std::vector<EngineJob*>& finished) {
     // a lone loop takes the session's own (graph-captured, single-row) launch chain
     DecodeJob& job = *j->job;
     const int64_t tok = job.seq.back();
-    int rc = wlk_decode(j->s, &tok, 1, 1, 0, job.P.sot_index);
     std::vector<int32_t> ids, rows;
     std::vector<float> deltas;
     float lp[2] = {0.f, 0.f};
     int32_t top[2] = {0, 0}, frame = 0;
-    if (rc == WLK_OK) {
-        job.adjustments(ids, deltas);
-        rows.assign(ids.size(), -1);
-        rc = wlk_select(j->s, rows.data(), ids.data(), deltas.data(), (int)ids.size(), 2, job.P.content_mel_len, lp, top,
-                        &frame);
+    job.adjustments(ids, deltas);
+    int rc = wlk_step_select(j->s, tok, ids.data(), deltas.data(), (int)ids.size(), job.P.content_mel_len, lp, top, &frame);
+    if (rc == 1) {   // the session does not qualify for the one-replay step
+        rc = wlk_decode(j->s, &tok, 1, 1, 0, job.P.sot_index);
+        if (rc == WLK_OK) {
+            rows.assign(ids.size(), -1);
+            rc = wlk_select(j->s, rows.data(), ids.data(), deltas.data(), (int)ids.size(), 2, job.P.content_mel_len, lp, top,
+                            &frame);
+        }
     }
     if (rc != WLK_OK) {
         j->rc = rc;

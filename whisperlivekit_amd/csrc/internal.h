@@ -197,6 +197,12 @@ struct wlk_session {
     static constexpr int kAdjCap = 4096;
     void* pinned = nullptr;  // 1 MiB
     static constexpr size_t kPinnedBytes = 1 << 20;
+    // single-token steps as one graph replay (wlk_step_select): host-coherent blocks the step's first / last kernel
+    // read / write directly, their device-side addresses, the device copy of the input block, one graph per KV set
+    wlk::StepBlock *step_host = nullptr, *step_host_dev = nullptr, *step_dev = nullptr;
+    wlk::StepResult *result_host = nullptr, *result_host_dev = nullptr;
+    hipGraphExec_t fstep_exec[2] = {nullptr, nullptr};
+    unsigned step_seq = 0;
 
     wlk::LaunchCtx ctx() { return wlk::LaunchCtx{stream, prof_on ? &prof : nullptr}; }
     wlk_engine* engine = nullptr;   // set by wlk_engine_attach: single-token steps run batched with the other attached sessions
@@ -204,6 +210,15 @@ struct wlk_session {
 
 
 // api.hip
+// One single-token step of a beam-1 session + its read-out (wlk_decode(first=0) followed by wlk_select(k=2)) as one
+// graph replay without copy nodes.  Returns 1 (and does nothing) when the session / step does not qualify.
+int wlk_step_select(wlk_session* s, int64_t token, const int32_t* adj_ids, const float* adj_deltas, int n_adj,
+                    int content_mel_len, float* top_logprobs2, int32_t* top_ids2, int32_t* frame);
+// wlk_no_speech_prob + wlk_select of the first step of an infer behind one synchronisation (the read-out runs whatever the
+// probability turns out to be; a caller that stops on no-speech simply ignores it)
+int wlk_select_first(wlk_session* s, int no_speech_token, const int32_t* adj_row, const int32_t* adj_ids,
+                     const float* adj_deltas, int n_adj, int k, int content_mel_len, float* no_speech_host,
+                     float* top_logprobs_host, int32_t* top_ids_host, int32_t* frames_host);
 void wlk_encode_group(const std::vector<wlk_session*>& group, const wlk::LaunchCtx& c, std::vector<int>& content_out);
 
 // engine.hip

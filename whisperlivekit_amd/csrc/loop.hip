@@ -17,6 +17,8 @@
 #include "../../include/wlk_hip.h"
 #include "common.h"
 #include "internal.h"
+#include <cstdlib>
+
 #include "loop.h"
 
 namespace wlk {
@@ -256,19 +258,45 @@ int wlk_decode_until_stop(wlk_session* s, const int64_t* tokens, int n_tok, cons
     while (job.begin_step()) {
         const bool first = job.fresh;
         const int64_t* feed = first ? job.seq.data() : job.seq.data() + job.seq.size() - 1;
+        float lp[2];
+        int32_t top[2], frame = 0;
+        if (!first) {
+            // single-token step and its read-out as one graph replay; 1 = this session / step does not qualify
+            job.adjustments(ids, deltas);
+            const int rc = wlk_step_select(s, feed[0], ids.data(), deltas.data(), (int)ids.size(), p->content_mel_len, lp,
+                                           top, &frame);
+            if (rc == WLK_OK) {
+                if (!job.consume(lp, top, frame)) break;
+                if (wlk_engine_wants(s)) {
+                    if (int rc2 = wlk_engine_run_job(s, &job)) return rc2;
+                    break;
+                }
+                continue;
+            }
+            if (rc != 1) return rc;
+        }
         if (int rc = wlk_decode(s, feed, 1, first ? (int)job.seq.size() : 1, first ? 1 : 0, p->sot_index)) return rc;
-        if (first && p->no_speech_token >= 0) {
+        job.adjustments(ids, deltas);
+        rows.assign(ids.size(), -1);
+        static const bool merged_first = getenv("WLK_NO_FIRST_MERGE") == nullptr;   // A/B switch
+        if (first && p->no_speech_token >= 0 && !merged_first) {
             float prob = 0.f;
             if (int rc = wlk_no_speech_prob(s, p->no_speech_token, &prob)) return rc;
             if (job.no_speech(prob)) break;
-        }
-        job.adjustments(ids, deltas);
-        rows.assign(ids.size(), -1);
-        float lp[2];
-        int32_t top[2], frame = 0;
-        if (int rc = wlk_select(s, rows.data(), ids.data(), deltas.data(), (int)ids.size(), 2, p->content_mel_len, lp, top,
-                                &frame))
+            if (int rc = wlk_select(s, rows.data(), ids.data(), deltas.data(), (int)ids.size(), 2, p->content_mel_len, lp, top,
+                                    &frame))
+                return rc;
+        } else if (first && p->no_speech_token >= 0) {
+            // no-speech probability and read-out share one synchronisation; a no-speech stop ignores the read-out
+            float prob = 0.f;
+            if (int rc = wlk_select_first(s, p->no_speech_token, rows.data(), ids.data(), deltas.data(), (int)ids.size(), 2,
+                                          p->content_mel_len, &prob, lp, top, &frame))
+                return rc;
+            if (job.no_speech(prob)) break;
+        } else if (int rc = wlk_select(s, rows.data(), ids.data(), deltas.data(), (int)ids.size(), 2, p->content_mel_len, lp,
+                                       top, &frame)) {
             return rc;
+        }
         if (!job.consume(lp, top, frame)) break;
         if (wlk_engine_wants(s)) {
             // the prefill is done: the single-token steps of this loop advance together with the loops of the other

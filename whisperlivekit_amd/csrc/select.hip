@@ -62,6 +62,7 @@ struct TopkArgs {
     int n_adj;
     float* top_vals;
     int* top_ids;
+    StepHostOut host;   // single-session graph steps: n_adj comes from the device block, results also go to the host
 };
 
 __device__ __forceinline__ void topk_stage1_body(float* __restrict__ logits, int n_vocab, int k,
@@ -130,8 +131,16 @@ __global__ __launch_bounds__(256) void topk_stage1_kernel(float* __restrict__ lo
     topk_stage1_body(logits, n_vocab, k, parts, adj_row, adj_ids, adj_deltas, n_adj, blockIdx.x, blockIdx.y);
 }
 
+// results of a single-session graph step go straight into pinned host memory; the flag is stored after a system-scope
+// fence, so a host that sees the flag sees the fields
+__device__ __forceinline__ void publish_flag(unsigned* flag, unsigned seq) {
+    __threadfence_system();
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ void topk_stage2_body(const SelPartial* __restrict__ parts, int k,
-                                                 float* __restrict__ top_vals, int* __restrict__ top_ids, int row) {
+                                                 float* __restrict__ top_vals, int* __restrict__ top_ids, int row,
+                                                 const StepHostOut host = StepHostOut{}) {
     const int lane = threadIdx.x;   // one lane per slice (the first wave of the workgroup)
     const SelPartial p = parts[(long)row * kSelBlocks + lane];
     float mx = p.mx;
@@ -161,8 +170,13 @@ __device__ __forceinline__ void topk_stage2_body(const SelPartial* __restrict__ 
         if (lane == 0) {
             top_ids[row * k + round] = wi;
             top_vals[row * k + round] = (wv - mx) - lse;
+            if (host.result && row == 0 && round < 2) {
+                host.result->top_ids[round] = wi;
+                host.result->top_vals[round] = (wv - mx) - lse;
+            }
         }
     }
+    if (host.result && lane == 0 && row == 0) publish_flag(&host.result->flag_topk, host.block->seq);
 }
 
 __global__ __launch_bounds__(64) void topk_stage2_kernel(const SelPartial* __restrict__ parts, int k,
@@ -322,7 +336,7 @@ __global__ __launch_bounds__(256) void align_argmax_kernel(AlignArgs a) {
 
 // Step 2 variant for the common case (z of all alignment heads fits LDS): 1024 threads stage z with
 // coalesced loads once, then medians / head mean / arg-max run out of LDS.
-__device__ __forceinline__ void align_argmax_lds_body(AlignArgs a, int b) {
+__device__ __forceinline__ void align_argmax_lds_body(AlignArgs a, int b, const StepHostOut host = StepHostOut{}) {
     extern __shared__ __attribute__((aligned(16))) float zs[];   // [n_align][T]
     __shared__ float bestv[1024];
     __shared__ int besti[1024];
@@ -362,7 +376,14 @@ __device__ __forceinline__ void align_argmax_lds_body(AlignArgs a, int b) {
         }
         __syncthreads();
     }
-    if (tid == 0) a.frames[b] = besti[0] == 0x7fffffff ? 0 : besti[0];
+    if (tid == 0) {
+        const int frame = besti[0] == 0x7fffffff ? 0 : besti[0];
+        a.frames[b] = frame;
+        if (host.result && b == 0) {
+            host.result->frame = frame;
+            publish_flag(&host.result->flag_align, host.block->seq);
+        }
+    }
 }
 
 __global__ __launch_bounds__(1024) void align_argmax_lds_kernel(AlignArgs a) { align_argmax_lds_body(a, blockIdx.x); }
@@ -376,7 +397,8 @@ __global__ __launch_bounds__(1024) void align_argmax_lds_kernel(AlignArgs a) { a
 __global__ __launch_bounds__(256) void select_stage1_kernel(TopkArgs t, AlignArgs a, int zf_blocks) {
     const int n_topk = kSelBlocks * t.n_rows;
     if ((int)blockIdx.x < n_topk) {
-        topk_stage1_body(t.logits, t.n_vocab, t.k, t.parts, t.adj_row, t.adj_ids, t.adj_deltas, t.n_adj,
+        const int n_adj = t.host.block ? t.host.block->n_adj : t.n_adj;
+        topk_stage1_body(t.logits, t.n_vocab, t.k, t.parts, t.adj_row, t.adj_ids, t.adj_deltas, n_adj,
                          blockIdx.x % kSelBlocks, blockIdx.x / kSelBlocks);
     } else {
         const int i = blockIdx.x - n_topk;
@@ -387,21 +409,26 @@ __global__ __launch_bounds__(256) void select_stage1_kernel(TopkArgs t, AlignArg
 
 __global__ __launch_bounds__(1024) void select_stage2_kernel(TopkArgs t, AlignArgs a) {
     if ((int)blockIdx.x < a.n_beam) {
-        align_argmax_lds_body(a, blockIdx.x);
+        align_argmax_lds_body(a, blockIdx.x, t.host);
     } else if (threadIdx.x < 64) {
-        topk_stage2_body(t.parts, t.k, t.top_vals, t.top_ids, blockIdx.x - a.n_beam);
+        topk_stage2_body(t.parts, t.k, t.top_vals, t.top_ids, blockIdx.x - a.n_beam, t.host);
     }
 }
 
-bool launch_select_fused(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, int k, float* top_vals, int* top_ids,
-                         void* scratch, const int* adj_row, const int* adj_ids, const float* adj_deltas, int n_adj,
-                         const AlignArgs& a) {
+bool select_fused_applicable(int n_rows, int k, const AlignArgs& a) {
     static const bool enabled = [] {
         const char* e = getenv("WLK_SELECT_FUSED");
         return !(e && e[0] == '0');
     }();
     const size_t lds = (size_t)a.n_align * a.T * sizeof(float);
-    if (!enabled || a.n_align <= 0 || a.n_beam != n_rows || lds + 8192 + 1024 > 150 * 1024 || k < 1 || k > kMaxTopK) return false;
+    return enabled && a.n_align > 0 && a.n_beam == n_rows && lds + 8192 + 1024 <= 150 * 1024 && k >= 1 && k <= kMaxTopK;
+}
+
+bool launch_select_fused(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, int k, float* top_vals, int* top_ids,
+                         void* scratch, const int* adj_row, const int* adj_ids, const float* adj_deltas, int n_adj,
+                         const AlignArgs& a, const StepHostOut& host) {
+    const size_t lds = (size_t)a.n_align * a.T * sizeof(float);
+    if (!select_fused_applicable(n_rows, k, a)) return false;
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     WLK_HIP(hipGetDevice(&dev));
@@ -410,7 +437,8 @@ bool launch_select_fused(const LaunchCtx& ctx, float* logits, int n_vocab, int n
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set[dev].store(true, std::memory_order_release);
     }
-    TopkArgs t{logits, n_vocab, k, n_rows, static_cast<SelPartial*>(scratch), adj_row, adj_ids, adj_deltas, n_adj, top_vals, top_ids};
+    TopkArgs t{logits, n_vocab, k, n_rows, static_cast<SelPartial*>(scratch), adj_row, adj_ids, adj_deltas, n_adj, top_vals, top_ids,
+               host};
     const int zf = (a.T + 63) / 64;
     {
         KernelScope ks(ctx, "sel_stage1", 0.0, 4.0 * 3.0 * n_rows * (double)n_vocab);
