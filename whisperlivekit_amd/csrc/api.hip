@@ -387,6 +387,10 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         WLK_HIP(hipMalloc(&s->topk_scratch, topk_scratch_bytes(beam)));
         s->probs = dev_alloc<float>(beam);
         WLK_HIP(hipHostMalloc(&s->pinned, wlk_session::kPinnedBytes, hipHostMallocDefault));
+        WLK_HIP(hipHostMalloc(&s->dec_stage, 65536, hipHostMallocDefault));
+        WLK_HIP(hipHostMalloc(&s->audio_stage, wlk_session::kPinnedBytes, hipHostMallocDefault));
+        WLK_HIP(hipEventCreateWithFlags(&s->audio_stage_ev, hipEventDisableTiming));
+        WLK_HIP(hipEventCreateWithFlags(&s->dec_stage_ev, hipEventDisableTiming));
         if (beam == 1) {
             void* hp = nullptr;
             WLK_HIP(hipHostMalloc(&hp, 4096, hipHostMallocMapped | hipHostMallocCoherent));
@@ -425,6 +429,10 @@ int wlk_session_destroy(wlk_session* s) {
     if (s->pcm16_dev) (void)hipFree(s->pcm16_dev);
     if (s->esplit) (void)hipFree(s->esplit);
     if (s->pinned) (void)hipHostFree(s->pinned);
+    if (s->dec_stage) (void)hipHostFree(s->dec_stage);
+    if (s->audio_stage) (void)hipHostFree(s->audio_stage);
+    if (s->audio_stage_ev) (void)hipEventDestroy(s->audio_stage_ev);
+    if (s->dec_stage_ev) (void)hipEventDestroy(s->dec_stage_ev);
     if (s->step_host) (void)hipHostFree(s->step_host);
     if (s->step_dev) (void)hipFree(s->step_dev);
     for (auto& e : s->fstep_exec)
@@ -452,6 +460,16 @@ int wlk_session_set_debug(wlk_session* s, int on) {
     });
 }
 
+// A/B switch (WLK_DRAIN_STAGING=1): drain the stream around the staging blocks as the library did before the blocks had
+// events of their own
+static bool drain_staging() {
+    static const bool on = [] {
+        const char* e = getenv("WLK_DRAIN_STAGING");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+
 // ---- audio ----------------------------------------------------------------------------------
 int wlk_audio_append(wlk_session* s, const float* pcm_host, int n) {
     if (!s || (n > 0 && !pcm_host) || n < 0) return fail(WLK_ERR_ARG, "bad audio chunk");
@@ -466,12 +484,14 @@ int wlk_audio_append(wlk_session* s, const float* pcm_host, int n) {
         // stage through pinned memory so the copy is asynchronous and the caller's buffer is free on return
         while (done < (size_t)n) {
             const size_t chunk = std::min((size_t)n - done, wlk_session::kPinnedBytes / sizeof(float));
-            WLK_HIP(hipStreamSynchronize(s->stream));  // pinned buffer is single-entry
-            std::memcpy(s->pinned, pcm_host + done, chunk * sizeof(float));
-            WLK_HIP(hipMemcpyAsync(dst + done, s->pinned, chunk * sizeof(float), hipMemcpyHostToDevice, s->stream));
+            if (s->audio_stage_used) WLK_HIP(hipEventSynchronize(s->audio_stage_ev));   // the block is single-entry
+            std::memcpy(s->audio_stage, pcm_host + done, chunk * sizeof(float));
+            WLK_HIP(hipMemcpyAsync(dst + done, s->audio_stage, chunk * sizeof(float), hipMemcpyHostToDevice, s->stream));
+            WLK_HIP(hipEventRecord(s->audio_stage_ev, s->stream));
+            s->audio_stage_used = true;
             done += chunk;
         }
-        WLK_HIP(hipStreamSynchronize(s->stream));
+        if (drain_staging()) WLK_HIP(hipStreamSynchronize(s->stream));
         s->audio_len += n;
         s->encoded = false;
         return WLK_OK;
@@ -493,13 +513,16 @@ int wlk_audio_append_pcm16(wlk_session* s, const int16_t* pcm_host, int n) {
         size_t done = 0;
         while (done < (size_t)n) {   // half the PCIe bytes of the fp32 path; widened on the device
             const size_t chunk = std::min((size_t)n - done, kMax);
-            WLK_HIP(hipStreamSynchronize(s->stream));  // pinned buffer and staging buffer are single-entry
-            std::memcpy(s->pinned, pcm_host + done, chunk * sizeof(int16_t));
-            WLK_HIP(hipMemcpyAsync(s->pcm16_dev, s->pinned, chunk * sizeof(int16_t), hipMemcpyHostToDevice, s->stream));
+            // the pinned block and the device staging buffer are single-entry: wait for the previous chunk's widening
+            if (s->audio_stage_used) WLK_HIP(hipEventSynchronize(s->audio_stage_ev));
+            std::memcpy(s->audio_stage, pcm_host + done, chunk * sizeof(int16_t));
+            WLK_HIP(hipMemcpyAsync(s->pcm16_dev, s->audio_stage, chunk * sizeof(int16_t), hipMemcpyHostToDevice, s->stream));
             launch_pcm16_to_float(c, s->pcm16_dev, dst + done, (int)chunk);
+            WLK_HIP(hipEventRecord(s->audio_stage_ev, s->stream));
+            s->audio_stage_used = true;
             done += chunk;
         }
-        WLK_HIP(hipStreamSynchronize(s->stream));
+        if (drain_staging()) WLK_HIP(hipStreamSynchronize(s->stream));
         s->audio_len += n;
         s->encoded = false;
         return WLK_OK;
@@ -754,7 +777,7 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
     // one host->device copy: [tokens | alignment-window row | beam of row | cache offset]
     // (wlk_step_select: the embedding kernel reads the step's inputs from the host-coherent block itself)
     if (!step_block)
-        WLK_HIP(hipMemcpyAsync(s->step_in, s->pinned, (size_t)(3 * s->max_rows + 1) * sizeof(int), hipMemcpyHostToDevice,
+        WLK_HIP(hipMemcpyAsync(s->step_in, s->dec_stage, (size_t)(3 * s->max_rows + 1) * sizeof(int), hipMemcpyHostToDevice,
                                s->stream));
     // decode steps (<= 8 rows): LayerNorm and the KV-cache append are fused into the weight-streaming
     // GEMV launches; prefill keeps them as separate kernels in front of the MFMA GEMMs
@@ -922,8 +945,11 @@ int wlk_decode(wlk_session* s, const int64_t* tokens, int n_rows, int n_tok, int
         if ((size_t)(s->max_rows * 3 + 4) * sizeof(int) > 65536) return fail(WLK_ERR_CAPACITY, "too many rows");
 
         // staging block (pinned): tokens as int32 | alignment-window row of each query row | beam of row | offset
-        WLK_HIP(hipStreamSynchronize(s->stream));  // the previous call's copies out of this block are done
-        int* stage = static_cast<int*>(s->pinned);
+        // the previous call's copy out of this block is done (an event behind it, not a drained stream: the prefill
+        // of an infer is enqueued while the encoder is still running)
+        if (s->dec_stage_used) WLK_HIP(hipEventSynchronize(s->dec_stage_ev));
+        if (drain_staging()) WLK_HIP(hipStreamSynchronize(s->stream));
+        int* stage = static_cast<int*>(s->dec_stage);
         const int slot_row = first ? 0 : ctx_len + ((s->n_steps - 1) % kAlignWindow);
         const int MR = s->max_rows;
         for (int b = 0; b < n_rows; ++b)
@@ -958,6 +984,8 @@ int wlk_decode(wlk_session* s, const int64_t* tokens, int n_rows, int n_tok, int
         } else {
             enqueue_decode(s, c, n_rows, n_tok, first != 0, sot_index);
         }
+        WLK_HIP(hipEventRecord(s->dec_stage_ev, s->stream));
+        s->dec_stage_used = true;
         s->have_sot = false;
         if (first) {
             s->have_sot = true;

@@ -478,6 +478,9 @@ bool wlk_engine_batches_encodes(const wlk_session* s) {
 
 int wlk_engine_encode(wlk_session* s, int* content_mel_len) {
     wlk_engine* e = s->engine;
+    // the encode lane runs on the engine's stream: what this session still has in flight on its own stream (the audio
+    // chunk on its way to the ring, an eviction shift) must be in place first
+    if (hipStreamSynchronize(s->stream) != hipSuccess) return fail(WLK_ERR_HIP, "encode: the session's stream failed");
     EncodeReq req;
     req.s = s;
     {

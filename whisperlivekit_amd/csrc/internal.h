@@ -197,6 +197,16 @@ struct wlk_session {
     static constexpr int kAdjCap = 4096;
     void* pinned = nullptr;  // 1 MiB
     static constexpr size_t kPinnedBytes = 1 << 20;
+    // wlk_decode's staging block has its own pinned allocation and an event behind its last use, so that a prefill can be
+    // enqueued behind a still-running encoder instead of waiting for the stream to drain
+    void* dec_stage = nullptr;
+    hipEvent_t dec_stage_ev = nullptr;
+    bool dec_stage_used = false;
+    // the same for the audio chunks on their way to the device ring: the caller's buffer is free on return, the copy is
+    // still in flight, the next append waits for it before reusing the block
+    void* audio_stage = nullptr;
+    hipEvent_t audio_stage_ev = nullptr;
+    bool audio_stage_used = false;
     // single-token steps as one graph replay (wlk_step_select): host-coherent blocks the step's first / last kernel
     // read / write directly, their device-side addresses, the device copy of the input block, one graph per KV set
     wlk::StepBlock *step_host = nullptr, *step_host_dev = nullptr, *step_dev = nullptr;
