@@ -73,14 +73,16 @@ struct wlk_engine {
     int attached = 0;
     std::atomic<int> in_loop{0};   // sessions currently inside wlk_decode_until_stop or wlk_encode
     // encode lane: concurrent encodes of the attached sessions are stacked into one launch chain (grid.y = sessions)
-    hipStream_t enc_stream = nullptr;
-    std::thread enc_worker;
+    // (WLK_ENGINE_ENCODE_LANES > 1: that many chains side by side, each on its own stream)
+    std::vector<hipStream_t> enc_streams;
+    std::vector<std::thread> enc_workers;
+    int enc_batch_cap = kMaxBatch;
     std::condition_variable cv_enc_work, cv_enc_done;
     std::deque<EncodeReq*> enc_submitted;
     bool batch_encodes = true;
     int gather_us = 0;
     uint64_t n_enc_batches = 0, n_enc_sessions = 0;
-    void run_encodes();
+    void run_encodes(int lane);
     uint64_t n_iterations = 0, n_rows = 0, n_batched = 0, n_batched_rows = 0;
 
     void run();
@@ -319,8 +321,9 @@ void wlk_engine::run() {
     }
 }
 
-void wlk_engine::run_encodes() {
+void wlk_engine::run_encodes(int lane) {
     (void)hipSetDevice(m->device);
+    hipStream_t enc_stream = enc_streams[lane];
     for (;;) {
         std::vector<EncodeReq*> batch;
         {
@@ -338,7 +341,7 @@ void wlk_engine::run_encodes() {
                        cv_enc_work.wait_until(lk, deadline) != std::cv_status::timeout) {
                 }
             }
-            while (!enc_submitted.empty() && (int)batch.size() < kMaxBatch) {
+            while (!enc_submitted.empty() && (int)batch.size() < enc_batch_cap) {
                 batch.push_back(enc_submitted.front());
                 enc_submitted.pop_front();
             }
@@ -359,10 +362,10 @@ void wlk_engine::run_encodes() {
             rc = dynamic_cast<const HipError*>(&e) ? WLK_ERR_HIP : WLK_ERR_STATE;
             err = e.what();
         }
-        n_enc_batches += 1;
-        n_enc_sessions += batch.size();
         {
             std::lock_guard<std::mutex> lk(mu);
+            n_enc_batches += 1;
+            n_enc_sessions += batch.size();
             for (EncodeReq* r : batch) {
                 r->rc = rc;
                 r->err = err;
@@ -392,7 +395,11 @@ static wlk_engine* engine_create(wlk_model* m) {
     const bool prio = !(pe && pe[0] == '0');
     WLK_HIP(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio ? prio_hi : prio_lo));
     if (const char* g = std::getenv("WLK_NO_GRAPH")) e->use_graph = !(g[0] == '1');
-    WLK_HIP(hipStreamCreateWithPriority(&e->enc_stream, hipStreamNonBlocking, prio_lo));
+    int lanes = 1;
+    if (const char* g = std::getenv("WLK_ENGINE_ENCODE_LANES")) lanes = std::max(1, std::min(4, std::atoi(g)));
+    if (const char* g = std::getenv("WLK_ENGINE_ENCODE_BATCH")) e->enc_batch_cap = std::max(1, std::min(kMaxBatch, std::atoi(g)));
+    e->enc_streams.resize(lanes, nullptr);
+    for (auto& st : e->enc_streams) WLK_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_lo));
     if (const char* g = std::getenv("WLK_BATCH_ENCODE")) e->batch_encodes = !(g[0] == '0');
     if (const char* g = std::getenv("WLK_ENCODE_GATHER_US")) e->gather_us = std::max(0, std::atoi(g));
     const size_t R = 8, d = D.n_text_state, T = D.n_audio_ctx, V = D.n_vocab;
@@ -413,7 +420,8 @@ static wlk_engine* engine_create(wlk_model* m) {
     WLK_HIP(hipStreamSynchronize(e->stream));
     wlk_engine* raw = e.release();
     raw->worker = std::thread([raw] { raw->run(); });
-    raw->enc_worker = std::thread([raw] { raw->run_encodes(); });
+    for (int lane = 0; lane < (int)raw->enc_streams.size(); ++lane)
+        raw->enc_workers.emplace_back([raw, lane] { raw->run_encodes(lane); });
     return raw;
 }
 
@@ -427,8 +435,10 @@ void wlk_engine_destroy_for_model(wlk_model* m) {
     e->cv_work.notify_all();
     e->cv_enc_work.notify_all();
     if (e->worker.joinable()) e->worker.join();
-    if (e->enc_worker.joinable()) e->enc_worker.join();
-    if (e->enc_stream) (void)hipStreamDestroy(e->enc_stream);
+    for (auto& w : e->enc_workers)
+        if (w.joinable()) w.join();
+    for (auto& st : e->enc_streams)
+        if (st) (void)hipStreamDestroy(st);
     (void)hipSetDevice(m->device);
     float* fl[] = {e->x, e->qkv, e->att, e->q, e->mlp, e->logits, e->xsplit, e->z, e->attn_last, e->res_dev};
     for (float* p : fl)
