@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -1178,6 +1179,7 @@ extern "C++" int wlk_step_select(wlk_session* s, int64_t token, const int32_t* a
         // the last kernel stores the two flags after the fields; spin on them, and look at the stream now and then so
         // that a failed launch cannot hang the caller
         volatile StepResult* r = s->result_host;
+        const auto t_start = std::chrono::steady_clock::now();
         for (unsigned spins = 0;; ++spins) {
             const unsigned f1 = __atomic_load_n(&s->result_host->flag_topk, __ATOMIC_ACQUIRE);
             const unsigned f2 = __atomic_load_n(&s->result_host->flag_align, __ATOMIC_ACQUIRE);
@@ -1191,6 +1193,8 @@ extern "C++" int wlk_step_select(wlk_session* s, int64_t token, const int32_t* a
                     throw std::runtime_error("fused step: the graph finished without delivering its result");
                 }
                 if (q != hipErrorNotReady) WLK_HIP(q);
+                if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30))
+                    throw std::runtime_error("fused step: no result after 30 s");
             }
             __builtin_ia32_pause();
         }
