@@ -2,6 +2,7 @@
 // sequences for encode / decode / select.  Host-side orchestration only; the arithmetic lives in
 // the kernel files next to this one.
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <atomic>
 #include <chrono>
@@ -197,6 +198,12 @@ int wlk_model_create(const wlk_dims* dims, int device, float* arena_dev, wlk_mod
         m->filt_hi = dev_alloc<int>(dims->n_mels);
         m->head_rank = dev_alloc<int>((size_t)dims->n_text_layer * dims->n_text_head);
         m->layer_ranks = dev_alloc<int>((size_t)dims->n_text_layer * dims->n_text_head);
+        m->all_ranks = dev_alloc<int>((size_t)dims->n_text_layer * dims->n_text_head);
+        {
+            std::vector<int> iota((size_t)dims->n_text_layer * dims->n_text_head);
+            for (size_t i = 0; i < iota.size(); ++i) iota[i] = (int)i;
+            WLK_HIP(hipMemcpy(m->all_ranks, iota.data(), iota.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
         m->layer_rank_count.assign(dims->n_text_layer, 0);
         std::vector<int> none((size_t)dims->n_text_layer * dims->n_text_head, -1);
         WLK_HIP(hipMemcpy(m->head_rank, none.data(), none.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -312,6 +319,7 @@ int wlk_model_destroy(wlk_model* m) {
     (void)hipFree(m->filt_hi);
     (void)hipFree(m->head_rank);
     (void)hipFree(m->layer_ranks);
+    (void)hipFree(m->all_ranks);
     delete m;
     return WLK_OK;
 }
@@ -412,6 +420,9 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
 
 int wlk_session_destroy(wlk_session* s) {
     if (!s) return WLK_OK;
+    if (s->step_count)
+        fprintf(stderr, "[wlk] one-replay steps: %llu, mean %.1f us per step (graph launch call %.1f us)\n",
+                (unsigned long long)s->step_count, s->step_ns / 1e3 / s->step_count, s->step_launch_ns / 1e3 / s->step_count);
     (void)wlk_engine_detach(s);
     (void)hipSetDevice(s->m->device);
     (void)hipStreamSynchronize(s->stream);
@@ -791,6 +802,7 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
         launch_embed(c, s->tokens_dev, m->w_tok_emb, m->w_dec_pos, s->dx, n_rows, n_tok, s->d_offset, d);
     const float scale = std::pow((float)kHeadDim, -0.25f);
     const size_t cache_layer = (size_t)s->beam * ctx_len * d;
+    bool scores_dumped = false;   // prefill: raw alignment-head scores are waiting in the window rows
     for (int i = 0; i < D.n_text_layer; ++i) {
         const LayerW& L = m->dec_layers[i];
         float* kc = s->kcache[s->kv_cur] + i * cache_layer;
@@ -848,8 +860,7 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
                 fa.part_l = fa.part_m + (size_t)s->max_rows * H * fa.k_splits;
             }
             launch_prefill_cross_attention(c, fa);
-            launch_ring_softmax(c, s->ring, s->ring_row, s->beam_of_row, m->layer_ranks + (size_t)i * H,
-                                m->layer_rank_count[i], R, s->ring_rows, s->beam, T);
+            scores_dumped = true;   // softmaxed in place behind the last layer, all alignment heads in one launch
         } else {
             CrossAttnArgs ca;
             ca.q = s->dq;
@@ -890,6 +901,8 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
         launch_linear(c, xo, "dec_xout");
         transformer_mlp(c, L, s->dx, s->dh, s->dmlp, R, d, "dec_ln2", "dec_fc1", "dec_fc2");
     }
+    if (scores_dumped && m->n_align > 0)
+        launch_ring_softmax(c, s->ring, s->ring_row, s->beam_of_row, m->all_ranks, m->n_align, R, s->ring_rows, s->beam, T);
     // final LayerNorm + vocabulary projection only for the rows the policy reads
     GemmArgs lg;
     lg.lda = d; lg.W = m->w_tok_emb; lg.C = s->logits_last; lg.ldc = V; lg.M = n_rows; lg.N = V; lg.K = d;
@@ -1056,10 +1069,12 @@ static int select_impl(wlk_session* s, const int32_t* adj_row, const int32_t* ad
         a.newest_row = s->n_steps == 1 ? s->prefill_rows - 1 : D.n_text_ctx + ((s->n_steps - 2) % kAlignWindow);
         a.content_len = content_mel_len;
         a.z = s->z; a.attn_last = s->attn_last; a.frames = s->frames;
+        // the no-speech probability of the sot rows is one more role of the read-out's second launch
         float* ns_dev = s->top_vals + (size_t)B * 17;
-        if (no_speech_host) launch_token_prob(c, s->logits_sot, V, B, no_speech_token, ns_dev);
         if (!launch_select_fused(c, s->logits_last, V, B, k, s->top_vals, s->top_ids, s->topk_scratch, adj_rows_d,
-                                 adj_ids_d, adj_deltas_d, n_adj, a)) {
+                                 adj_ids_d, adj_deltas_d, n_adj, a, StepHostOut{}, no_speech_host ? s->logits_sot : nullptr,
+                                 no_speech_token, ns_dev)) {
+            if (no_speech_host) launch_token_prob(c, s->logits_sot, V, B, no_speech_token, ns_dev);
             launch_logsoftmax_topk(c, s->logits_last, V, B, k, s->top_vals, s->top_ids, s->topk_scratch, adj_rows_d,
                                    adj_ids_d, adj_deltas_d, n_adj);
             launch_alignatt(c, a);
@@ -1146,6 +1161,8 @@ extern "C++" int wlk_step_select(wlk_session* s, int64_t token, const int32_t* a
         b.seq = seq;
         std::atomic_thread_fence(std::memory_order_release);
 
+        static const bool timing = getenv("WLK_STEP_TIMING") != nullptr;
+        const auto t_enter = std::chrono::steady_clock::now();
         hipGraphExec_t& exec = s->fstep_exec[s->kv_cur];
         if (!exec) {
             hipGraph_t graph = nullptr;
@@ -1180,6 +1197,7 @@ extern "C++" int wlk_step_select(wlk_session* s, int64_t token, const int32_t* a
         // that a failed launch cannot hang the caller
         volatile StepResult* r = s->result_host;
         const auto t_start = std::chrono::steady_clock::now();
+        if (timing) s->step_launch_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_start - t_enter).count();
         for (unsigned spins = 0;; ++spins) {
             const unsigned f1 = __atomic_load_n(&s->result_host->flag_topk, __ATOMIC_ACQUIRE);
             const unsigned f2 = __atomic_load_n(&s->result_host->flag_align, __ATOMIC_ACQUIRE);
@@ -1197,6 +1215,10 @@ extern "C++" int wlk_step_select(wlk_session* s, int64_t token, const int32_t* a
                     throw std::runtime_error("fused step: no result after 30 s");
             }
             __builtin_ia32_pause();
+        }
+        if (timing) {
+            s->step_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_enter).count();
+            s->step_count += 1;
         }
         top_logprobs2[0] = r->top_vals[0]; top_logprobs2[1] = r->top_vals[1];
         top_ids2[0] = r->top_ids[0]; top_ids2[1] = r->top_ids[1];

@@ -361,7 +361,8 @@ void launch_alignatt(const LaunchCtx& ctx, const AlignArgs& a);
 // the configuration needs the separate kernels (no alignment heads, window too large for LDS, WLK_SELECT_FUSED=0)
 bool launch_select_fused(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, int k, float* top_vals, int* top_ids,
                          void* scratch, const int* adj_row, const int* adj_ids, const float* adj_deltas, int n_adj,
-                         const AlignArgs& a, const StepHostOut& host = StepHostOut{});
+                         const AlignArgs& a, const StepHostOut& host = StepHostOut{}, const float* ns_logits = nullptr,
+                         int ns_token = 0, float* ns_probs = nullptr);
 bool select_fused_applicable(int n_rows, int k, const AlignArgs& a);
 // batched steps: one read-out per row with the row's own window / counters (a.ring, prefill_rows, n_single, newest_row
 // and content_len are taken from rows[r]; a.n_beam is the number of rows, each row is its own beam 0)

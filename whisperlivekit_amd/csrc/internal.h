@@ -112,6 +112,7 @@ struct wlk_model {
     int* filt_hi = nullptr;
     int* head_rank = nullptr;         // [L][H] alignment rank or -1
     int* layer_ranks = nullptr;       // [L][H] ranks of each layer's alignment heads, compacted
+    int* all_ranks = nullptr;         // [L*H] 0, 1, 2, ...: every alignment rank in one launch
     std::vector<int> layer_rank_count;
     std::vector<int> align_pairs;     // (layer, head)*
     int n_align = 0;
@@ -213,6 +214,7 @@ struct wlk_session {
     wlk::StepResult *result_host = nullptr, *result_host_dev = nullptr;
     hipGraphExec_t fstep_exec[2] = {nullptr, nullptr};
     unsigned step_seq = 0;
+    uint64_t step_ns = 0, step_launch_ns = 0, step_count = 0;   // WLK_STEP_TIMING=1: printed when the session is destroyed
 
     wlk::LaunchCtx ctx() { return wlk::LaunchCtx{stream, prof_on ? &prof : nullptr}; }
     wlk_engine* engine = nullptr;   // set by wlk_engine_attach: single-token steps run batched with the other attached sessions

@@ -44,6 +44,9 @@ __global__ __launch_bounds__(256) void mel_frame_kernel(MelArgs a) {
     if (tid < kNFreq) {
         double re = 0.0, im = 0.0;
         int idx = 0;  // (tid * n) mod 400
+        // the two fma chains are the only loop-carried dependency: unrolled, the LDS reads of eight steps are in
+        // flight together instead of one round trip per step (same fma order)
+#pragma unroll 8
         for (int n = 0; n < kNFft; ++n) {
             const double x = (double)xw[n];
             int sidx = idx + 300;  // sin(theta) = cos(theta - pi/2) = tw[(idx - 100) mod 400]

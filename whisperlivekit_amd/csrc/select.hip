@@ -63,6 +63,10 @@ struct TopkArgs {
     float* top_vals;
     int* top_ids;
     StepHostOut host;   // single-session graph steps: n_adj comes from the device block, results also go to the host
+    // first step of an infer: the no-speech probability of the sot rows rides in the second launch (n_rows more blocks)
+    const float* ns_logits = nullptr;
+    int ns_token = 0;
+    float* ns_probs = nullptr;
 };
 
 __device__ __forceinline__ void topk_stage1_body(float* __restrict__ logits, int n_vocab, int k,
@@ -204,18 +208,41 @@ void launch_logsoftmax_topk(const LaunchCtx& ctx, float* logits, int n_vocab, in
 
 size_t topk_scratch_bytes(int n_rows) { return sizeof(SelPartial) * kSelBlocks * (size_t)n_rows; }
 
+// softmax(logits)[token] of one row by one 1024-thread workgroup.  The row is read ONCE (each thread keeps its strided
+// elements in registers between the max pass and the sum pass); the order of every max / sum is that of the plain
+// two-pass loops.
+__device__ __forceinline__ void token_prob_body(const float* __restrict__ logits, int n_vocab, int token,
+                                                float* __restrict__ probs, int row) {
+    __shared__ float red[16];
+    constexpr int kKeep = 64;   // elements per thread held in registers: rows up to 65 536 logits
+    const int tid = threadIdx.x;
+    const float* x = logits + (long)row * n_vocab;
+    float mx = -INFINITY, sum = 0.f;
+    if (n_vocab <= kKeep * kSelThreads) {
+        float v[kKeep];
+#pragma unroll
+        for (int j = 0; j < kKeep; ++j) {
+            const int i = tid + j * kSelThreads;
+            v[j] = i < n_vocab ? x[i] : -INFINITY;
+        }
+#pragma unroll
+        for (int j = 0; j < kKeep; ++j) mx = fmaxf(mx, v[j]);
+        mx = block_max(mx, red);
+#pragma unroll
+        for (int j = 0; j < kKeep; ++j)
+            if (tid + j * kSelThreads < n_vocab) sum += expf(v[j] - mx);
+    } else {
+        for (int i = tid; i < n_vocab; i += kSelThreads) mx = fmaxf(mx, x[i]);
+        mx = block_max(mx, red);
+        for (int i = tid; i < n_vocab; i += kSelThreads) sum += expf(x[i] - mx);
+    }
+    sum = block_sum(sum, red);
+    if (tid == 0) probs[row] = expf(x[token] - mx) / sum;
+}
+
 __global__ __launch_bounds__(kSelThreads) void token_prob_kernel(const float* __restrict__ logits, int n_vocab,
                                                                  int token, float* __restrict__ probs) {
-    __shared__ float red[16];
-    const int tid = threadIdx.x;
-    const float* x = logits + (long)blockIdx.x * n_vocab;
-    float mx = -INFINITY;
-    for (int i = tid; i < n_vocab; i += kSelThreads) mx = fmaxf(mx, x[i]);
-    mx = block_max(mx, red);
-    float sum = 0.f;
-    for (int i = tid; i < n_vocab; i += kSelThreads) sum += expf(x[i] - mx);
-    sum = block_sum(sum, red);
-    if (tid == 0) probs[blockIdx.x] = expf(x[token] - mx) / sum;
+    token_prob_body(logits, n_vocab, token, probs, blockIdx.x);
 }
 
 void launch_token_prob(const LaunchCtx& ctx, const float* logits, int n_vocab, int n_rows, int token, float* probs) {
@@ -410,8 +437,10 @@ __global__ __launch_bounds__(256) void select_stage1_kernel(TopkArgs t, AlignArg
 __global__ __launch_bounds__(1024) void select_stage2_kernel(TopkArgs t, AlignArgs a) {
     if ((int)blockIdx.x < a.n_beam) {
         align_argmax_lds_body(a, blockIdx.x, t.host);
-    } else if (threadIdx.x < 64) {
-        topk_stage2_body(t.parts, t.k, t.top_vals, t.top_ids, blockIdx.x - a.n_beam, t.host);
+    } else if ((int)blockIdx.x < a.n_beam + t.n_rows) {
+        if (threadIdx.x < 64) topk_stage2_body(t.parts, t.k, t.top_vals, t.top_ids, blockIdx.x - a.n_beam, t.host);
+    } else {
+        token_prob_body(t.ns_logits, t.n_vocab, t.ns_token, t.ns_probs, blockIdx.x - a.n_beam - t.n_rows);
     }
 }
 
@@ -426,7 +455,7 @@ bool select_fused_applicable(int n_rows, int k, const AlignArgs& a) {
 
 bool launch_select_fused(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, int k, float* top_vals, int* top_ids,
                          void* scratch, const int* adj_row, const int* adj_ids, const float* adj_deltas, int n_adj,
-                         const AlignArgs& a, const StepHostOut& host) {
+                         const AlignArgs& a, const StepHostOut& host, const float* ns_logits, int ns_token, float* ns_probs) {
     const size_t lds = (size_t)a.n_align * a.T * sizeof(float);
     if (!select_fused_applicable(n_rows, k, a)) return false;
     static std::atomic<bool> attr_set[64];
@@ -438,7 +467,7 @@ bool launch_select_fused(const LaunchCtx& ctx, float* logits, int n_vocab, int n
         attr_set[dev].store(true, std::memory_order_release);
     }
     TopkArgs t{logits, n_vocab, k, n_rows, static_cast<SelPartial*>(scratch), adj_row, adj_ids, adj_deltas, n_adj, top_vals, top_ids,
-               host};
+               host, ns_logits, ns_token, ns_probs};
     const int zf = (a.T + 63) / 64;
     {
         KernelScope ks(ctx, "sel_stage1", 0.0, 4.0 * 3.0 * n_rows * (double)n_vocab);
@@ -448,7 +477,8 @@ bool launch_select_fused(const LaunchCtx& ctx, float* logits, int n_vocab, int n
     }
     {
         KernelScope ks(ctx, "sel_stage2");
-        hipLaunchKernelGGL(select_stage2_kernel, dim3(a.n_beam + n_rows), dim3(1024), lds, ctx.stream, t, a);
+        hipLaunchKernelGGL(select_stage2_kernel, dim3(a.n_beam + n_rows + (ns_logits ? n_rows : 0)), dim3(1024), lds,
+                           ctx.stream, t, a);
         WLK_HIP(hipGetLastError());
     }
     return true;
