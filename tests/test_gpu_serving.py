@@ -255,3 +255,11 @@ def test_finalized_model_is_immutable():
     assert s.encode() == 50
     s.close()
     m.close()
+
+
+@pytest.mark.gpu
+def test_graft_entry_smoke_runs():
+    """The driver's round-end check: one tiny hot-path invocation on cuda:0 compared with the oracle."""
+    import importlib
+    entry = importlib.import_module("__graft_entry__")
+    entry.smoke()
