@@ -1173,7 +1173,8 @@ extern "C++" int wlk_step_select(wlk_session* s, int64_t token, const int32_t* a
                 a.rows = &s->step_dev->row;
                 StepHostOut ho;
                 ho.result = s->result_host_dev;
-                ho.block = s->step_dev;
+                ho.n_adj = &s->step_dev->n_adj;
+                ho.seq = &s->step_dev->seq;
                 if (!launch_select_fused(c, s->logits_last, D.n_vocab, 1, 2, s->top_vals, s->top_ids, s->topk_scratch,
                                          s->step_dev->adj_row, s->step_dev->adj_ids, s->step_dev->adj_deltas, 0, a, ho))
                     throw std::runtime_error("fused step: read-out not available");
@@ -1193,29 +1194,11 @@ extern "C++" int wlk_step_select(wlk_session* s, int64_t token, const int32_t* a
         s->last_rows = 1;
         s->last_ntok = 1;
 
-        // the last kernel stores the two flags after the fields; spin on them, and look at the stream now and then so
-        // that a failed launch cannot hang the caller
+        // the last kernel stores the two flags after the fields
         volatile StepResult* r = s->result_host;
         const auto t_start = std::chrono::steady_clock::now();
         if (timing) s->step_launch_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_start - t_enter).count();
-        for (unsigned spins = 0;; ++spins) {
-            const unsigned f1 = __atomic_load_n(&s->result_host->flag_topk, __ATOMIC_ACQUIRE);
-            const unsigned f2 = __atomic_load_n(&s->result_host->flag_align, __ATOMIC_ACQUIRE);
-            if (f1 == seq && f2 == seq) break;
-            if ((spins & 0x3ff) == 0x3ff) {
-                const hipError_t q = hipStreamQuery(s->stream);
-                if (q == hipSuccess) {
-                    if (__atomic_load_n(&s->result_host->flag_topk, __ATOMIC_ACQUIRE) == seq &&
-                        __atomic_load_n(&s->result_host->flag_align, __ATOMIC_ACQUIRE) == seq)
-                        break;
-                    throw std::runtime_error("fused step: the graph finished without delivering its result");
-                }
-                if (q != hipErrorNotReady) WLK_HIP(q);
-                if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30))
-                    throw std::runtime_error("fused step: no result after 30 s");
-            }
-            __builtin_ia32_pause();
-        }
+        wlk_wait_step_flags(s->stream, s->result_host, 1, seq);
         if (timing) {
             s->step_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_enter).count();
             s->step_count += 1;

@@ -88,10 +88,24 @@ struct StepResult {
     unsigned flag_topk, flag_align;   // = StepBlock::seq once the fields above are visible to the host
     int pad;
 };
-struct StepHostOut {              // by-value kernel argument of the read-out kernels
-    StepResult* result = nullptr; // pinned; nullptr = device-only results
-    const StepBlock* block = nullptr;   // device copy (n_adj, seq)
+struct StepHostOut {              // by-value kernel argument of the read-out kernels of a graph-replayed step
+    StepResult* result = nullptr; // pinned, one entry per row; nullptr = device-only results
+    const int* n_adj = nullptr;   // device scalars of the step: number of logit adjustments (overrides the launch
+    const unsigned* seq = nullptr;   // argument when set), sequence number echoed in the result flags
 };
+// the same for a batched step of the engine (rows = sessions)
+constexpr int kEngineFusedAdj = 1024;
+struct EngineBlock {
+    int n_adj;
+    unsigned seq;
+    int pad[2];
+    StepRow rows[8];
+    int adj_row[kEngineFusedAdj];
+    int adj_ids[kEngineFusedAdj];
+    float adj_deltas[kEngineFusedAdj];
+};
+void launch_embed_rows_step(const LaunchCtx& ctx, const EngineBlock* host_block, EngineBlock* dev_block, const float* tok_emb,
+                            const float* pos_emb, float* x, int n_rows, int d);
 void launch_embed_step(const LaunchCtx& ctx, const StepBlock* host_block, StepBlock* dev_block, int* tokens_dev,
                        int* ring_row, int* beam_of_row, int* d_offset, const float* tok_emb, const float* pos_emb, float* x,
                        int d);

@@ -7,6 +7,8 @@
 // These are HBM/L2-bound byte movers (one pass over K and V per query row); the rules that
 // matter are coalescing (16 lanes x float4 = one 256-byte head row per load), wavefront
 // reductions for the softmax, and keeping scores in LDS.
+#include <cstddef>
+
 #include "common.h"
 
 namespace wlk {
@@ -86,6 +88,37 @@ void launch_embed_step(const LaunchCtx& ctx, const StepBlock* host_block, StepBl
     KernelScope ks(ctx, "dec_embed");
     hipLaunchKernelGGL(embed_step_kernel, dim3(1), dim3(256), 0, ctx.stream, host_block, dev_block, tokens_dev, ring_row,
                        beam_of_row, d_offset, tok_emb, pos_emb, x, d);
+    WLK_HIP(hipGetLastError());
+}
+
+// First kernel of a batched graph step: workgroup r embeds row r's token; together the workgroups copy the step's block
+// (row table, adjustment count, logit adjustments) from host-coherent memory into its device copy.
+__global__ __launch_bounds__(256) void embed_rows_step_kernel(const EngineBlock* __restrict__ host_block,
+                                                              EngineBlock* __restrict__ dev_block,
+                                                              const float* __restrict__ tok_emb,
+                                                              const float* __restrict__ pos_emb, float* __restrict__ x, int d) {
+    constexpr int kWords = sizeof(EngineBlock) / 4, kRowWords = sizeof(StepRow) / 4;
+    constexpr int kRow0 = offsetof(EngineBlock, rows) / 4;
+    __shared__ unsigned mine[kRowWords];
+    const int tid = threadIdx.x, row = blockIdx.x, n_blocks = gridDim.x;
+    const unsigned* src = reinterpret_cast<const unsigned*>(host_block);
+    unsigned* dst = reinterpret_cast<unsigned*>(dev_block);
+    if (tid < kRowWords) mine[tid] = __hip_atomic_load(src + kRow0 + row * kRowWords + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // the whole block in one round trip (12.5 KiB; every load is independent of the others)
+    for (int w = row * 256 + tid; w < kWords; w += n_blocks * 256)
+        dst[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    const StepRow* sr = reinterpret_cast<const StepRow*>(mine);
+    const float* e = tok_emb + (long)sr->token * d;
+    const float* pe = pos_emb + (long)sr->offset * d;
+    for (int c = tid; c < d; c += 256) x[(long)row * d + c] = e[c] + pe[c];
+}
+
+void launch_embed_rows_step(const LaunchCtx& ctx, const EngineBlock* host_block, EngineBlock* dev_block, const float* tok_emb,
+                            const float* pos_emb, float* x, int n_rows, int d) {
+    KernelScope ks(ctx, "dec_embed");
+    hipLaunchKernelGGL(embed_rows_step_kernel, dim3(n_rows), dim3(256), 0, ctx.stream, host_block, dev_block, tok_emb,
+                       pos_emb, x, d);
     WLK_HIP(hipGetLastError());
 }
 

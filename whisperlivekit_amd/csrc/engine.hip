@@ -53,7 +53,7 @@ struct wlk_engine {
     int max_rows = 1;
     hipStream_t stream = nullptr;
     // device workspace of one batched step
-    StepRow* rows_dev = nullptr;
+    StepRow* rows_dev = nullptr;   // = blk_dev->rows
     float *x = nullptr, *qkv = nullptr, *att = nullptr, *q = nullptr, *mlp = nullptr, *logits = nullptr, *xsplit = nullptr,
           *z = nullptr, *attn_last = nullptr;
     float* res_dev = nullptr;      // [top log-probs R*2 | top ids R*2 | frames R]
@@ -61,6 +61,13 @@ struct wlk_engine {
     int* adj_dev = nullptr;        // [rows n | ids n | deltas n]
     char* pinned = nullptr;
     static constexpr size_t kPinnedBytes = 256 * 1024;
+    // a batched step as ONE graph replay without copy nodes (as wlk_step_select does for one session): host-coherent
+    // block + results, their device-side addresses, the device copy of the block, one graph per row count
+    EngineBlock *blk_host = nullptr, *blk_host_dev = nullptr, *blk_dev = nullptr;
+    StepResult *res_host = nullptr, *res_host_dev = nullptr;
+    hipGraphExec_t fstep_exec[9] = {};
+    unsigned step_seq = 0;
+    bool fused_steps = true;
     hipGraphExec_t step_exec[9] = {};   // captured launch chain per row count (adjustment count is a device scalar)
     int* n_adj_dev = nullptr;
     bool use_graph = true;
@@ -88,17 +95,19 @@ struct wlk_engine {
     void run();
     void step_single(EngineJob* j, std::vector<EngineJob*>& finished);
     void step_batched(std::vector<EngineJob*>& group, std::vector<EngineJob*>& finished);
-    void enqueue_decoder(int R);            // embed .. logits of R rows (captured into a hipGraph per row count)
+    void enqueue_decoder(int R, bool from_block = false);   // embed .. logits of R rows (captured into a hipGraph per row count)
+    bool step_batched_one_replay(std::vector<EngineJob*>& group, std::vector<EngineJob*>& finished);
     void enqueue_select(int R, int n_adj);  // logit adjustments + log-softmax top-2 + AlignAtt read-out per row
 };
 
 // ---- one batched step ----------------------------------------------------------------------------------------
-void wlk_engine::enqueue_decoder(int R) {
+void wlk_engine::enqueue_decoder(int R, bool from_block) {
     const wlk_dims& D = m->D;
     const int d = D.n_text_state, T = D.n_audio_ctx, H = D.n_text_head, V = D.n_vocab, ctx_len = D.n_text_ctx;
     const LaunchCtx c{stream, nullptr};
     const float scale = std::pow((float)kHeadDim, -0.25f);
-    launch_embed_rows(c, rows_dev, m->w_tok_emb, m->w_dec_pos, x, R, d);
+    if (from_block) launch_embed_rows_step(c, blk_host_dev, blk_dev, m->w_tok_emb, m->w_dec_pos, x, R, d);
+    else launch_embed_rows(c, rows_dev, m->w_tok_emb, m->w_dec_pos, x, R, d);
     float* sc = xsplit;
     float* pm = sc + (size_t)8 * H * T;
     float* pl = pm + (size_t)8 * H * 8;
@@ -168,7 +177,106 @@ void wlk_engine::enqueue_select(int R, int n_adj) {
     else WLK_HIP(hipMemsetAsync(frames, 0, sizeof(int) * R, stream));
 }
 
+// The batched step as one graph replay: the first kernel pulls the row table and the logit adjustments out of the
+// host-coherent block, the last one writes every row's result and flags into host-coherent memory.  Returns false when
+// the step does not qualify (too many adjustments, no alignment heads, WLK_FUSED_STEP=0): the caller takes the chain
+// with copy nodes and an eager read-out.
+bool wlk_engine::step_batched_one_replay(std::vector<EngineJob*>& group, std::vector<EngineJob*>& finished) {
+    const wlk_dims& D = m->D;
+    const int R = (int)group.size();
+    const int T = D.n_audio_ctx, V = D.n_vocab, ctx_len = D.n_text_ctx;
+    if (!fused_steps || !use_graph || !blk_host) return false;
+    AlignArgs a{};
+    a.ring = nullptr; a.n_align = m->n_align; a.n_beam = R; a.ring_rows = ctx_len + kAlignWindow; a.T = T;
+    a.single_base = ctx_len;
+    a.z = z; a.attn_last = attn_last; a.frames = reinterpret_cast<int*>(res_dev) + 4 * max_rows;
+    a.rows = blk_dev->rows;
+    if (!select_fused_applicable(R, 2, a)) return false;
+    EngineBlock& b = *blk_host;
+    std::vector<int32_t> ids;
+    std::vector<float> deltas;
+    int n_adj = 0;
+    for (int r = 0; r < R; ++r) {   // adjustments first: an overflow must leave the sessions untouched
+        group[r]->job->adjustments(ids, deltas);
+        if (n_adj + (int)ids.size() > kEngineFusedAdj) return false;
+        for (size_t i = 0; i < ids.size(); ++i, ++n_adj) {
+            b.adj_row[n_adj] = r;
+            b.adj_ids[n_adj] = ids[i];
+            b.adj_deltas[n_adj] = deltas[i];
+        }
+    }
+    for (int r = 0; r < R; ++r) {
+        wlk_session* s = group[r]->s;
+        DecodeJob& job = *group[r]->job;
+        if (s->self_len + 1 > ctx_len) throw std::runtime_error("text context exceeded");
+        if (s->n_steps < 1) throw std::runtime_error("engine step before the prefill");
+        const int after = s->n_steps + 1;
+        StepRow& sr = b.rows[r];
+        sr.kcache = s->kcache[s->kv_cur];
+        sr.vcache = s->vcache[s->kv_cur];
+        sr.cross_kv = s->cross_kv;
+        sr.ring = s->ring;
+        sr.token = (int)job.seq.back();
+        if (sr.token < 0 || sr.token >= D.n_vocab) throw std::invalid_argument("token id out of range");
+        sr.offset = s->self_len;
+        sr.ring_row = ctx_len + ((s->n_steps - 1) % kAlignWindow);
+        sr.prefill_rows = after <= kAlignWindow ? s->prefill_rows : 0;
+        sr.n_single = std::min(after - 1, kAlignWindow);
+        sr.newest_row = ctx_len + ((after - 2) % kAlignWindow);
+        sr.content_len = std::min(job.P.content_mel_len, T);
+        sr.pad = 0;
+    }
+    b.n_adj = n_adj;
+    const unsigned seq = ++step_seq ? step_seq : ++step_seq;
+    b.seq = seq;
+    std::atomic_thread_fence(std::memory_order_release);
+    hipGraphExec_t& exec = fstep_exec[R];
+    if (!exec) {
+        const LaunchCtx c{stream, nullptr};
+        hipGraph_t graph = nullptr;
+        WLK_HIP(hipStreamSynchronize(stream));
+        WLK_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        try {
+            enqueue_decoder(R, true);
+            StepHostOut ho;
+            ho.result = res_host_dev;
+            ho.n_adj = &blk_dev->n_adj;
+            ho.seq = &blk_dev->seq;
+            float* top_vals = res_dev;
+            int* top_ids = reinterpret_cast<int*>(res_dev) + 2 * max_rows;
+            if (!launch_select_fused(c, logits, V, R, 2, top_vals, top_ids, topk_scratch, blk_dev->adj_row, blk_dev->adj_ids,
+                                     blk_dev->adj_deltas, 0, a, ho))
+                throw std::runtime_error("batched step: read-out not available");
+        } catch (...) {
+            (void)hipStreamEndCapture(stream, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
+            throw;
+        }
+        WLK_HIP(hipStreamEndCapture(stream, &graph));
+        WLK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+    }
+    WLK_HIP(hipGraphLaunch(exec, stream));
+    wlk_wait_step_flags(stream, res_host, R, seq);
+    n_batched += 1;
+    n_batched_rows += R;
+    for (int r = 0; r < R; ++r) {
+        wlk_session* s = group[r]->s;
+        s->self_len += 1;
+        s->n_steps += 1;
+        s->have_sot = false;
+        s->last_rows = 1;
+        s->last_ntok = 1;
+        const volatile StepResult& res = res_host[r];
+        const float lp[2] = {res.top_vals[0], res.top_vals[1]};
+        const int32_t top[2] = {res.top_ids[0], res.top_ids[1]};
+        if (!group[r]->job->consume(lp, top, res.frame)) finished.push_back(group[r]);
+    }
+    return true;
+}
+
 void wlk_engine::step_batched(std::vector<EngineJob*>& group, std::vector<EngineJob*>& finished) {
+    if (step_batched_one_replay(group, finished)) return;
     const wlk_dims& D = m->D;
     const int R = (int)group.size();
     const int T = D.n_audio_ctx, ctx_len = D.n_text_ctx;
@@ -403,7 +511,6 @@ static wlk_engine* engine_create(wlk_model* m) {
     if (const char* g = std::getenv("WLK_BATCH_ENCODE")) e->batch_encodes = !(g[0] == '0');
     if (const char* g = std::getenv("WLK_ENCODE_GATHER_US")) e->gather_us = std::max(0, std::atoi(g));
     const size_t R = 8, d = D.n_text_state, T = D.n_audio_ctx, V = D.n_vocab;
-    e->rows_dev = dev_alloc<StepRow>(R);
     e->x = dev_alloc<float>(R * d);
     e->qkv = dev_alloc<float>(R * 3 * d);
     e->att = dev_alloc<float>(R * d);
@@ -417,6 +524,21 @@ static wlk_engine* engine_create(wlk_model* m) {
     WLK_HIP(hipMalloc(&e->topk_scratch, topk_scratch_bytes((int)R)));
     e->adj_dev = dev_alloc<int>(3 * (size_t)kEngineAdjCap);
     WLK_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->pinned), wlk_engine::kPinnedBytes, hipHostMallocDefault));
+    {
+        static_assert(sizeof(EngineBlock) <= 16384, "results start 16 KiB into the host-coherent block");
+        void* hp = nullptr;
+        WLK_HIP(hipHostMalloc(&hp, 32768, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(hp, 0, 32768);
+        void* dp = nullptr;
+        WLK_HIP(hipHostGetDevicePointer(&dp, hp, 0));
+        e->blk_host = static_cast<EngineBlock*>(hp);
+        e->blk_host_dev = static_cast<EngineBlock*>(dp);
+        e->res_host = reinterpret_cast<StepResult*>(static_cast<char*>(hp) + 16384);
+        e->res_host_dev = reinterpret_cast<StepResult*>(static_cast<char*>(dp) + 16384);
+        e->blk_dev = reinterpret_cast<EngineBlock*>(dev_alloc<int>(sizeof(EngineBlock) / 4));
+        e->rows_dev = e->blk_dev->rows;   // the row table of either step form lives inside the block's device copy
+        if (const char* g = std::getenv("WLK_FUSED_STEP")) e->fused_steps = !(g[0] == '0');
+    }
     WLK_HIP(hipStreamSynchronize(e->stream));
     wlk_engine* raw = e.release();
     raw->worker = std::thread([raw] { raw->run(); });
@@ -443,10 +565,13 @@ void wlk_engine_destroy_for_model(wlk_model* m) {
     float* fl[] = {e->x, e->qkv, e->att, e->q, e->mlp, e->logits, e->xsplit, e->z, e->attn_last, e->res_dev};
     for (float* p : fl)
         if (p) (void)hipFree(p);
-    if (e->rows_dev) (void)hipFree(e->rows_dev);
     if (e->topk_scratch) (void)hipFree(e->topk_scratch);
     if (e->adj_dev) (void)hipFree(e->adj_dev);
     if (e->pinned) (void)hipHostFree(e->pinned);
+    if (e->blk_host) (void)hipHostFree(e->blk_host);
+    if (e->blk_dev) (void)hipFree(e->blk_dev);
+    for (auto& g : e->fstep_exec)
+        if (g) (void)hipGraphExecDestroy(g);
     for (auto& g : e->step_exec)
         if (g) (void)hipGraphExecDestroy(g);
     if (e->stream) (void)hipStreamDestroy(e->stream);

@@ -3,6 +3,7 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <chrono>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -220,6 +221,32 @@ struct wlk_session {
     wlk_engine* engine = nullptr;   // set by wlk_engine_attach: single-token steps run batched with the other attached sessions
 };
 
+
+// Wait for the result flags of a graph-replayed step (written by its last kernel into host-coherent memory): spin on
+// them, look at the stream every 1024 spins so that a failed launch cannot hang the caller, give up after 30 s.
+inline void wlk_wait_step_flags(hipStream_t stream, const wlk::StepResult* res, int n, unsigned seq) {
+    const auto t_start = std::chrono::steady_clock::now();
+    auto all_set = [&]() {
+        for (int i = 0; i < n; ++i)
+            if (__atomic_load_n(&res[i].flag_topk, __ATOMIC_ACQUIRE) != seq || __atomic_load_n(&res[i].flag_align, __ATOMIC_ACQUIRE) != seq)
+                return false;
+        return true;
+    };
+    for (unsigned spins = 0;; ++spins) {
+        if (all_set()) return;
+        if ((spins & 0x3ff) == 0x3ff) {
+            const hipError_t q = hipStreamQuery(stream);
+            if (q == hipSuccess) {
+                if (all_set()) return;
+                throw std::runtime_error("graph step: the replay finished without delivering its result");
+            }
+            if (q != hipErrorNotReady) WLK_HIP(q);
+            if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30))
+                throw std::runtime_error("graph step: no result after 30 s");
+        }
+        __builtin_ia32_pause();
+    }
+}
 
 // api.hip
 // One single-token step of a beam-1 session + its read-out (wlk_decode(first=0) followed by wlk_select(k=2)) as one

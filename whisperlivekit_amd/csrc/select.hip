@@ -174,13 +174,13 @@ __device__ __forceinline__ void topk_stage2_body(const SelPartial* __restrict__ 
         if (lane == 0) {
             top_ids[row * k + round] = wi;
             top_vals[row * k + round] = (wv - mx) - lse;
-            if (host.result && row == 0 && round < 2) {
-                host.result->top_ids[round] = wi;
-                host.result->top_vals[round] = (wv - mx) - lse;
+            if (host.result && round < 2) {
+                host.result[row].top_ids[round] = wi;
+                host.result[row].top_vals[round] = (wv - mx) - lse;
             }
         }
     }
-    if (host.result && lane == 0 && row == 0) publish_flag(&host.result->flag_topk, host.block->seq);
+    if (host.result && lane == 0) publish_flag(&host.result[row].flag_topk, *host.seq);
 }
 
 __global__ __launch_bounds__(64) void topk_stage2_kernel(const SelPartial* __restrict__ parts, int k,
@@ -406,9 +406,9 @@ __device__ __forceinline__ void align_argmax_lds_body(AlignArgs a, int b, const 
     if (tid == 0) {
         const int frame = besti[0] == 0x7fffffff ? 0 : besti[0];
         a.frames[b] = frame;
-        if (host.result && b == 0) {
-            host.result->frame = frame;
-            publish_flag(&host.result->flag_align, host.block->seq);
+        if (host.result) {
+            host.result[b].frame = frame;
+            publish_flag(&host.result[b].flag_align, *host.seq);
         }
     }
 }
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(1024) void align_argmax_lds_kernel(AlignArgs a) { a
 __global__ __launch_bounds__(256) void select_stage1_kernel(TopkArgs t, AlignArgs a, int zf_blocks) {
     const int n_topk = kSelBlocks * t.n_rows;
     if ((int)blockIdx.x < n_topk) {
-        const int n_adj = t.host.block ? t.host.block->n_adj : t.n_adj;
+        const int n_adj = t.host.n_adj ? *t.host.n_adj : t.n_adj;
         topk_stage1_body(t.logits, t.n_vocab, t.k, t.parts, t.adj_row, t.adj_ids, t.adj_deltas, n_adj,
                          blockIdx.x % kSelBlocks, blockIdx.x / kSelBlocks);
     } else {
