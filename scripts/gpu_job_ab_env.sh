@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 export WLK_SYNTHETIC_VOCAB=1
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-diarization --no-eight-streams"
 : > gpurun_out/ab_env.log
-for i in 1 2 3 4 5; do
+for i in 1 2 3; do
   echo "env" >> gpurun_out/ab_env.log; env $NEW_ENV timeout 300 $B 2>/dev/null | tail -1 >> gpurun_out/ab_env.log
   echo "base" >> gpurun_out/ab_env.log; timeout 300 $B 2>/dev/null | tail -1 >> gpurun_out/ab_env.log
 done
