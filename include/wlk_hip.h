@@ -291,6 +291,14 @@ const char* wlk_diag_last_error(void);
 int wlk_diag_linear(const float* a, int64_t lda, int64_t a_floats, const float* w, const float* bias,
                     const float* r, int64_t ldr, int m, int n, int k, int flags, float scale, int scale_cols,
                     int force_gemv, float* c);
+/* ---- word-timestamp alignment ------------------------------------------------------------------
+ * Dynamic time warping of a [n_rows tokens, n_cols frames] fp32 cost matrix on `device`: replaces `dtw_cpu`
+ * (whisperlivekit/whisper/timing.py:82-105; CUDA counterpart `dtw_cuda` :108-138) under `find_alignment` (:163-243).
+ * `trace` receives (n_rows + 1) x (n_cols + 1) step codes, row-major: 0 = diagonal, 1 = up (previous token), 2 = left
+ * (previous frame), -1 in row 0 / column 0 - the array dtw_cpu hands to `backtrace` (:58-79).  Same strict comparisons
+ * (ties go left) and one fp32 add per cell.  n_rows <= 1024.  Host pointers; synchronous. */
+int wlk_dtw(int device, const float* x, int32_t n_rows, int32_t n_cols, int8_t* trace);
+
 /* kernel-tuning probe: average microseconds per launch over `reps` back-to-back launches of one linear layer on
  * device-resident pseudo-random operands (same `force_gemv` meaning as wlk_diag_linear) */
 int wlk_diag_linear_time(int m, int n, int k, int flags, int force_gemv, int reps, float* us_per_launch);

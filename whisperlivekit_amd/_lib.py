@@ -130,6 +130,7 @@ def _declare(lib: C.CDLL) -> None:
         "wlk_diag_last_error": (C.c_char_p, []),
         "wlk_diag_linear": (cint, [p, C.c_int64, C.c_int64, p, p, p, C.c_int64, cint, cint, cint, cint, C.c_float,
                                    cint, cint, p]),
+        "wlk_dtw": (cint, [cint, C.POINTER(C.c_float), C.c_int32, C.c_int32, C.POINTER(C.c_int8)]),
         "wlk_diag_linear_time": (cint, [cint, cint, cint, cint, cint, cint, C.POINTER(C.c_float)]),
         "wlk_diag_linear_ln": (cint, [p, p, p, p, p, cint, cint, cint, cint, p]),
         "wlk_diag_layernorm": (cint, [p, p, p, cint, cint, p]),
@@ -158,6 +159,7 @@ EXPORTED_SYMBOLS = (
     "wlk_vad_weights_floats", "wlk_vad_tensor_lookup", "wlk_vad_tensor_name", "wlk_vad_create", "wlk_vad_destroy",
     "wlk_vad_stream_create", "wlk_vad_stream_reset", "wlk_vad_stream_run", "wlk_vad_stream_state",
     "wlk_vad_stream_destroy",
+    "wlk_dtw",
     "wlk_diag_last_error", "wlk_diag_linear", "wlk_diag_linear_time", "wlk_diag_linear_ln", "wlk_diag_layernorm",
     "wlk_diag_encoder_attention", "wlk_diag_encoder_attention_time",
 )
