@@ -11,8 +11,11 @@ from typing import Optional
 # (default 4).  With the sessions' prefill streams, the batch engine's step stream and its encode lane, fewer queues
 # measure faster on MI355X (8 streams: 2 queues +2.5-3.6 % over 4, 8 queues -4 %, 16 queues -8 %; one stream: no
 # difference) - GPU-filling encoder kernels from different streams slow each other down more than they overlap.  Only
-# a default: an exported value wins, and it has no effect once the HIP runtime is initialised in this process.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+# a default: an exported value wins, and it has no effect once the HIP runtime is initialised in this process.  Ranks of
+# a multi-process job (torchrun sets WORLD_SIZE) keep HIP's own default: RCCL shares the queues there, each GPU serves
+# fewer sessions, and that configuration could not be measured.
+if int(os.environ.get("WORLD_SIZE", "1") or 1) <= 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 _LIB_NAME = "libwlk_hip.so"
 _lock = threading.Lock()
