@@ -1,0 +1,76 @@
+"""Host half of the reference's word timestamps (whisper/timing.py:220-388) in whisperlivekit_amd/timing.py, against
+known answers produced by the reference's own find_alignment / merge_punctuations / add_word_timestamps
+(scripts/gen_golden_word_timing.py).  Also: the DTW oracle - and on the GPU the HIP kernel - on cost matrices that
+really came out of the reference's z-scored, median-filtered attention."""
+import copy
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import timing_oracle
+from whisperlivekit_amd import timing
+
+KAT = H.golden_json("word_timing_kat.json")
+
+
+def as_timings(rows):
+    return [timing.WordTiming(r["word"], list(r["tokens"]), r["start"], r["end"], r["probability"]) for r in rows]
+
+
+def as_rows(alignment):
+    return [dict(word=t.word, tokens=[int(x) for x in t.tokens], start=float(t.start), end=float(t.end),
+                 probability=float(t.probability)) for t in alignment]
+
+
+@pytest.mark.parametrize("case", KAT["find_alignment"], ids=lambda c: c["text"].strip()[:12])
+def test_word_timings_from_the_reference_path(case):
+    got = timing.word_timings(case["path"][0], case["path"][1], case["words"], case["word_tokens"],
+                              case["text_token_probs"])
+    want = case["timings"]
+    assert [t.word for t in got] == [w["word"] for w in want]
+    assert [t.tokens for t in got] == [w["tokens"] for w in want]
+    np.testing.assert_array_equal([t.start for t in got], [w["start"] for w in want])
+    np.testing.assert_array_equal([t.end for t in got], [w["end"] for w in want])
+    # the probabilities were recomputed by a second forward pass of the generator: equal up to that pass's rounding
+    np.testing.assert_allclose([t.probability for t in got], [w["probability"] for w in want], rtol=1e-5, atol=1e-9)
+
+
+def test_word_timings_of_eot_only():
+    assert timing.word_timings([0], [0], ["<eot>"], [[50256]], []) == []
+
+
+@pytest.mark.parametrize("case", KAT["find_alignment"], ids=lambda c: c["text"].strip()[:12])
+def test_dtw_oracle_on_reference_attention(case):
+    x = np.array(case["matrix"], dtype=np.float32).reshape(case["matrix_shape"])
+    np.testing.assert_array_equal(timing_oracle.dtw(x), np.array(case["path"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", KAT["find_alignment"], ids=lambda c: c["text"].strip()[:12])
+def test_hip_dtw_on_reference_attention(case):
+    x = np.array(case["matrix"], dtype=np.float32).reshape(case["matrix_shape"])
+    np.testing.assert_array_equal(timing.dtw(x), np.array(case["path"]))
+
+
+@pytest.mark.parametrize("i", range(len(KAT["merge"])))
+def test_merge_punctuations(i):
+    case = KAT["merge"][i]
+    alignment = as_timings(case["before"])
+    timing.merge_punctuations(alignment)
+    assert as_rows(alignment) == case["after"]
+
+
+@pytest.mark.parametrize("i", range(len(KAT["attach"])))
+def test_attach_words(i):
+    case = KAT["attach"][i]
+    before = case["before"]
+    segments = copy.deepcopy(before["segments"])
+    per_segment = [[t for t in s["tokens"] if t < case["eot"]] for s in segments]
+    timing.attach_words(segments, as_timings(before["alignment"]), per_segment,
+                        last_speech_timestamp=before["last_speech_timestamp"])
+    assert segments == case["after"]
+
+
+def test_attach_words_without_segments():
+    timing.attach_words([], [], [], last_speech_timestamp=0.0)

@@ -55,3 +55,126 @@ def dtw(x, device: int = 0) -> np.ndarray:
     if hasattr(x, "detach"):
         x = x.detach().cpu().numpy()
     return backtrace(dtw_trace(np.asarray(x), device))
+
+
+# ---- from a warping path to words (host logic of find_alignment / add_word_timestamps) ---------------------------------
+# Everything below is integer / float bookkeeping on a few hundred words per window; it stays in Python next to the
+# reference's own.  Pinned by tests/golden/word_timing_kat.json (scripts/gen_golden_word_timing.py runs the reference).
+from dataclasses import dataclass, field  # noqa: E402
+from typing import List, Sequence  # noqa: E402
+
+TOKENS_PER_SECOND = 50            # whisper/audio.py: 20 ms per encoder position
+HOP_LENGTH, SAMPLE_RATE = 160, 16000
+SENTENCE_END_MARKS = ".。!！?？"
+PREPEND_PUNCTUATIONS = "\"'“¿([{-"
+APPEND_PUNCTUATIONS = "\"'.。,，!！?？:：”)]}、"
+
+
+@dataclass
+class WordTiming:
+    """timing.py:155-161 (same field names: the segments built from it are read by the reference's callers)."""
+    word: str
+    tokens: List[int] = field(default_factory=list)
+    start: float = 0.0
+    end: float = 0.0
+    probability: float = 0.0
+
+
+def word_timings(text_indices, time_indices, words: Sequence[str], word_tokens: Sequence[Sequence[int]],
+                 text_token_probs: Sequence[float]) -> List[WordTiming]:
+    """The tail of find_alignment (timing.py:220-243): the frame at which the path first enters a token is that
+    token's start; a word runs from its first token's start to the next word's first token's start.
+
+    ``words`` / ``word_tokens`` come from ``tokenizer.split_to_word_tokens(text_tokens + [eot])`` (the last entry is
+    the eot pseudo-word and only closes the last real word)."""
+    if len(word_tokens) <= 1:
+        return []
+    text_indices = np.asarray(text_indices)
+    time_indices = np.asarray(time_indices)
+    first_of_token = np.ones(len(text_indices), dtype=bool)
+    first_of_token[1:] = text_indices[1:] != text_indices[:-1]
+    token_start = time_indices[first_of_token] / TOKENS_PER_SECOND
+    bounds = np.concatenate([[0], np.cumsum([len(t) for t in word_tokens[:-1]])]).astype(np.int64)
+    out = []
+    for w, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+        out.append(WordTiming(words[w], list(word_tokens[w]), token_start[lo], token_start[hi],
+                              np.mean(text_token_probs[lo:hi])))
+    return out
+
+
+def merge_punctuations(alignment: List[WordTiming], prepended: str = PREPEND_PUNCTUATIONS,
+                       appended: str = APPEND_PUNCTUATIONS) -> None:
+    """timing.py:245-276, in place: opening punctuation joins the word after it (scanning backwards, so runs chain),
+    closing punctuation joins the word before it; emptied entries stay in the list with word == ""."""
+    target = len(alignment) - 1
+    for i in range(len(alignment) - 2, -1, -1):
+        cur, nxt = alignment[i], alignment[target]
+        if cur.word.startswith(" ") and cur.word.strip() in prepended:
+            nxt.word, nxt.tokens = cur.word + nxt.word, cur.tokens + nxt.tokens
+            cur.word, cur.tokens = "", []
+        else:
+            target = i
+    target = 0
+    for j in range(1, len(alignment)):
+        prv, cur = alignment[target], alignment[j]
+        if not prv.word.endswith(" ") and cur.word in appended:
+            prv.word, prv.tokens = prv.word + cur.word, prv.tokens + cur.tokens
+            cur.word, cur.tokens = "", []
+        else:
+            target = j
+
+
+def attach_words(segments: List[dict], alignment: List[WordTiming], text_tokens_per_segment: Sequence[Sequence[int]], *,
+                 last_speech_timestamp: float, prepend_punctuations: str = PREPEND_PUNCTUATIONS,
+                 append_punctuations: str = APPEND_PUNCTUATIONS) -> None:
+    """add_word_timestamps after its find_alignment call (timing.py:295-388): clamp implausibly long words around
+    sentence ends, merge punctuation, deal the words out to the segments by token count, reconcile word and segment
+    boundaries.  Mutates ``alignment`` and ``segments`` (adds "words", may move "start" / "end")."""
+    if not segments:
+        return
+    durations = np.array([t.end - t.start for t in alignment])
+    durations = durations[durations.nonzero()]
+    median_duration = min(0.7, float(np.median(durations))) if len(durations) else 0.0
+    max_duration = median_duration * 2
+    if len(durations):
+        for prev, cur in zip(alignment[:-1], alignment[1:]):
+            if cur.end - cur.start > max_duration:
+                if cur.word in SENTENCE_END_MARKS:
+                    cur.end = cur.start + max_duration
+                elif prev.word in SENTENCE_END_MARKS:
+                    cur.start = cur.end - max_duration
+    merge_punctuations(alignment, prepend_punctuations, append_punctuations)
+
+    offset = segments[0]["seek"] * HOP_LENGTH / SAMPLE_RATE      # same operation order as the reference (rounding)
+    cursor = 0
+    for segment, seg_tokens in zip(segments, text_tokens_per_segment):
+        taken, words = 0, []
+        while cursor < len(alignment) and taken < len(seg_tokens):
+            t = alignment[cursor]
+            if t.word:
+                words.append(dict(word=t.word, start=round(offset + t.start, 2), end=round(offset + t.end, 2),
+                                  probability=t.probability))
+            taken += len(t.tokens)
+            cursor += 1
+        if words:
+            first, last = words[0], words[-1]
+            # the first (and second) word after a pause must not be longer than twice the median word
+            after_pause = first["end"] - last_speech_timestamp > median_duration * 4
+            too_long = first["end"] - first["start"] > max_duration or (
+                len(words) > 1 and words[1]["end"] - first["start"] > max_duration * 2)
+            if after_pause and too_long:
+                if len(words) > 1 and words[1]["end"] - words[1]["start"] > max_duration:
+                    boundary = max(words[1]["end"] / 2, words[1]["end"] - max_duration)
+                    first["end"] = words[1]["start"] = boundary
+                first["start"] = max(0, first["end"] - max_duration)
+            # prefer the segment-level timestamps where the outer words are too long
+            if segment["start"] < first["end"] and segment["start"] - 0.5 > first["start"]:
+                first["start"] = max(0, min(first["end"] - median_duration, segment["start"]))
+            else:
+                segment["start"] = first["start"]
+            if segment["end"] > last["start"] and segment["end"] + 0.5 < last["end"]:
+                last["end"] = max(last["start"] + median_duration, segment["end"])
+            else:
+                segment["end"] = last["end"]
+            last_speech_timestamp = segment["end"]
+        segment["words"] = words
