@@ -47,3 +47,30 @@ def backtrace(trace: np.ndarray) -> np.ndarray:
 
 def dtw(x: np.ndarray) -> np.ndarray:
     return backtrace(dtw_trace(x))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# find_alignment's arithmetic (whisperlivekit/whisper/timing.py:176-218): one decoder pass over
+# [sot sequence, <|notimestamps|>, text tokens, <|endoftext|>], the cross-attention scores of the alignment heads,
+# softmax over the first num_frames // 2 encoder positions, z-score over the TOKEN axis (no epsilon here, unlike the
+# streaming policy), median filter of width 7 along the frames, mean over the heads, the rows of the text tokens.
+# Pinned by the matrices the reference's find_alignment handed to dtw (tests/golden/word_timing_kat.json.gz).
+# ---------------------------------------------------------------------------------------------------------------
+def alignment_cost(sd, dims, align_heads, mel, sot_sequence, no_timestamps, text_tokens, eot, num_frames,
+                   medfilt_width: int = 7, qk_scale: float = 1.0):
+    """-> (cost matrix [len(text_tokens) + 1, num_frames // 2] as handed to dtw, per-token probabilities)."""
+    import torch
+
+    from . import whisper_oracle as wo
+    tokens = torch.tensor([[*sot_sequence, no_timestamps, *text_tokens, eot]], dtype=torch.int64)
+    with torch.no_grad():
+        xa = wo.encoder_forward(sd, dims, mel.unsqueeze(0) if mel.dim() == 2 else mel)
+        logits, qks = wo.decoder_forward(sd, dims, tokens, xa, wo.DecoderCache(dims.n_text_layer))
+        sampled = logits[0, len(sot_sequence):, :eot]
+        probs = sampled.softmax(dim=-1)[np.arange(len(text_tokens)), list(text_tokens)].tolist()
+        w = torch.stack([qks[l][0, h] for l, h in align_heads])              # heads x tokens x frames
+        w = (w[:, :, : num_frames // 2] * qk_scale).softmax(dim=-1)
+        std, mean = torch.std_mean(w, dim=-2, keepdim=True, unbiased=False)
+        w = wo.median_filter((w - mean) / std, medfilt_width)
+        matrix = w.mean(dim=0)[len(sot_sequence): -1]
+    return (-matrix).numpy().astype(np.float32), probs

@@ -52,25 +52,15 @@ def main():
     ref_stubs.install(synthetic_vocab=False)
     import torch
     from whisperlivekit.whisper import timing as T
-    from whisperlivekit.whisper.model import ModelDimensions, Whisper
     from whisperlivekit.whisper.tokenizer import get_tokenizer
-    from whisperlivekit_amd.dims import ALIGNMENT_HEADS, MODEL_DIMS
 
     out = {"find_alignment": [], "merge": [], "attach": []}
     rng = np.random.default_rng(0)
 
-    # ---- find_alignment on a seeded micro model -------------------------------------------------------------------
-    torch.manual_seed(0)
-    d = MODEL_DIMS["micro.en"]
-    dims = ModelDimensions(n_mels=d.n_mels, n_audio_ctx=d.n_audio_ctx, n_audio_state=d.n_audio_state,
-                           n_audio_head=d.n_audio_head, n_audio_layer=d.n_audio_layer, n_vocab=d.n_vocab,
-                           n_text_ctx=d.n_text_ctx, n_text_state=d.n_text_state, n_text_head=d.n_text_head,
-                           n_text_layer=d.n_text_layer)
-    model = Whisper(dims).eval()
-    heads = torch.zeros(dims.n_text_layer, dims.n_text_head, dtype=torch.bool)
-    for l, h in ALIGNMENT_HEADS["micro.en"]:
-        heads[l, h] = True
-    model.register_buffer("alignment_heads", heads.to_sparse(), persistent=False)
+    # ---- find_alignment on the seeded micro model of the other goldens (synth weights in the reference's Whisper) ----
+    import gen_golden
+    model = gen_golden.build_reference_model("micro.en", 0)
+    dims = model.dims
     tokenizer = get_tokenizer(False, language="en", task="transcribe")
     texts = [" Hello, world! This is a test.", " (well) \"quoted\" - text: done", " naïve café — 你好。", " one"]
     captured = {}
@@ -84,9 +74,9 @@ def main():
     T.dtw = spy
     for i, text in enumerate(texts):
         text_tokens = tokenizer.encode(text)
-        mel = torch.from_numpy(rng.standard_normal((dims.n_mels, 3000)).astype(np.float32))
-        num_frames = int(rng.integers(400, 3000))
-        torch.manual_seed(i)
+        case_rng = np.random.default_rng(100 + i)      # tests rebuild the mel from this seed
+        mel = torch.from_numpy(case_rng.standard_normal((dims.n_mels, 3000)).astype(np.float32))
+        num_frames = int(case_rng.integers(400, 3000))
         # the tail of find_alignment consumes text_token_probs: capture them through the returned probabilities
         got = T.find_alignment(model, tokenizer, text_tokens, mel, num_frames)
         words, word_tokens = tokenizer.split_to_word_tokens(text_tokens + [tokenizer.eot])
@@ -97,7 +87,9 @@ def main():
         probs = logits[len(tokenizer.sot_sequence):, : tokenizer.eot].softmax(dim=-1)
         token_probs = probs[np.arange(len(text_tokens)), text_tokens].tolist()
         out["find_alignment"].append(dict(
-            text=text, text_tokens=[int(t) for t in text_tokens], num_frames=num_frames,
+            text=text, text_tokens=[int(t) for t in text_tokens], num_frames=num_frames, mel_seed=100 + i,
+            sot_sequence=[int(t) for t in tokenizer.sot_sequence], no_timestamps=int(tokenizer.no_timestamps),
+            eot=int(tokenizer.eot),
             matrix_shape=list(captured["matrix"].shape),
             matrix=[float(v) for v in captured["matrix"].ravel()],
             path=captured["path"].tolist(), words=list(words), word_tokens=[[int(t) for t in w] for w in word_tokens],

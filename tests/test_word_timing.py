@@ -74,3 +74,25 @@ def test_attach_words(i):
 
 def test_attach_words_without_segments():
     timing.attach_words([], [], [], last_speech_timestamp=0.0)
+
+
+@pytest.mark.parametrize("case", KAT["find_alignment"], ids=lambda c: c["text"].strip()[:12])
+def test_oracle_alignment_cost_matches_reference(case):
+    """The arithmetic in front of the DTW (decoder pass, softmax over the content frames, z-score over tokens, median
+    filter, head mean) restated on the oracle's encoder / decoder: the matrix the reference handed to dtw, and from it
+    the same path and the same words."""
+    import torch
+    from whisperlivekit_amd.dims import ALIGNMENT_HEADS, MODEL_DIMS
+    dims = MODEL_DIMS["micro.en"]
+    sd = H.oracle_sd("micro.en", 0)
+    mel = torch.from_numpy(np.random.default_rng(case["mel_seed"]).standard_normal((dims.n_mels, 3000)).astype(np.float32))
+    cost, probs = timing_oracle.alignment_cost(sd, dims, ALIGNMENT_HEADS["micro.en"], mel, case["sot_sequence"],
+                                               case["no_timestamps"], case["text_tokens"], case["eot"], case["num_frames"])
+    want = np.array(case["matrix"], dtype=np.float32).reshape(case["matrix_shape"])
+    assert cost.shape == want.shape
+    np.testing.assert_allclose(cost, want, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(probs, case["text_token_probs"], rtol=1e-5, atol=1e-9)
+    path = timing_oracle.dtw(cost)
+    np.testing.assert_array_equal(path, np.array(case["path"]))
+    got = timing.word_timings(path[0], path[1], case["words"], case["word_tokens"], probs)
+    assert [(t.word, t.start, t.end) for t in got] == [(w["word"], w["start"], w["end"]) for w in case["timings"]]
