@@ -302,7 +302,7 @@ def gen_cif():
 
 def slow_case(k):
     """Long-running cases are regenerated only when named in GOLDEN_ONLY (they take minutes of CPU)."""
-    return k.startswith("bench_base_30s") or k.startswith("large_v3")
+    return k.startswith("bench_") or k.startswith("large_v3")
 
 
 def dump_stream(k, v):
@@ -358,6 +358,8 @@ def gen_streams():
             lambda seed=seed: run_stream("base.en", synth.to_pcm16_roundtrip(synth.speech_like(30.0, seed))))
     # config 3 at FULL depth (32 + 32 layers, 1280 wide, 128 mels, multilingual vocabulary): 2 s in 4 calls
     table["large_v3_2s"] = lambda: run_stream("large-v3", synth.to_pcm16_roundtrip(synth.speech_like(2.0, 5)))
+    # config 3 as bench.py times it (`--model large-v3 --seconds 10`): seed 0, 20 x 0.5 s (tens of minutes of CPU)
+    table["bench_large-v3_10s_s0"] = lambda: run_stream("large-v3", synth.to_pcm16_roundtrip(synth.speech_like(10.0, 0)))
     if REAL_VOCAB:
         # a17 with the REAL vocabulary: word splitting / pending UTF-8 / prompt encoding on real GPT-2 byte sequences.
         #   GOLDEN_REAL_VOCAB=1 python scripts/gen_golden.py streams

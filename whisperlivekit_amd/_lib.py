@@ -7,15 +7,8 @@ import os
 import threading
 from typing import Optional
 
-# Serving many sessions from one process: HIP maps the process's streams onto GPU_MAX_HW_QUEUES hardware queues
-# (default 4).  With the sessions' prefill streams, the batch engine's step stream and its encode lane, fewer queues
-# measure faster on MI355X (8 streams: 2 queues +2.5-3.6 % over 4, 8 queues -4 %, 16 queues -8 %; one stream: no
-# difference) - GPU-filling encoder kernels from different streams slow each other down more than they overlap.  Only
-# a default: an exported value wins, and it has no effect once the HIP runtime is initialised in this process.  Ranks of
-# a multi-process job (torchrun sets WORLD_SIZE) keep HIP's own default: RCCL shares the queues there, each GPU serves
-# fewer sessions, and that configuration could not be measured.
-if int(os.environ.get("WORLD_SIZE", "1") or 1) <= 1:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+# Importing this module changes nothing in the process environment (the host process may run other HIP users - torch
+# diarization, translation models - whose runtime settings are not this backend's to retune).
 
 _LIB_NAME = "libwlk_hip.so"
 _lock = threading.Lock()
@@ -55,6 +48,25 @@ class LoopResult(C.Structure):
 
 
 STOP_NONE, STOP_CONTEXT_FULL, STOP_BUDGET, STOP_NO_SPEECH, STOP_COMPLETED, STOP_REWIND, STOP_FRAME = range(7)
+
+
+def configure_hw_queues(n: int) -> bool:
+    """Deployment knob, never applied implicitly: map the process's HIP streams onto ``n`` hardware queues
+    (GPU_MAX_HW_QUEUES; HIP's default is 4).  Serving 8 sessions of one GPU from one process measured 2 queues +2.5-3.6 %
+    over 4, 8 queues -4 %, 16 queues -8 % (one session: no difference): GPU-filling encoder kernels of different streams
+    slow each other down more than they overlap.  The HIP runtime reads the variable once, when it initialises, and it
+    applies to EVERY HIP user of the process - so this must be called by the process owner before anything touches HIP
+    (`HipSimulStreamingASR(hw_queues=2)` forwards here; `bench.py` exports the variable itself for its single-process
+    runs).  An exported value wins.  Returns True when the value was set by this call."""
+    if n < 1:
+        raise ValueError("hw_queues must be >= 1")
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        return False
+    if _lib is not None:
+        raise WlkError("configure_hw_queues: the HIP library is already loaded in this process - export "
+                       "GPU_MAX_HW_QUEUES before start-up instead")
+    os.environ["GPU_MAX_HW_QUEUES"] = str(int(n))
+    return True
 
 
 def lib_path() -> str:

@@ -66,7 +66,11 @@ class HipSimulStreamingASR:
     def __init__(self, model_size: str = "base.en", *, device: int = 0, model_path: Optional[str] = None,
                  state_dict=None, dims: Optional[ModelDims] = None, alignment_heads=None,
                  synthetic_seed: Optional[int] = None, hip_model: Optional[HipWhisperModel] = None,
-                 custom_alignment_heads: Optional[Sequence[Tuple[int, int]]] = None, **cfg_kwargs):
+                 custom_alignment_heads: Optional[Sequence[Tuple[int, int]]] = None,
+                 hw_queues: Optional[int] = None, **cfg_kwargs):
+        if hw_queues is not None:     # explicit deployment knob (process-wide, see _lib.configure_hw_queues); default: off
+            from . import _lib
+            _lib.configure_hw_queues(hw_queues)
         self.model_name = model_size
         self.cfg = build_config(model_size, **cfg_kwargs)
         self.tokenizer = None

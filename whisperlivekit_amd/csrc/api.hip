@@ -628,6 +628,17 @@ static void transformer_mlp(const LaunchCtx& c, const LayerW& L, float* x, float
 // One encode of every session of `group` (1..kMaxBatch sessions of one model) as ONE launch chain: the log-mel of each
 // session (its own kernels: the frame counts differ), then every encoder operator once with grid.y = sessions - shared
 // weights, per-session activation buffers through pointer tables.  A group of one is the plain per-session encode.
+extern "C++" std::string wlk_encode_precheck(const wlk_session* s, const wlk_model* m) {
+    if (!s) return "encode: session is NULL";
+    if (s->m != m) return "encode: the session belongs to another model";
+    const int N = s->audio_len;
+    const int n_total = (N + kPadSamples) / kHop;
+    int n_active = N > 0 ? (N + kNFft / 2 + kHop - 1) / kHop : 0;
+    if (n_active > n_total) n_active = n_total;
+    if (n_active > s->frame_cap) return "audio longer than the session's frame capacity";
+    return std::string();
+}
+
 extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const LaunchCtx& c,
                                    std::vector<int>& content_out) {
     const int B = (int)group.size();
@@ -1188,17 +1199,27 @@ extern "C++" int wlk_step_select(wlk_session* s, int64_t token, const int32_t* a
             (void)hipGraphDestroy(graph);
         }
         WLK_HIP(hipGraphLaunch(exec, s->stream));
-        s->have_sot = false;
-        s->self_len += 1;
-        s->n_steps += 1;
-        s->last_rows = 1;
-        s->last_ntok = 1;
 
         // the last kernel stores the two flags after the fields
         volatile StepResult* r = s->result_host;
         const auto t_start = std::chrono::steady_clock::now();
         if (timing) s->step_launch_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_start - t_enter).count();
-        wlk_wait_step_flags(s->stream, s->result_host, 1, seq);
+        try {
+            wlk_wait_step_flags(s->stream, s->result_host, 1, seq);
+        } catch (...) {
+            // no result: whatever the replay did to the caches is unknown, so the session must be re-encoded (and
+            // re-prefilled) before it decodes again - never continue at a guessed cache offset
+            s->encoded = false;
+            s->n_steps = 0;
+            s->self_len = 0;
+            throw;
+        }
+        // the step is in the caches and its result is here: only now does the bookkeeping advance
+        s->have_sot = false;
+        s->self_len += 1;
+        s->n_steps += 1;
+        s->last_rows = 1;
+        s->last_ntok = 1;
         if (timing) {
             s->step_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_enter).count();
             s->step_count += 1;

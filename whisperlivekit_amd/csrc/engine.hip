@@ -88,9 +88,9 @@ struct wlk_engine {
     std::deque<EncodeReq*> enc_submitted;
     bool batch_encodes = true;
     int gather_us = 0;
-    uint64_t n_enc_batches = 0, n_enc_sessions = 0;
+    std::atomic<uint64_t> n_enc_batches{0}, n_enc_sessions{0};   // written by the lane workers, read by the stats calls
     void run_encodes(int lane);
-    uint64_t n_iterations = 0, n_rows = 0, n_batched = 0, n_batched_rows = 0;
+    std::atomic<uint64_t> n_iterations{0}, n_rows{0}, n_batched{0}, n_batched_rows{0};
 
     void run();
     void step_single(EngineJob* j, std::vector<EngineJob*>& finished);
@@ -401,8 +401,24 @@ void wlk_engine::run() {
         for (size_t lo = 0; lo < active.size(); lo += (size_t)max_rows) {
             std::vector<EngineJob*> group;
             for (size_t i = lo; i < std::min(active.size(), lo + (size_t)max_rows); ++i) {
-                if (active[i]->job->begin_step()) group.push_back(active[i]);
-                else finished.push_back(active[i]);        // text context full / token budget spent
+                EngineJob* j = active[i];
+                if (!j->job->begin_step()) {
+                    finished.push_back(j);        // text context full / token budget spent
+                    continue;
+                }
+                // host-side preconditions of a step are checked per session BEFORE anything is launched, so a session
+                // in a bad state fails alone instead of taking the rows batched with it down
+                const char* why = nullptr;
+                if (j->s->self_len + 1 > m->D.n_text_ctx) why = "text context exceeded";
+                else if (j->s->n_steps < 1) why = "engine step before the prefill";
+                else if (j->job->seq.empty() || j->job->seq.back() < 0 || j->job->seq.back() >= m->D.n_vocab) why = "token id out of range";
+                if (why) {
+                    j->rc = WLK_ERR_STATE;
+                    j->err = why;
+                    finished.push_back(j);
+                    continue;
+                }
+                group.push_back(j);
             }
             try {
                 if (group.size() == 1) step_single(group[0], finished);
@@ -454,31 +470,51 @@ void wlk_engine::run_encodes(int lane) {
                 enc_submitted.pop_front();
             }
         }
-        int rc = WLK_OK;
-        std::string err;
-        try {
-            std::vector<wlk_session*> group;
-            for (EncodeReq* r : batch) group.push_back(r->s);
-            std::vector<int> content;
-            wlk_encode_group(group, LaunchCtx{enc_stream, nullptr}, content);
-            WLK_HIP(hipStreamSynchronize(enc_stream));
-            for (size_t i = 0; i < batch.size(); ++i) batch[i]->content = content[i];
-        } catch (const std::length_error& e) {
-            rc = WLK_ERR_CAPACITY;
-            err = e.what();
-        } catch (const std::exception& e) {
-            rc = dynamic_cast<const HipError*>(&e) ? WLK_ERR_HIP : WLK_ERR_STATE;
-            err = e.what();
+        // requests that cannot be encoded (audio past the session's frame capacity, a session of another model) are
+        // answered on their own before anything is launched: one misbehaving stream must not fail the others of its batch
+        std::vector<EncodeReq*> good;
+        for (EncodeReq* r : batch) {
+            const std::string why = wlk_encode_precheck(r->s, m);
+            if (why.empty()) {
+                good.push_back(r);
+            } else {
+                r->rc = WLK_ERR_CAPACITY;
+                r->err = why;
+            }
         }
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            n_enc_batches += 1;
-            n_enc_sessions += batch.size();
-            for (EncodeReq* r : batch) {
+        auto encode = [&](const std::vector<EncodeReq*>& reqs) {     // -> status shared by `reqs`
+            int rc = WLK_OK;
+            std::string err;
+            try {
+                std::vector<wlk_session*> group;
+                for (EncodeReq* r : reqs) group.push_back(r->s);
+                std::vector<int> content;
+                wlk_encode_group(group, LaunchCtx{enc_stream, nullptr}, content);
+                WLK_HIP(hipStreamSynchronize(enc_stream));
+                for (size_t i = 0; i < reqs.size(); ++i) reqs[i]->content = content[i];
+            } catch (const std::length_error& e) {
+                rc = WLK_ERR_CAPACITY;
+                err = e.what();
+            } catch (const std::exception& e) {
+                rc = dynamic_cast<const HipError*>(&e) ? WLK_ERR_HIP : WLK_ERR_STATE;
+                err = e.what();
+            }
+            for (EncodeReq* r : reqs) {
                 r->rc = rc;
                 r->err = err;
-                r->done = true;
             }
+            return rc;
+        };
+        if (!good.empty() && encode(good) != WLK_OK && good.size() > 1) {
+            // the stacked chain failed as a whole: once more, one session at a time, so that only the session(s) that
+            // actually fail report an error (a sticky HIP error fails them all again - nothing is lost by trying)
+            for (EncodeReq* r : good) encode({r});
+        }
+        n_enc_batches.fetch_add(1, std::memory_order_relaxed);
+        n_enc_sessions.fetch_add(good.size(), std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (EncodeReq* r : batch) r->done = true;
         }
         cv_enc_done.notify_all();
     }
@@ -672,8 +708,8 @@ int wlk_engine_detach(wlk_session* s) {
 int wlk_engine_encode_stats(wlk_model* m, uint64_t* batches, uint64_t* sessions) {
     if (!m) return fail(WLK_ERR_ARG, "model is NULL");
     std::lock_guard<std::mutex> lk(m->engine_mu);
-    if (batches) *batches = m->engine ? m->engine->n_enc_batches : 0;
-    if (sessions) *sessions = m->engine ? m->engine->n_enc_sessions : 0;
+    if (batches) *batches = m->engine ? m->engine->n_enc_batches.load(std::memory_order_relaxed) : 0;
+    if (sessions) *sessions = m->engine ? m->engine->n_enc_sessions.load(std::memory_order_relaxed) : 0;
     return WLK_OK;
 }
 
@@ -681,10 +717,10 @@ int wlk_engine_stats(wlk_model* m, uint64_t* iterations, uint64_t* rows, uint64_
     if (!m) return fail(WLK_ERR_ARG, "model is NULL");
     std::lock_guard<std::mutex> lk(m->engine_mu);
     wlk_engine* e = m->engine;
-    if (iterations) *iterations = e ? e->n_iterations : 0;
-    if (rows) *rows = e ? e->n_rows : 0;
-    if (batched_steps) *batched_steps = e ? e->n_batched : 0;
-    if (batched_rows) *batched_rows = e ? e->n_batched_rows : 0;
+    if (iterations) *iterations = e ? e->n_iterations.load(std::memory_order_relaxed) : 0;
+    if (rows) *rows = e ? e->n_rows.load(std::memory_order_relaxed) : 0;
+    if (batched_steps) *batched_steps = e ? e->n_batched.load(std::memory_order_relaxed) : 0;
+    if (batched_rows) *batched_rows = e ? e->n_batched_rows.load(std::memory_order_relaxed) : 0;
     return WLK_OK;
 }
 

@@ -4,6 +4,8 @@
 #include <map>
 #include <memory>
 #include <chrono>
+#include <cstdlib>
+#include <thread>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -222,9 +224,18 @@ struct wlk_session {
 };
 
 
-// Wait for the result flags of a graph-replayed step (written by its last kernel into host-coherent memory): spin on
-// them, look at the stream every 1024 spins so that a failed launch cannot hang the caller, give up after 30 s.
+// Wait for the result flags of a graph-replayed step (written by its last kernel into host-coherent memory).  A step is
+// ~250 us of GPU time, so the wait spins first (lowest latency: the flags arrive over PCIe, there is no interrupt to
+// wait for) - but only for WLK_STEP_SPIN_US (default 400 us, i.e. a step that runs alone and on time never leaves the
+// spin); after that the thread yields between looks and, once the wait is 2 ms old, sleeps 50 us at a time: a step that
+// queues behind other sessions' encoder kernels - the loaded-server case - costs the host a few wake-ups instead of a
+// pegged core per session.  The stream is queried every 1024 looks so that a failed launch cannot hang the caller;
+// gives up after 30 s.
 inline void wlk_wait_step_flags(hipStream_t stream, const wlk::StepResult* res, int n, unsigned seq) {
+    static const long spin_us = [] {
+        const char* e = getenv("WLK_STEP_SPIN_US");
+        return e ? atol(e) : 400L;
+    }();
     const auto t_start = std::chrono::steady_clock::now();
     auto all_set = [&]() {
         for (int i = 0; i < n; ++i)
@@ -232,19 +243,28 @@ inline void wlk_wait_step_flags(hipStream_t stream, const wlk::StepResult* res, 
                 return false;
         return true;
     };
-    for (unsigned spins = 0;; ++spins) {
+    bool spinning = true;
+    for (unsigned looks = 0;; ++looks) {
         if (all_set()) return;
-        if ((spins & 0x3ff) == 0x3ff) {
+        if ((looks & 0x3ff) == 0x3ff) {
             const hipError_t q = hipStreamQuery(stream);
             if (q == hipSuccess) {
                 if (all_set()) return;
                 throw std::runtime_error("graph step: the replay finished without delivering its result");
             }
             if (q != hipErrorNotReady) WLK_HIP(q);
-            if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30))
-                throw std::runtime_error("graph step: no result after 30 s");
         }
-        __builtin_ia32_pause();
+        if (spinning) {
+            __builtin_ia32_pause();
+            if ((looks & 0x3f) == 0x3f &&
+                std::chrono::steady_clock::now() - t_start > std::chrono::microseconds(spin_us))
+                spinning = false;
+            continue;
+        }
+        const auto waited = std::chrono::steady_clock::now() - t_start;
+        if (waited > std::chrono::seconds(30)) throw std::runtime_error("graph step: no result after 30 s");
+        if (waited > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        else std::this_thread::yield();
     }
 }
 
@@ -259,6 +279,9 @@ int wlk_select_first(wlk_session* s, int no_speech_token, const int32_t* adj_row
                      const float* adj_deltas, int n_adj, int k, int content_mel_len, float* no_speech_host,
                      float* top_logprobs_host, int32_t* top_ids_host, int32_t* frames_host);
 void wlk_encode_group(const std::vector<wlk_session*>& group, const wlk::LaunchCtx& c, std::vector<int>& content_out);
+// host-side preconditions of one session's encode (model, frame capacity); empty string = fine.  The encode lane asks
+// this per request before it stacks requests into one chain.
+std::string wlk_encode_precheck(const wlk_session* s, const wlk_model* m);
 
 // engine.hip
 bool wlk_engine_batches_encodes(const wlk_session* s);
