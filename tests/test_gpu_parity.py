@@ -86,6 +86,55 @@ def test_gemm_matches_torch(lib, M, N, K, lda, flags, tag):
     assert err <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+KSPLIT_CASES = [
+    # M, N, K, lda, flags: every tile shape of the one-tile-per-CU k-split kernel (3x1, 3x3, 3x4, three rounds of 3x4, the
+    # large-v3 picks), ragged M / N tails, overlapping A rows (the stride-2 convolution), every epilogue
+    (1500, 512, 512, 512, 2), (1500, 512, 2048, 2048, 2), (1500, 512, 1536, 1024, 3), (1500, 1536, 512, 512, 4),
+    (1500, 2048, 512, 512, 1), (1500, 6144, 512, 512, 4), (1500, 1280, 1280, 1280, 2), (1500, 3840, 1280, 1280, 4),
+    (1500, 5120, 1280, 1280, 1), (1500, 1280, 5120, 5120, 2), (1500, 384, 384, 384, 2), (1500, 1152, 384, 384, 4),
+    (1500, 1536, 384, 384, 1), (1500, 384, 1536, 1536, 2), (1500, 768, 768, 768, 16), (1500, 2304, 768, 768, 8),
+    (1501, 520, 256, 256, 3), (777, 200, 320, 320, 2), (515, 96, 1024, 1024, 0),
+]
+
+
+@pytest.mark.parametrize("M,N,K,lda,flags", KSPLIT_CASES)
+def test_ksplit_gemm_matches_torch_and_is_deterministic(lib, M, N, K, lda, flags):
+    """Encoder-sized problems take the one-tile-per-CU kernel (four waves split K, partial tiles added in wave order):
+    vs fp64, run-to-run identical, and within rounding of the 64x64 kernel it replaces on these shapes."""
+    rng = np.random.default_rng(M + N + K)
+    a_floats = (M - 1) * lda + K
+    a = rng.standard_normal(a_floats).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    r = rng.standard_normal((M, N)).astype(np.float32)
+    outs = []
+    for mode in (4, 4, 3):       # 4 = k-split (must apply), 3 = the 64x64 kernel
+        c = np.full((M, N), np.nan, np.float32)
+        rc = lib.wlk_diag_linear(vp(a), lda, a_floats, vp(w), vp(bias), vp(r) if flags & 2 else None, N, M, N, K, flags,
+                                 0.5, N // 2, mode, vp(c))
+        assert rc == 0, lib.wlk_diag_last_error()
+        outs.append(c)
+    assert np.array_equal(outs[0], outs[1])
+    A = torch.from_numpy(np.lib.stride_tricks.as_strided(a, (M, K), (lda * 4, 4)).copy())
+    ref = A.double() @ torch.from_numpy(w).double().T + torch.from_numpy(bias).double()
+    if flags & 4:
+        ref[:, : N // 2] *= 0.5
+    if flags & 1:
+        ref = torch.nn.functional.gelu(ref)
+    if flags & 8:
+        ref = torch.relu(ref)
+    if flags & 16:
+        ref = ref * torch.sigmoid(ref)
+    if flags & 2:
+        ref = ref + torch.from_numpy(r).double()
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((torch.from_numpy(outs[0]).double() - ref).abs().max())
+    err_classic = float((torch.from_numpy(outs[2]).double() - ref).abs().max())
+    report(f"gemm_ksplit_{M}x{N}x{K}", max_abs_err=err, max_abs_err_64x64_kernel=err_classic, ref_abs_max=scale)
+    assert err <= 2e-5 * scale
+    assert float(np.abs(outs[0] - outs[2]).max()) <= 2e-5 * scale
+
+
 @pytest.mark.parametrize("M,N,K,flags", [(60, 512, 512, 2), (60, 512, 2048, 2), (9, 1536, 512, 4), (149, 2048, 512, 1),
                                          (401, 512, 2048, 2), (401, 2048, 512, 16), (401, 1536, 512, 0),
                                          (401, 192, 768, 2 | 8), (1500, 512, 2048, 3), (1500, 512, 512, 2),

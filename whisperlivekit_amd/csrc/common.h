@@ -183,10 +183,13 @@ struct GemmArgs {
     int batch = 0;
     PtrTable z;
     bool force_kwave = false;
+    long long* dbg_clock = nullptr;  // probe only: 4 s_memtime stamps per workgroup (start, loop start, loop end, end)
+    int force_kernel = 0;           // diagnostics / A-B: 0 = by shape, 2 = k-wave, 3 = the 64x64 kernel, 4 = the k-split kernel
     bool gemm_plain_loop = false;   // A/B switch: LDS fragment reads right before use instead of a group ahead   // diagnostics: take the k-wave kernel (under-filled grids) whatever the shape
 };
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag);
-bool gemm_takes_kwave(int M, int N, int K);   // launch_gemm's shape rule for the k-wave kernel (under-filled grids)
+bool gemm_takes_kwave(int M, int N, int K);
+bool gemm_takes_ksplit(int M, int N, int K);  // ... for the one-tile-per-CU k-split kernel (encoder-sized problems)   // launch_gemm's shape rule for the k-wave kernel (under-filled grids)
 // weight-streaming path for M <= 8 rows (decode steps); same contract as launch_gemm
 void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag);
 inline int gemv_row_bucket(int M) { return M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : 8; }

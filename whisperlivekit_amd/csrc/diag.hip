@@ -1,5 +1,7 @@
 // Kernel-level diagnostics behind the C ABI: run ONE kernel on host data and hand the result back,
 // so the GPU parity tests can compare each building block with a plain fp32 reference.
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/wlk_hip.h"
@@ -44,6 +46,7 @@ int wlk_diag_linear(const float* a, int64_t lda, int64_t a_floats, const float* 
         g.scale_cols = scale_cols;
         LaunchCtx ctx;
         g.force_kwave = force_gemv == 2;
+        g.force_kernel = force_gemv >= 2 ? force_gemv : 0;
         if (force_gemv == 1) launch_gemv(ctx, g, "diag_gemv");
         else launch_gemm(ctx, g, "diag_gemm");
         WLK_HIP(hipDeviceSynchronize());
@@ -67,6 +70,14 @@ int wlk_diag_linear_time(int m, int n, int k, int flags, int force, int reps, fl
         g.A = A.p; g.lda = k; g.W = W.p; g.bias = B.p; g.C = Cc.p; g.ldc = n; g.R = (flags & kGemmResidual) ? R.p : nullptr;
         g.ldr = n; g.M = m; g.N = n; g.K = k; g.flags = flags; g.scale = 0.5f; g.scale_cols = n / 2;
         g.force_kwave = force == 2;
+        g.force_kernel = force >= 2 ? force : 0;
+        long long* dbg = nullptr;
+        const bool want_clock = getenv("WLK_GEMM_CLOCKS") != nullptr;
+        if (want_clock) {
+            WLK_HIP(hipMalloc(reinterpret_cast<void**>(&dbg), 4 * 8192 * sizeof(long long)));
+            WLK_HIP(hipMemset(dbg, 0, 4 * 8192 * sizeof(long long)));
+            g.dbg_clock = dbg;
+        }
         hipStream_t st;
         WLK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         LaunchCtx ctx{st, nullptr};
@@ -86,6 +97,23 @@ int wlk_diag_linear_time(int m, int n, int k, int flags, int force, int reps, fl
         float ms = 0.f;
         WLK_HIP(hipEventElapsedTime(&ms, e0, e1));
         *us_per_launch = 1e3f * ms / (float)reps;
+        if (want_clock) {
+            std::vector<long long> h(4 * 8192);
+            WLK_HIP(hipMemcpy(h.data(), dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            long long t0 = 0, t1 = 0;
+            double pro = 0, loop = 0, epi = 0;
+            int n = 0;
+            for (int i = 0; i < 8192; ++i) {
+                if (!h[4 * i + 3]) continue;
+                if (!n || h[4 * i] < t0) t0 = h[4 * i];
+                if (!n || h[4 * i + 3] > t1) t1 = h[4 * i + 3];
+                pro += h[4 * i + 1] - h[4 * i]; loop += h[4 * i + 2] - h[4 * i + 1]; epi += h[4 * i + 3] - h[4 * i + 2];
+                ++n;
+            }
+            if (n) fprintf(stderr, "[clocks] %d workgroups: prologue %.0f, loop %.0f, fold+epilogue %.0f ticks (mean); first start -> last end %lld ticks\n",
+                           n, pro / n, loop / n, epi / n, t1 - t0);
+            (void)hipFree(dbg);
+        }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         (void)hipStreamDestroy(st);

@@ -18,7 +18,10 @@
 // from lanes 32-63, for A and B alike.  A contraction is order-free, so each lane fetches its
 // four k values with ONE 16-byte LDS read instead of four strided 4-byte reads.
 #include <algorithm>
+#include <atomic>
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -363,6 +366,596 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kwave_kernel(GemmArgs g) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Encoder-sized problems (M ~ 1500 rows, N = d .. 12d): the "one tile per compute unit" kernel.
+//
+// What the 64x64 kernel above loses on these shapes is not arithmetic but quantisation and fixed cost: 1500 x 512
+// is 192 workgroups of 64x64 on 256 compute units, 1500 x 1536 is 2.25 rounds, every launch pays its prologue and
+// epilogue at one wave per SIMD.  Here the tile is chosen so that the whole problem is ONE round of 256 workgroups
+// (1500 rows = 16 tiles of 96; N = 512 / 1536 / 2048 -> 32 / 96 / 128 columns = 16 tiles; 6144 -> three full rounds),
+// and the four waves of a workgroup do not split the tile but K: every wave multiplies the WHOLE (32 TM) x (32 TN) tile
+// over its own quarter of each 64-deep K slab (TM x TN independent accumulator tiles: 192 accumulator registers for
+// 96 x 128), and the four partial tiles are added in wave order through LDS at the end (fixed order: run-to-run
+// identical; the order does not depend on the batch, so a session stacked with others gets its solo arithmetic).
+// Per MFMA this needs (TM + TN) / (TM TN) LDS fragment reads instead of 2, and per flop the fewest bytes from L2.
+//
+// Slabs arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass), one 1 KiB piece per wave
+// instruction = 8 rows x one 128-byte line, issued for slab t+1 before the math on slab t and waited for at the one
+// barrier per slab.  The DMA writes lane-linearly, so the bank swizzle lives in the SOURCE address: lane l of a piece
+// fetches 16-byte chunk (l & 7) ^ ((row >> 1) & 7) of its row's line, and the fragment reads apply the same XOR - each
+// 16-lane service group of a ds_read_b128 then touches 16 distinct bank quads (rows of equal parity in a group have
+// distinct (row >> 1) & 7).  The k-permutation of the kernels above applies unchanged: one 16-byte read = 4 MFMA steps.
+// -------------------------------------------------------------------------------------------------
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) - indices into register arrays
+// stay constants whatever the optimiser thinks of the body's size (a runtime-indexed accumulator array goes to scratch)
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+// Workgroup barrier that orders LDS traffic only: every LDS access of this wave has completed (lgkmcnt(0)), nothing is
+// said about global memory.  __syncthreads() also waits for outstanding global stores (vmcnt(0)) - inside the fold that
+// was ~2 us of store-acknowledge latency per round (measured with s_memtime stamps: 23k of a workgroup's 83k cycles).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Fold of the four k-partials + epilogue, shared by the k-split and the k-pipe kernel.
+//
+// Every wave finishes a quarter of EVERY tile - accumulator registers 4w .. 4w+3 = rows 8w .. 8w+3 (+4 for lanes 32-63):
+// balanced for any tile count, and no accumulator is ever selected by a runtime index.  What shaped the rest (all
+// measured with s_memtime stamps, 96 x 128 tile, 83k cycles per workgroup):
+//  * the tile loop is a RUNTIME loop - unrolled over 12 tiles the erf-heavy epilogue was ~200 KB of straight-line code
+//    that every workgroup pulled through the instruction cache once, at < 2 bytes per cycle: 57 us per workgroup;
+//  * there is NO global load inside the loop: vmcnt retires in order, so a wait for a bias or residual value issued
+//    behind the previous tile's stores is a wait for those stores to be acknowledged (~2000 cycles per tile).  Residual
+//    operands and per-column constants are fetched at kernel start into registers (EpilogueOperands, in flight
+//    during the main loop), parked in LDS next to the partials, and read back by runtime tile index;
+//  * barriers order LDS only (lds_barrier): __syncthreads() would also wait for the stores.
+// LDS use: NT x 4 KiB (residuals) + 2 KiB (column constants) + P x 16 KiB (partials of the P tiles of a pass).
+template <int TM, int TN>
+struct EpilogueOperands {
+    float res[TM * TN][4];     // residual values of this wave's quarter of every tile (0 without kGemmResidual)
+    float bias[TN], mul[TN];   // per tile column
+};
+
+template <int TM, int TN>
+__device__ __forceinline__ void ksplit_fetch_epilogue(const GemmArgs& g, EpilogueOperands<TM, TN>& eo, int wave, int lane, int m0,
+                                                      int n0, const float* gR) {
+    const bool has_res = (g.flags & kGemmResidual) != 0, scaled = (g.flags & kGemmScaleCols) != 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + 32 * j + (lane & 31);
+        eo.bias[j] = g.bias && col < g.N ? g.bias[col] : 0.f;
+        eo.mul[j] = scaled && (g.scale_period ? col % g.scale_period : col) < g.scale_cols ? g.scale : 1.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < TM * TN; ++q) {
+        const int i = q / TN, j = q % TN;
+        const int col = min(n0 + 32 * j + (lane & 31), g.N - 1);
+        const int row0 = m0 + 32 * i + 8 * wave + 4 * (lane >> 5);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) eo.res[q][e] = has_res ? gR[(long)min(row0 + e, g.M - 1) * g.ldr + col] : 0.f;
+    }
+}
+
+template <int TM, int TN, int LDS_FLOATS>
+__device__ __forceinline__ void ksplit_fold_store(const GemmArgs& g, f32x16 (&acc)[TM][TN], const EpilogueOperands<TM, TN>& eo,
+                                                  float* lds, int wave, int lane, int m0, int n0, float* gC) {
+    constexpr int NT = TM * TN;
+    constexpr int RES_FLOATS = NT * 1024, COL_FLOATS = 512;
+    constexpr int P_FIT = (LDS_FLOATS - RES_FLOATS - COL_FLOATS) / 4096;
+    static_assert(P_FIT >= 1, "no room for the fold");
+    constexpr int P = P_FIT < NT ? P_FIT : NT;                     // tiles per pass (4 waves x 4 KiB each)
+    constexpr int PASSES = (NT + P - 1) / P;
+    float* resbuf = lds;                          // [tile][wave][lane][4]
+    float* colbuf = lds + RES_FLOATS;             // [bias | mul][TN][32]   (written by wave 0's lanes 0-31)
+    float* red = colbuf + COL_FLOATS;             // [tile of the pass][wave][4 x (64 lanes x 16 bytes)]
+    const bool gelu = (g.flags & kGemmGelu) != 0, relu = (g.flags & kGemmRelu) != 0, swish = (g.flags & kGemmSwish) != 0;
+    static_for<NT>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        *reinterpret_cast<float4*>(resbuf + (q * 4 + wave) * 256 + lane * 4) =
+            make_float4(eo.res[q][0], eo.res[q][1], eo.res[q][2], eo.res[q][3]);
+    });
+    if (wave == 0 && lane < 32) {
+        static_for<TN>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            colbuf[j * 32 + lane] = eo.bias[j];
+            colbuf[128 + j * 32 + lane] = eo.mul[j];
+        });
+    }
+    static_for<PASSES>([&](auto PP) {
+        constexpr int pass = decltype(PP)::value, q_lo = pass * P, q_hi = (q_lo + P < NT ? q_lo + P : NT);
+        if constexpr (pass > 0) lds_barrier();       // the previous pass's reads are done
+        static_for<q_hi - q_lo>([&](auto T) {
+            constexpr int t = decltype(T)::value, q = q_lo + t, i = q / TN, j = q % TN;
+            float* dst = red + (t * 4 + wave) * 1024 + lane * 4;
+            static_for<4>([&](auto V) {
+                constexpr int v = decltype(V)::value;
+                *reinterpret_cast<float4*>(dst + v * 256) =
+                    make_float4(acc[i][j][4 * v], acc[i][j][4 * v + 1], acc[i][j][4 * v + 2], acc[i][j][4 * v + 3]);
+            });
+        });
+        lds_barrier();
+#pragma unroll 1
+        for (int q = q_lo; q < q_hi; ++q) {
+            const float* p = red + ((q - q_lo) * 4) * 1024 + wave * 256 + lane * 4;
+            float4 s4 = *reinterpret_cast<const float4*>(p);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 t4 = *reinterpret_cast<const float4*>(p + w * 1024);
+                s4.x += t4.x; s4.y += t4.y; s4.z += t4.z; s4.w += t4.w;
+            }
+            const float4 r4 = *reinterpret_cast<const float4*>(resbuf + (q * 4 + wave) * 256 + lane * 4);
+            const int i = q / TN, j = q - i * TN;
+            const float b = colbuf[j * 32 + (lane & 31)], mul = colbuf[128 + j * 32 + (lane & 31)];
+            const int col = n0 + 32 * j + (lane & 31);
+            const int row0 = m0 + 32 * i + 8 * wave + 4 * (lane >> 5);
+            if (col < g.N) {
+                const float res[4] = {r4.x, r4.y, r4.z, r4.w};
+                // the four outputs side by side, one uniform branch per activation (not per element): four independent
+                // dependency chains for a wave that has nobody to share its SIMD with
+                float v[4] = {(s4.x + b) * mul, (s4.y + b) * mul, (s4.z + b) * mul, (s4.w + b) * mul};   // mul == 1.0f where no
+                                                                                                       // scale applies: bit-neutral
+                if (gelu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                }
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (swish) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+                }
+                float* out = gC + (long)row0 * g.ldc + col;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (row0 + e < g.M) out[(long)e * g.ldc] = v[e] + res[e];
+            }
+        }
+    });
+}
+
+// KS = slab depth (32 or 64 floats of K per trip; each of the four waves contracts KS / 4 of them)
+template <int TM, int TN, int KS>
+struct KSplitCfg {
+    static constexpr int BM = 32 * TM, BN = 32 * TN;
+    static constexpr int HALVES = KS / 32;                                        // 128-byte lines per slab row
+    static constexpr int A_PIECES = BM / 8 * HALVES, W_PIECES = BN / 8 * HALVES;  // 1 KiB pieces per slab
+    static constexpr int PIECES_PER_WAVE = (A_PIECES + W_PIECES) / 4;
+    static constexpr int SLAB_FLOATS = (BM + BN) * KS;
+    static constexpr int RED_FLOATS = TM * TN * 1024 + 512 + 2 * 4096;            // the fold: residuals + constants + >= 2 tiles per pass
+    static constexpr int LDS_FLOATS = (2 * SLAB_FLOATS > RED_FLOATS ? 2 * SLAB_FLOATS : RED_FLOATS);
+    static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
+};
+
+// ABL (timing ablations of the probe only, results are wrong): 1 = no DMA inside the loop, 2 = no MFMA, 3 = no fragment reads
+template <int TM, int TN, int KS, int ABL = 0>
+__global__ __launch_bounds__(256) void gemm_nt_f32_ksplit_kernel(GemmArgs g) {
+    using Cfg = KSplitCfg<TM, TN, KS>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, NP = Cfg::PIECES_PER_WAVE, HALVES = Cfg::HALVES, STEPS = KS / 32;
+    extern __shared__ __attribute__((aligned(1024))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool batched = g.batch > 0;
+    const float* const gA = batched ? table_at(g.z.in, blockIdx.y) : g.A;
+    float* const gC = batched ? table_at(g.z.out, blockIdx.y) : g.C;
+    const float* const gR = batched ? table_at(g.z.res, blockIdx.y) : g.R;
+    // XCD-aware tile mapping (see gemm_nt_f32_kernel): 4 row bands x 2 column bands, one per XCD
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    int tile_m, tile_n;
+    if (tiles_m >= 8) {
+        const int band_m = (tiles_m + 3) / 4, band_n = (tiles_n + 1) / 2;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        tile_m = (xcd >> 1) * band_m + slot / band_n;
+        tile_n = (xcd & 1) * band_n + slot % band_n;
+        if (slot >= band_m * band_n || tile_m >= tiles_m || tile_n >= tiles_n) return;   // padding workgroups
+    } else {
+        tile_m = blockIdx.x / tiles_n;
+        tile_n = blockIdx.x - tile_m * tiles_n;
+        if (tile_m >= tiles_m) return;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // DMA sources of this wave's pieces (piece j = wave + 4 i: A pieces first, then W; piece = (row group of 8, line)).
+    // Rows past the end of the operand are clamped: they only feed output rows / columns that are never stored.
+    const float* src[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int j = wave + 4 * i;
+        const bool is_a = j < Cfg::A_PIECES;
+        const int jj = is_a ? j : j - Cfg::A_PIECES;
+        const int row_local = (jj / HALVES) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row_local >> 1) & 7);
+        const int col = (jj % HALVES) * 32 + chunk * 4;
+        if (is_a) src[i] = gA + (long)min(m0 + row_local, g.M - 1) * g.lda + col;
+        else src[i] = g.W + (long)min(n0 + row_local, g.N - 1) * g.K + col;
+    }
+    // one DMA piece of this wave: slab kt -> buffer buf
+    auto issue_piece = [&](auto I, int kt, int buf) {
+        constexpr int i = decltype(I)::value;
+        const int j = wave + 4 * i;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long)kt * KS),
+                                         (__attribute__((address_space(3))) void*)(lds + buf * Cfg::SLAB_FLOATS + j * 256), 16, 0, 0);
+    };
+
+    // fragment addresses (floats): row r of an operand sits in piece (r >> 3, line), 8 x 16-byte chunks per line; wave w
+    // owns chunks [w KS / 16, (w + 1) KS / 16) of a slab row; read step s takes chunk 2 s (lanes 0-31) / 2 s + 1 (32-63)
+    const int cg0 = (KS / 16) * wave + (lane >> 5);     // chunk of step 0 within the slab row; step 1 is + 2 (same line)
+    const int line = cg0 >> 3, c0 = cg0 & 7;
+    int a_off[TM], w_off[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int r = 32 * t + (lane & 31);
+        a_off[t] = (((r >> 3) * HALVES + line) * 64 + (r & 7) * 8 + (c0 ^ ((r >> 1) & 7))) * 4;
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int r = 32 * t + (lane & 31);
+        w_off[t] = Cfg::A_PIECES * 256 + (((r >> 3) * HALVES + line) * 64 + (r & 7) * 8 + (c0 ^ ((r >> 1) & 7))) * 4;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // One slab per trip, one basic block: fragment reads of slab kt (all STEPS (TM + TN) of them) FIRST - a ds_read placed
+    // behind an outstanding LDS-DMA would make hipcc drain the DMA queue (it cannot tell the two buffers apart) - then
+    // the MFMAs with the DMA pieces of slab kt + 1 (other buffer) dealt between the first of them, then the one barrier
+    // (hipcc waits for the DMA in front of it; the sched_barrier keeps the matrix work from sinking below it, which
+    // would expose the whole DMA latency).  The last trip re-fetches its own slab into the idle buffer instead of
+    // branching; the barrier drains it before the fold reuses LDS.  The other buffer's last reads sit before the
+    // previous trip's barrier.
+    const int nslab = g.K / KS;
+    EpilogueOperands<TM, TN> eo;          // residual / bias values: in flight during the main loop (see ksplit_fold_store)
+    ksplit_fetch_epilogue<TM, TN>(g, eo, wave, lane, m0, n0, gR);
+    static_for<NP>([&](auto I) { issue_piece(I, 0, 0); });
+    __syncthreads();
+    constexpr int NMF = 4 * STEPS * TM * TN;            // MFMAs per trip
+    constexpr int GAP = NMF / NP >= 2 ? 2 : 1;          // one DMA piece every GAP MFMAs (a piece's ~60 issue cycles fit inside one
+                                                        // MFMA's 64); front-loaded, so the rest of the trip covers the DMA latency
+    for (int kt = 0; kt < nslab; ++kt) {
+        const int cur = kt & 1;
+        const int nxt = min(kt + 1, nslab - 1);
+        const float* base = lds + cur * Cfg::SLAB_FLOATS;
+        float4 fa[STEPS][TM], fb[STEPS][TN];
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {      // step 1 = chunk + 2: one XOR on the float offset (bit 3)
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                if constexpr (ABL == 3) fa[s][t] = make_float4(1.f, 2.f, 3.f, (float)kt);
+                else fa[s][t] = *reinterpret_cast<const float4*>(base + (a_off[t] ^ (s * 8)));
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                if constexpr (ABL == 3) fb[s][t] = make_float4(1.f, 2.f, 3.f, (float)kt);
+                else fb[s][t] = *reinterpret_cast<const float4*>(base + (w_off[t] ^ (s * 8)));
+            }
+        }
+        static_for<NMF>([&](auto X) {
+            constexpr int x = decltype(X)::value;
+            constexpr int s = x / (4 * TM * TN), c = (x / (TM * TN)) & 3, q = x % (TM * TN), i = q / TN, j = q % TN;
+            const float a = c == 0 ? fa[s][i].x : c == 1 ? fa[s][i].y : c == 2 ? fa[s][i].z : fa[s][i].w;
+            const float b = c == 0 ? fb[s][j].x : c == 1 ? fb[s][j].y : c == 2 ? fb[s][j].z : fb[s][j].w;
+            if constexpr (ABL == 2) {
+                asm volatile("" ::"v"(a), "v"(b));
+            } else {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+            }
+            if constexpr (ABL != 1 && x % GAP == GAP - 1 && x / GAP < NP) {
+                issue_piece(std::integral_constant<int, x / GAP>{}, nxt, cur ^ 1);
+            }
+        });
+        if constexpr (ABL == 0) {
+            // issue order of the trip: all fragment reads, then GAP MFMAs / one DMA piece, NP times, then the remaining
+            // MFMAs (left to itself hipcc bunches the pieces behind one MFMA: ~60 cycles of issue each, the pipe idles)
+            __builtin_amdgcn_sched_group_barrier(0x100, STEPS * (TM + TN), 0);
+            static_for<NP>([&](auto) {
+                __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            });
+            if constexpr (NMF - NP * GAP > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NP * GAP, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+
+    ksplit_fold_store<TM, TN, Cfg::LDS_FLOATS>(g, acc, eo, lds, wave, lane, m0, n0, gC);
+}
+
+// -------------------------------------------------------------------------------------------------
+// The same kernel with the slab pipeline under manual control ("k-pipe"): 32-deep slabs in a ring of NB LDS buffers,
+// the DMA of slab t + NB - 1 issued during trip t, COUNTED waits (s_waitcnt vmcnt((NB - 2) NP): only slab t + 1 has to
+// have landed, the younger slabs stay in flight across the barrier), fragment reads of slab t + 1 issued in the
+// middle of trip t so that their latency hides behind the second half of the trip's MFMAs.  hipcc cannot express
+// this: it drains the whole DMA queue in front of every __syncthreads() and in front of any LDS read that follows an
+// LDS-DMA (it cannot tell the ring's buffers apart), which is exactly the latency a one-workgroup-per-CU kernel has
+// no other wave to hide behind.  So the fragment reads, both wait kinds and the barrier are inline asm / raw builtins
+// here and the ordering is argued by hand:
+//   RAW  slab t+1 is read (trip t, after the barrier) only after EVERY wave has waited for its own pieces of it:
+//        pieces retire in issue order, at the wait the youngest (NB - 2) NP belong to slabs t+2 .. t+NB-1;
+//   WAR  buffer (t + NB - 1) % NB = (t - 1) % NB is refilled from trip t on; slab t-1 was read in trip t-2 (waited for
+//        with lgkmcnt(0) at that trip's end), and the barrier of trip t-1 lies between;
+//   the fragments' lgkmcnt(0) takes the fragment registers as in/out operands, so no MFMA that reads them can be
+//        scheduled above it.
+// Trips past the end re-fetch the last slab into a dead buffer (uniform counting, no branches); the loop's exit
+// drains everything before the fold reuses LDS.
+// -------------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int TM, int TN, int NB>
+struct KPipeCfg {
+    static constexpr int BM = 32 * TM, BN = 32 * TN, KS = 32;
+    static constexpr int A_PIECES = BM / 8, W_PIECES = BN / 8;                   // 1 KiB pieces per slab (8 rows x 128 B)
+    static constexpr int PIECES_PER_WAVE = (A_PIECES + W_PIECES) / 4;
+    static constexpr int SLAB_FLOATS = (BM + BN) * KS;
+    static constexpr int RED_FLOATS = TM * TN * 1024 + 512 + 2 * 4096;
+    static constexpr int LDS_FLOATS = (NB * SLAB_FLOATS > RED_FLOATS ? NB * SLAB_FLOATS : RED_FLOATS);
+    static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt range");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define WLK_VM(n) else if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");
+    WLK_VM(1) WLK_VM(2) WLK_VM(3) WLK_VM(4) WLK_VM(5) WLK_VM(6) WLK_VM(7) WLK_VM(8) WLK_VM(9) WLK_VM(10) WLK_VM(11) WLK_VM(12)
+    WLK_VM(13) WLK_VM(14) WLK_VM(15) WLK_VM(16) WLK_VM(17) WLK_VM(18) WLK_VM(19) WLK_VM(20) WLK_VM(21) WLK_VM(22) WLK_VM(23)
+    WLK_VM(24) WLK_VM(25) WLK_VM(26) WLK_VM(27) WLK_VM(28) WLK_VM(30) WLK_VM(32) WLK_VM(33) WLK_VM(35) WLK_VM(36) WLK_VM(40)
+    WLK_VM(42) WLK_VM(44) WLK_VM(48)
+#undef WLK_VM
+    else static_assert(N < 0, "add the vmcnt literal");
+}
+
+template <int TM, int TN, int NB>
+__global__ __launch_bounds__(256) void gemm_nt_f32_kpipe_kernel(GemmArgs g) {
+    using Cfg = KPipeCfg<TM, TN, NB>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, NP = Cfg::PIECES_PER_WAVE, KS = 32, D = NB - 1;
+    extern __shared__ __attribute__((aligned(1024))) float lds[];
+    const long long t_start = g.dbg_clock ? (long long)__builtin_readcyclecounter() : 0;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool batched = g.batch > 0;
+    const float* const gA = batched ? table_at(g.z.in, blockIdx.y) : g.A;
+    float* const gC = batched ? table_at(g.z.out, blockIdx.y) : g.C;
+    const float* const gR = batched ? table_at(g.z.res, blockIdx.y) : g.R;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    int tile_m, tile_n;
+    if (tiles_m >= 8) {
+        const int band_m = (tiles_m + 3) / 4, band_n = (tiles_n + 1) / 2;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        tile_m = (xcd >> 1) * band_m + slot / band_n;
+        tile_n = (xcd & 1) * band_n + slot % band_n;
+        if (slot >= band_m * band_n || tile_m >= tiles_m || tile_n >= tiles_n) return;   // padding workgroups
+    } else {
+        tile_m = blockIdx.x / tiles_n;
+        tile_n = blockIdx.x - tile_m * tiles_n;
+        if (tile_m >= tiles_m) return;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const float* src[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int j = wave + 4 * i;
+        const bool is_a = j < Cfg::A_PIECES;
+        const int jj = is_a ? j : j - Cfg::A_PIECES;
+        const int row_local = jj * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row_local >> 1) & 7);
+        if (is_a) src[i] = gA + (long)min(m0 + row_local, g.M - 1) * g.lda + chunk * 4;
+        else src[i] = g.W + (long)min(n0 + row_local, g.N - 1) * g.K + chunk * 4;
+    }
+    const int nslab = g.K / KS;
+    auto issue_piece = [&](auto I, int kt, int buf) {     // slab kt (clamped) -> ring buffer buf
+        constexpr int i = decltype(I)::value;
+        const int j = wave + 4 * i;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long)min(kt, nslab - 1) * KS),
+                                         (__attribute__((address_space(3))) void*)(lds + buf * Cfg::SLAB_FLOATS + j * 256), 16, 0, 0);
+    };
+
+    // fragment byte addresses inside a ring buffer: wave w owns chunks 2w, 2w + 1 of every row's 128-byte line
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
+    const int c0 = 2 * wave + (lane >> 5);
+    unsigned a_addr[TM], w_addr[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int r = 32 * t + (lane & 31);
+        a_addr[t] = lds_base + (unsigned)(((r >> 3) * 64 + (r & 7) * 8 + (c0 ^ ((r >> 1) & 7))) * 16);
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int r = 32 * t + (lane & 31);
+        w_addr[t] = lds_base + (unsigned)(Cfg::A_PIECES * 1024 + ((r >> 3) * 64 + (r & 7) * 8 + (c0 ^ ((r >> 1) & 7))) * 16);
+    }
+    auto read_frags = [&](f32x4v (&fa)[TM], f32x4v (&fb)[TN], int buf) {
+        const unsigned off = (unsigned)buf * (unsigned)(Cfg::SLAB_FLOATS * 4);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[t]) : "v"(a_addr[t] + off));
+#pragma unroll
+        for (int t = 0; t < TN; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[t]) : "v"(w_addr[t] + off));
+    };
+    auto wait_frags = [&](f32x4v (&fa)[TM], f32x4v (&fb)[TN]) {   // lgkmcnt(0), tied to the registers it makes valid
+        static_assert(TM + TN <= 8, "operand list");
+        if constexpr (TM == 3 && TN == 4)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));
+        else if constexpr (TM == 3 && TN == 3)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]));
+        else if constexpr (TM == 3 && TN == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb[0]), "+v"(fb[1]));
+        else if constexpr (TM == 3 && TN == 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb[0]));
+        else if constexpr (TM == 2 && TN == 4)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));
+        else if constexpr (TM == 2 && TN == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]), "+v"(fb[1]));
+        else if constexpr (TM == 4 && TN == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]));
+        else if constexpr (TM == 2 && TN == 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]));
+        else static_assert(TM < 0, "add the operand list of this tile");
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    constexpr int NMF = 4 * TM * TN;                     // MFMAs per trip
+    constexpr int HEAD = NMF / 2;                        // ... in front of the barrier
+    constexpr int GAP = HEAD / NP >= 1 ? HEAD / NP : 1;  // one DMA piece every GAP MFMAs of the head
+    static_assert(NP <= HEAD, "more DMA pieces than head MFMAs");
+
+    // residual / bias values first: they are older than every DMA piece, so the counted waits below cover them, and they
+    // land during the first trips (see ksplit_fold_store)
+    EpilogueOperands<TM, TN> eo;
+    ksplit_fetch_epilogue<TM, TN>(g, eo, wave, lane, m0, n0, gR);
+    // prologue: slabs 0 .. D-1 in flight, slab 0 landed and read
+    static_for<D>([&](auto S) {
+        constexpr int sl = decltype(S)::value;
+        static_for<NP>([&](auto I) { issue_piece(I, sl, sl); });
+    });
+    wait_vmcnt<(D - 1) * NP>();
+    __builtin_amdgcn_s_barrier();
+    f32x4v fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    read_frags(fa0, fb0, 0);
+    wait_frags(fa0, fb0);
+
+    // one trip: MFMAs of slab kt from (fa, fb); DMA of slab kt + D; reads of slab kt + 1 into (na, nb)
+    auto trip = [&](f32x4v (&fa)[TM], f32x4v (&fb)[TN], f32x4v (&na)[TM], f32x4v (&nb)[TN], int kt) {
+        const int dma_buf = (kt + D) % NB, next_buf = (kt + 1) % NB;
+        static_for<HEAD>([&](auto X) {
+            constexpr int x = decltype(X)::value;
+            constexpr int c = x / (TM * TN), q = x % (TM * TN), i = q / TN, j = q % TN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][c], fb[j][c], acc[i][j], 0, 0, 0);
+            if constexpr (x % GAP == GAP - 1 && x / GAP < NP) issue_piece(std::integral_constant<int, x / GAP>{}, kt + D, dma_buf);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vmcnt<(D - 1) * NP>();
+        __builtin_amdgcn_s_barrier();
+        read_frags(na, nb, next_buf);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NMF - HEAD>([&](auto X) {
+            constexpr int x = HEAD + decltype(X)::value;
+            constexpr int c = x / (TM * TN), q = x % (TM * TN), i = q / TN, j = q % TN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][c], fb[j][c], acc[i][j], 0, 0, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        wait_frags(na, nb);
+    };
+    const long long t_loop = g.dbg_clock ? (long long)__builtin_readcyclecounter() : 0;
+    int kt = 0;
+    for (; kt + 1 < nslab; kt += 2) {
+        trip(fa0, fb0, fa1, fb1, kt);
+        trip(fa1, fb1, fa0, fb0, kt + 1);
+    }
+    if (kt < nslab) trip(fa0, fb0, fa1, fb1, kt);
+    wait_vmcnt<0>();
+    __syncthreads();
+    const long long t_fold = g.dbg_clock ? (long long)__builtin_readcyclecounter() : 0;
+
+    ksplit_fold_store<TM, TN, Cfg::LDS_FLOATS>(g, acc, eo, lds, wave, lane, m0, n0, gC);
+    if (g.dbg_clock && threadIdx.x == 0) {
+        long long* d = g.dbg_clock + 4 * ((long)blockIdx.y * gridDim.x + blockIdx.x);
+        d[0] = t_start; d[1] = t_loop; d[2] = t_fold; d[3] = (long long)__builtin_readcyclecounter();
+    }
+}
+
+template <int TM, int TN, int NB>
+static void launch_kpipe(const LaunchCtx& ctx, const GemmArgs& g) {
+    using Cfg = KPipeCfg<TM, TN, NB>;
+    static_assert(Cfg::LDS_BYTES <= 160 * 1024, "ring does not fit the 160 KiB LDS");
+    static std::atomic<uint64_t> configured{0};
+    int dev = 0;
+    WLK_HIP(hipGetDevice(&dev));
+    if (!(configured.load(std::memory_order_acquire) >> (dev & 63) & 1)) {
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_kpipe_kernel<TM, TN, NB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
+        configured.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+    const int tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.N + Cfg::BN - 1) / Cfg::BN;
+    const int blocks = tiles_m >= 8 ? 8 * ((tiles_m + 3) / 4) * ((tiles_n + 1) / 2) : tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm_nt_f32_kpipe_kernel<TM, TN, NB>), dim3(blocks, std::max(g.batch, 1)), dim3(256), Cfg::LDS_BYTES,
+                       ctx.stream, g);
+}
+
+template <int NB>
+static bool dispatch_kpipe(const LaunchCtx& ctx, const GemmArgs& g, int tm, int tn) {
+#define WLK_KP(a, b) if (tm == a && tn == b) { launch_kpipe<a, b, NB>(ctx, g); return true; }
+    WLK_KP(3, 4) WLK_KP(3, 3) WLK_KP(3, 2) WLK_KP(3, 1) WLK_KP(2, 4) WLK_KP(2, 2) WLK_KP(2, 1) WLK_KP(4, 2)
+#undef WLK_KP
+    return false;
+}
+
+// Tile of the k-split kernel for an (M, N, K) problem, or {0, 0} when it does not apply: the shape that needs the fewest
+// rounds of 256 workgroups x tile area (ties: the larger tile).  Depends on the problem only, never on the batch.
+struct KSplitTile { int tm, tn, ks; };
+// Which problems take the one-tile-per-CU kernels, and with which tile.  Measured on MI355X (scripts/gemm_time_probe.py,
+// profiles/r03_gemm_probe_*.txt), M = 1500: they win where the output is narrow - N = 512: 12.3 / 34.6 / 28.0 us (out
+// projection, fc2, conv2) against 14.8 / 45.3 / 36.5 for the 64x64 kernel; N = 768 (small): 27 / 86 / 68 against
+// 32 / 110 / 85; N = 1280 (large-v3): 3-5 %; N = 1536 (base qkv, 96 x 96 tiles): 28.7 against 31.9 - and lose from
+// N = 2048 on: there the 64x64 kernel's three co-resident workgroups per CU hide each other's prologue and epilogue,
+// which a lone 96 x 128 workgroup cannot (its main loop runs at 88 % of the MFMA rate, but ~2.5 us of cold-start DMA
+// and ~6 us of fold + erf epilogue at one wave per SIMD are exposed: 40 vs 35.5 us on fc1).  The choice depends on
+// (M, N, K) only - never on the batch - so a session stacked with others keeps its solo arithmetic.
+// `forced` (diagnostics, force_kernel 4): any applicable problem, so that every tile instantiation stays tested.
+static KSplitTile ksplit_tile(int M, int N, int K, bool forced = false) {
+    static const int mode = [] {
+        const char* e = getenv("WLK_GEMM");
+        return e && e[0] == 'c' ? 0 : 1;      // WLK_GEMM=classic: the 64x64 kernel everywhere (A/B switch)
+    }();
+    if (K % 64 != 0 || K < 256 || M < 512) return {0, 0, 0};
+    if (!forced && (!mode || N > 1536)) return {0, 0, 0};
+    static const KSplitTile cand[] = {{3, 4, 104}, {3, 3, 104}, {3, 2, 104}, {3, 1, 104}, {2, 4, 104}, {2, 2, 104}, {2, 1, 104}, {4, 2, 104}};
+    KSplitTile best{0, 0, 0};
+    double best_cost = 0.0;
+    for (const KSplitTile& c : cand) {
+        const long tiles = (long)((M + 32 * c.tm - 1) / (32 * c.tm)) * ((N + 32 * c.tn - 1) / (32 * c.tn));
+        // rounds of 256 workgroups x (MFMA steps of a tile + fixed cost of a round + a charge for thin tiles' L2 traffic)
+        const double cost = ((tiles + 255) / 256) * (c.tm * c.tn * (K / 8.0) + 48.0 + 2.0 * (c.tm + c.tn) * (K / 64.0));
+        if (best.tm == 0 || cost < best_cost) { best = c; best_cost = cost; }
+    }
+    return best;
+}
+
+template <int TM, int TN, int KS, int ABL = 0>
+static void launch_ksplit(const LaunchCtx& ctx, const GemmArgs& g) {
+    using Cfg = KSplitCfg<TM, TN, KS>;
+    static_assert(Cfg::LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+    static std::atomic<uint64_t> configured{0};     // per device: more than 64 KiB of dynamic LDS has to be asked for
+    int dev = 0;
+    WLK_HIP(hipGetDevice(&dev));
+    if (!(configured.load(std::memory_order_acquire) >> (dev & 63) & 1)) {
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_ksplit_kernel<TM, TN, KS, ABL>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
+        configured.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+    const int tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.N + Cfg::BN - 1) / Cfg::BN;
+    const int blocks = tiles_m >= 8 ? 8 * ((tiles_m + 3) / 4) * ((tiles_n + 1) / 2) : tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm_nt_f32_ksplit_kernel<TM, TN, KS, ABL>), dim3(blocks, std::max(g.batch, 1)), dim3(256), Cfg::LDS_BYTES,
+                       ctx.stream, g);
+}
+
+template <int KS, int ABL>
+static bool dispatch_ksplit(const LaunchCtx& ctx, const GemmArgs& g, int tm, int tn) {
+#define WLK_KS(a, b) if (tm == a && tn == b) { launch_ksplit<a, b, KS, ABL>(ctx, g); return true; }
+    WLK_KS(3, 4) WLK_KS(3, 3) WLK_KS(3, 2) WLK_KS(3, 1) WLK_KS(2, 4) WLK_KS(2, 2) WLK_KS(2, 1) WLK_KS(4, 2)
+#undef WLK_KS
+    return false;
+}
+
 // 32x32 output tiles at or below which the k-wave kernel is used (WLK_KWAVE_MAX_TILES overrides; 0 disables)
 static long kwave_max_tiles() {
     static const long v = [] {
@@ -377,6 +970,8 @@ bool gemm_takes_kwave(int M, int N, int K) {
     return K >= 256 && tiles32 <= kwave_max_tiles();
 }
 
+bool gemm_takes_ksplit(int M, int N, int K) { return ksplit_tile(M, N, K).tm != 0; }
+
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (g.M <= 0 || g.N <= 0) return;
     if (g.K % 4 != 0 || g.lda % 4 != 0) throw std::invalid_argument("gemm: K and lda must be multiples of 4");
@@ -385,15 +980,35 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     const double nb = std::max(g.batch, 1);
     KernelScope ks(ctx, tag, nb * 2.0 * g.M * g.N * g.K,
                    4.0 * (nb * (double)g.M * g.K + (double)g.N * g.K + nb * (double)g.M * g.N));
-    if (g.batch > 0 && (gemm_takes_kwave(g.M, g.N, g.K) || g.force_kwave || (long)((g.N + 63) / 64) * ((g.M + 63) / 64) < 64))
-        throw std::invalid_argument("gemm: batched launches are only available on the 64x64 path");
     if (g.batch > kMaxBatch) throw std::invalid_argument("gemm: batch too large");
+    const bool want_kwave = g.force_kwave || g.force_kernel == 2;
+    // encoder-sized problems: one tile per compute unit, K split over the waves (force_kernel 3 = the 64x64 kernel)
+    const KSplitTile kt = (want_kwave || g.kcache || g.force_kernel == 3) ? KSplitTile{0, 0, 0} : ksplit_tile(g.M, g.N, g.K, g.force_kernel == 4);
+    if (g.force_kernel == 4 && !kt.tm) throw std::invalid_argument("gemm: the k-split kernel does not take this shape");
+    if (kt.tm) {
+        // probe override (scripts/gemm_tile_probe.py): WLK_KSPLIT_FORCE="tm,tn,ks" (ks 64: compiler-scheduled k-split; 103 / 104: k-pipe)
+        static const KSplitTile forced = [] {
+            KSplitTile f{0, 0, 0};
+            if (const char* e = getenv("WLK_KSPLIT_FORCE")) sscanf(e, "%d,%d,%d", &f.tm, &f.tn, &f.ks);
+            return f;
+        }();
+        const KSplitTile use = forced.tm ? forced : kt;
+        bool ok;
+        if (use.ks == 104) ok = dispatch_kpipe<4>(ctx, g, use.tm, use.tn);
+        else if (use.ks == 103) ok = dispatch_kpipe<3>(ctx, g, use.tm, use.tn);
+        else ok = dispatch_ksplit<64, 0>(ctx, g, use.tm, use.tn);
+        if (!ok) throw std::logic_error("gemm: k-split tile without an instantiation");
+        WLK_HIP(hipGetLastError());
+        return;
+    }
+    if (g.batch > 0 && (gemm_takes_kwave(g.M, g.N, g.K) || want_kwave || (long)((g.N + 63) / 64) * ((g.M + 63) / 64) < 64))
+        throw std::invalid_argument("gemm: batched launches are only available on the tiled paths");
     const long tiles64 = (long)((g.N + 63) / 64) * ((g.M + 63) / 64);
     const int tiles_n = (g.N + 63) / 64;
     const long tiles32 = (long)((g.N + 31) / 32) * ((g.M + 31) / 32);
-    if (g.kcache && !(gemm_takes_kwave(g.M, g.N, g.K) || g.force_kwave))
+    if (g.kcache && !(gemm_takes_kwave(g.M, g.N, g.K) || want_kwave))
         throw std::invalid_argument("gemm: fused KV-cache append is only available on the k-wave path");
-    if (gemm_takes_kwave(g.M, g.N, g.K) || (g.force_kwave && g.K >= 256)) {
+    if ((gemm_takes_kwave(g.M, g.N, g.K) && g.force_kernel != 3) || (want_kwave && g.K >= 256)) {
         hipLaunchKernelGGL(gemm_nt_f32_kwave_kernel, dim3((unsigned)tiles32), dim3(256), 0, ctx.stream, g);
     } else if (tiles64 >= 64) {
         const int tiles_m = (g.M + 63) / 64;
