@@ -29,6 +29,8 @@ namespace wlk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+long long* g_attn_dbg_clock = nullptr;
+
 constexpr int QT = 32, KT = 32, NWAVE = 4, K_LD = 68, O_LD = 65;
 constexpr int kAttnLdsFloats = NWAVE * KT * K_LD + NWAVE * KT * 64;  // K tiles + V tiles
 constexpr int kAttnLdsTotal = kAttnLdsFloats + QT * K_LD;            // + Q tile
@@ -250,6 +252,237 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Encoder self-attention with wave-private staging ("pw"): the arithmetic of flash_attention_kernel - same (head,
+// 32-query tile) workgroups, wave w takes key tiles w, w+4, ..., same MFMA sequences, same online-softmax updates,
+// same four-way merge, so the output is bit-identical to it - but no workgroup barrier inside the key loop.
+// flash_attention_kernel stages 128 keys per trip with all 256 threads (global -> registers -> LDS) between two
+// __syncthreads(), although each wave only ever reads ITS OWN 32-key tile back: a third of the kernel's time was that
+// staging (scripts/probes/attn_ablation.hip).  Here every wave fetches its own tiles by LDS-DMA into a private 16 KiB
+// region - K(t) while the previous tile's P.V runs, V(t) while Q.K^T(t) runs - so the only waits are the wave's own
+// s_waitcnt vmcnt(0) at the two phase changes, and the four waves of a workgroup drift freely.  The DMA writes
+// lane-linearly; rows are 256 bytes, so the bank swizzle (16-byte chunk c of key row r stored at chunk c ^ (r & 15)) is
+// applied to the source address and to the reads.  Fragment reads are inline asm: hipcc would drain the DMA queue in
+// front of every LDS read that follows an LDS-DMA.  Q fragments live in registers.  64 KiB of LDS: two workgroups per
+// CU, as before.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void enc_attention_pw_kernel(FlashArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) float lds[];
+    const bool dbg = a.dbg_clock != nullptr;
+    const long long t_start = dbg ? (long long)__builtin_readcyclecounter() : 0;
+    long long w_k = 0, w_v = 0, t_soft = 0;
+    const bool batched = a.batch > 0;
+    const float* const aq = batched ? table_at(a.z.in, blockIdx.y) : a.q;
+    const float* const ak = batched ? aq + a.z_k_off : a.k;
+    const float* const av = batched ? aq + a.z_v_off : a.v;
+    float* const aout = batched ? table_at(a.z.out, blockIdx.y) : a.out;
+    const int T = a.Tk, n_head = a.n_head;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int head = blockIdx.x % n_head;       // head == XCD for 8 heads: K/V of a head stay in one L2
+    const int q_tiles = (a.Tq + QT - 1) / QT;
+    const int qt_idx = (blockIdx.x / n_head) % q_tiles;
+    const int ks = blockIdx.x / (n_head * q_tiles);   // key-range split (0 when a.k_splits == 1)
+    const int q0 = qt_idx * QT;
+    const long ld = a.ldkv;
+    const int half = lane >> 5, lq = lane & 31;
+
+    float4 qf[8];                               // Q[q0 + lq][8 g + 4 half .. +4]
+    {
+        const bool ok = q0 + lq < a.Tq;
+        const float* qp = aq + (long)(ok ? q0 + lq : 0) * a.ldq + head * 64 + half * 4;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(qp + g * 8);
+            qf[g] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // private regions of this wave: K tile [32 keys][16 chunks of 16 bytes], V tile the same
+    float* Kb = lds + wave * 4096;
+    float* Vb = Kb + 2048;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
+    const unsigned kb_addr = lds_base + (unsigned)wave * 16384u, vb_addr = kb_addr + 8192u;
+    // DMA piece p (0..7) of a tile = key rows 4p .. 4p+3; lane l fills slot (row 4p + (l >> 4), chunk l & 15) with source
+    // chunk (l & 15) ^ (row & 15)
+    const int prow = lane >> 4;
+    const float* kbase = ak + head * 64;
+    const float* vbase = av + head * 64;
+    auto dma_piece = [&](const float* base, float* dst, int key0, int p) {
+        const int row = 4 * p + prow;
+        const int chunk = (lane & 15) ^ (row & 15);
+        const float* src = base + (long)min(key0 + row, T - 1) * ld + chunk * 4;   // rows past T: clamped, masked below
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + p * 256), 16, 0, 0);
+    };
+    // K fragment of group g: row lq, chunk 2g + half  ->  stored chunk (2g) ^ (half ^ (lq & 15))
+    const unsigned k_row = kb_addr + (unsigned)lq * 256u;
+    const unsigned k_h16 = (unsigned)(half ^ (lq & 15)) << 4;
+    // V values of key kn = rs + 4 half (rs = (r & 3) + 8 (r >> 2)): d = lq and d = lq + 32
+    const unsigned v_base = vb_addr + (unsigned)half * 1024u + (unsigned)(lq & 3) * 4u;
+    const unsigned v_c0 = (unsigned)((lq >> 2) ^ (4 * half));
+    auto v_addr = [&](int rs, int hi) { return v_base + (unsigned)rs * 256u + (((v_c0 ^ (unsigned)(hi * 8)) ^ (unsigned)(rs & 15)) << 4); };
+
+    // key tiles [t_lo, t_hi) of this workgroup: whole groups of four tiles per split, so that a split's four streams
+    // are tiles t_lo + w, t_lo + w + 4, ...
+    const int n_tiles_all = (T + KT - 1) / KT;
+    const int per_split = ((n_tiles_all + a.k_splits - 1) / a.k_splits + NWAVE - 1) / NWAVE * NWAVE;
+    const int t_lo = ks * per_split;
+    const int n_tiles = min(n_tiles_all, t_lo + per_split);
+    const bool live = q0 < a.Tq;
+    if (live && t_lo + wave < n_tiles) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) dma_piece(kbase, Kb, (t_lo + wave) * KT, p);
+    }
+    const long long t_loop = dbg ? (long long)__builtin_readcyclecounter() : 0;
+    for (int t = t_lo + wave; live && t < n_tiles; t += NWAVE) {
+        const int key0 = t * KT;
+        long long tw = dbg ? (long long)__builtin_readcyclecounter() : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // K(t) has landed (the only DMA this wave has in flight)
+        if (dbg) w_k += (long long)__builtin_readcyclecounter() - tw;
+        // ---- S^T = K Q^T, with the eight pieces of V(t) dealt between the MFMAs
+        f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+        f32x4a kc, kn;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kc) : "v"(k_row + k_h16));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kc));
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g + 1 < 8) asm volatile("ds_read_b128 %0, %1" : "=v"(kn) : "v"(k_row + (k_h16 ^ (unsigned)((g + 1) * 32))));
+            __builtin_amdgcn_sched_barrier(0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[0], qf[g].x, s, 0, 0, 0);
+            dma_piece(vbase, Vb, key0, g);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[1], qf[g].y, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[2], qf[g].z, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[3], qf[g].w, s, 0, 0, 0);
+            if (g + 1 < 8) {
+                __builtin_amdgcn_sched_barrier(0);      // the wait stays BEHIND the group's MFMAs: they cover the read's latency
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn));
+                kc = kn;
+            }
+        }
+        // ---- online softmax (flash_attention_kernel's, verbatim)
+        tw = dbg ? (long long)__builtin_readcyclecounter() : 0;
+        float mt = -INFINITY;
+        if (key0 + KT > T) {        // only the last tile has keys past the end (wave-uniform)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (key >= T) s[r] = -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __expf(m_run - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __expf(s[r] - m_new);
+            rs += s[r];
+        }
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+        // once the running maxima have settled alpha is exactly 1.0f in every lane and the rescale (32 multiplies through
+        // the accumulator file) is the identity: skipped then, bit for bit the same result
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        }
+        // ---- O^T += V P^T, with the eight pieces of K(t + 4) dealt between the MFMAs
+        if (dbg) { const long long n = (long long)__builtin_readcyclecounter(); t_soft += n - tw; tw = n; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // V(t) has landed
+        if (dbg) w_v += (long long)__builtin_readcyclecounter() - tw;
+        const bool more = t + NWAVE < n_tiles;
+        float v0, v1, v0n, v1n;
+        asm volatile("ds_read_b32 %0, %1" : "=v"(v0) : "v"(v_addr(0, 0)));
+        asm volatile("ds_read_b32 %0, %1" : "=v"(v1) : "v"(v_addr(0, 1)));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0), "+v"(v1));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (r + 1 < 16) {
+                const int rsn = ((r + 1) & 3) + 8 * ((r + 1) >> 2);
+                asm volatile("ds_read_b32 %0, %1" : "=v"(v0n) : "v"(v_addr(rsn, 0)));
+                asm volatile("ds_read_b32 %0, %1" : "=v"(v1n) : "v"(v_addr(rsn, 1)));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[r], o0, 0, 0, 0);
+            if (more && (r & 1) == 0) dma_piece(kbase, Kb, key0 + NWAVE * KT, r >> 1);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[r], o1, 0, 0, 0);
+            if (r + 1 < 16) {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0n), "+v"(v1n));
+                v0 = v0n;
+                v1 = v1n;
+            }
+        }
+    }
+
+    // merge the four key-stream states through LDS: flash_attention_kernel's (every wave's DMA is drained: a wave leaves
+    // the loop with nothing in flight, and the barrier comes with hipcc's vmcnt(0))
+    const long long t_merge = dbg ? (long long)__builtin_readcyclecounter() : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* Os = lds;                               // [NWAVE][QT][O_LD]
+    float* Ms = lds + NWAVE * QT * O_LD;           // [NWAVE][QT]
+    float* Ls = Ms + NWAVE * QT;                   // [NWAVE][QT]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dd = (r & 3) + 8 * (r >> 2) + 4 * half;
+        Os[(wave * QT + lq) * O_LD + dd] = o0[r];
+        Os[(wave * QT + lq) * O_LD + 32 + dd] = o1[r];
+    }
+    if (half == 0) {
+        Ms[wave * QT + lq] = m_run;
+        Ls[wave * QT + lq] = l_run;
+    }
+    __syncthreads();
+    {
+        const int dd = tid & 63;
+        const int qg = tid >> 6;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = qg * 8 + i;
+            const int qrow = q0 + q;
+            float M = Ms[q];
+#pragma unroll
+            for (int w = 1; w < NWAVE; ++w) M = fmaxf(M, Ms[w * QT + q]);
+            float L = 0.f, acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) {
+                const float mw = Ms[w * QT + q];
+                const float e = mw == -INFINITY ? 0.f : expf(mw - M);     // a stream without keys (short inputs / empty ranges)
+                L += e * Ls[w * QT + q];
+                acc += e * Os[(w * QT + q) * O_LD + dd];
+            }
+            if (a.k_splits == 1) {
+                if (qrow < a.Tq) aout[(long)qrow * a.ldo + head * 64 + dd] = acc / L;
+            } else if (qrow < a.Tq) {
+                // partial state of this key range (flash_attention_kernel's layout; folded by flash_merge_kernel)
+                float* const part_o = batched ? const_cast<float*>(table_at(a.z.res, blockIdx.y)) : a.part_o;
+                float* const part_m = batched ? part_o + (size_t)a.Tq * n_head * a.k_splits * 64 : a.part_m;
+                float* const part_l = batched ? part_m + (size_t)a.Tq * n_head * a.k_splits : a.part_l;
+                const long slot = ((long)qrow * n_head + head) * a.k_splits + ks;
+                part_o[slot * 64 + dd] = acc;
+                if (dd == 0) { part_m[slot] = M; part_l[slot] = L; }
+            }
+        }
+    }
+    if (dbg && tid == 0) {
+        long long* d = a.dbg_clock + 8 * ((long)blockIdx.y * gridDim.x + blockIdx.x);
+        d[0] = t_start; d[1] = t_loop; d[2] = t_merge; d[3] = (long long)__builtin_readcyclecounter();
+        d[4] = w_k; d[5] = w_v; d[6] = t_soft; d[7] = 1;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Encoder self-attention, 64 queries per workgroup WITH the 32-query kernel's arithmetic ("q64x"): eight waves =
@@ -691,6 +924,51 @@ static void launch_enc_q64x(const LaunchCtx& ctx, const FlashArgs& a, const char
     WLK_HIP(hipGetLastError());
 }
 
+// Key-range splits of the wave-private kernel.  376 workgroups (base.en: 47 query tiles x 8 heads) on 256 CUs leave 136
+// CUs idle for half of the launch (two co-resident workgroups share their SIMDs' matrix pipes, so a CU with two takes
+// twice as long as a CU with one); with two key ranges per (query tile, head) there are 752 workgroups of half the
+// length, 2.94 per CU.  Costs: the partial states go through memory and a merge launch follows, and the sum over keys
+// is grouped as (range 0) + (range 1): not bit-identical to the unsplit kernel (the merge kernel's arithmetic, as in the
+// decoder's split cross-attention).  Depends on (T, heads) only - never on the batch.
+int enc_attention_pw_splits(int T, int n_head) {
+    static const int forced = [] {
+        const char* e = getenv("WLK_ENC_KSPLIT");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced > 0) return std::min(forced, 4);
+    // Measured (profiles/r03_attention_ab.txt): base.en back to back 73.5 us unsplit, 69.6 with two ranges incl. the merge
+    // launch - and NOTHING inside the encoder chain (75.7-76.1 vs 74.8-76.1 us per launch, 145.6 vs 145.4 audio-s/s): the
+    // extra launch boundary and the partial states eat the balance.  So the default stays unsplit, which also keeps the
+    // kernel bit-identical to flash_attention_kernel; WLK_ENC_KSPLIT=2 is the A/B switch.
+    (void)T; (void)n_head;
+    return 1;
+}
+
+static void launch_enc_pw(const LaunchCtx& ctx, const FlashArgs& a, const char* tag) {
+    const size_t lds = 64 * 1024;            // 4 waves x (8 KiB K + 8 KiB V); the merge (34 KiB) reuses it
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    WLK_HIP(hipGetDevice(&dev));
+    if (dev < 64 && !attr_set[dev].load(std::memory_order_acquire)) {
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attention_pw_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    const int q_tiles = (a.Tq + QT - 1) / QT;
+    const double nb = std::max(a.batch, 1);
+    KernelScope ks(ctx, tag, nb * 4.0 * a.Tq * (double)a.Tk * 64.0 * a.n_head,
+                   nb * 4.0 * 64.0 * a.n_head * (2.0 * a.Tq + 2.0 * a.Tk));
+    FlashArgs b = a;
+    b.dbg_clock = g_attn_dbg_clock;
+    hipLaunchKernelGGL(enc_attention_pw_kernel, dim3(q_tiles * a.n_head * a.k_splits, std::max(a.batch, 1)), dim3(256), lds,
+                       ctx.stream, b);
+    WLK_HIP(hipGetLastError());
+    if (a.k_splits > 1) {
+        hipLaunchKernelGGL(flash_merge_kernel, dim3(a.Tq, a.n_head, std::max(a.batch, 1)), dim3(64), 0, ctx.stream, a);
+        WLK_HIP(hipGetLastError());
+    }
+}
+
 static void launch_enc_q64(const LaunchCtx& ctx, FlashArgs a, const char* tag) {
     const size_t lds = kAttn2LdsFloats * sizeof(float);     // 34 KB: below the 64 KB default limit, no attribute needed
     const int q_tiles = (a.Tq + QT2 - 1) / QT2;
@@ -749,7 +1027,8 @@ static int enc_attention_variant() {
     static const int v = [] {
         const char* e = getenv("WLK_ENC_ATTN");
         if (e && e[0] == 'q') return (e[1] == '6' && e[2] == '4' && e[3] == 'x') ? 3 : 2;
-        return 0;
+        if (e && e[0] == 'l') return 0;      // "lds": the barrier-staged 32-query kernel (round 1 / 2 default)
+        return 4;                            // "pw": wave-private LDS-DMA staging, bit-identical to "lds"
     }();
     return v;
 }
@@ -774,6 +1053,14 @@ void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out
         launch_enc_q64(ctx, a, "enc_attention");
     } else if (variant == 3) {
         launch_enc_q64x(ctx, a, "enc_attention");
+    } else if (variant == 4) {
+        a.k_splits = split_scratch ? enc_attention_pw_splits(T, n_head) : 1;
+        if (a.k_splits > 1) {
+            a.part_o = split_scratch;
+            a.part_m = split_scratch + (size_t)T * n_head * a.k_splits * 64;
+            a.part_l = a.part_m + (size_t)T * n_head * a.k_splits;
+        }
+        launch_enc_pw(ctx, a, "enc_attention");
     } else {
         launch_flash(ctx, a, "enc_attention");
     }
@@ -788,6 +1075,9 @@ void launch_encoder_attention_batched(const LaunchCtx& ctx, const PtrTable& z, i
     for (int i = 0; i < batch; ++i) have_scratch &= z.res[i] != nullptr;
     if (enc_attention_variant() == 3) {
         launch_enc_q64x(ctx, a, "enc_attention");
+    } else if (enc_attention_variant() == 4) {
+        a.k_splits = have_scratch ? enc_attention_pw_splits(T, n_head) : 1;   // one session's split count, whatever the batch
+        launch_enc_pw(ctx, a, "enc_attention");
     } else if (enc_attention_variant() == 2 && have_scratch) {
         // the split count of ONE session, whatever the batch: a session's arithmetic (and its rounding) must not depend
         // on who else encodes at the same time; B sessions are B whole copies of a balanced grid anyway

@@ -272,7 +272,9 @@ struct FlashArgs {
     float* part_o = nullptr;
     float* part_m = nullptr;
     float* part_l = nullptr;
+    long long* dbg_clock = nullptr;   // probe only (enc_attention_pw_kernel): 8 s_memtime figures per workgroup
 };
+extern long long* g_attn_dbg_clock;   // set by the timing probe (diag.hip); nullptr otherwise
 size_t flash_split_scratch_floats(int rows, int n_head, int k_splits);
 // encoder self-attention over qkv[T][3d] (q and k pre-scaled), out[T][d]
 void launch_encoder_attention(const LaunchCtx& ctx, const float* qkv, float* out, int T, int d, int n_head,

@@ -157,6 +157,12 @@ int wlk_diag_encoder_attention_time(int t, int d, int n_head, int k_splits, int 
         WLK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         LaunchCtx ctx{st, nullptr};
         auto go = [&]() { launch_encoder_attention(ctx, Q.p, O.p, t, d, n_head, k_splits, S.p); };
+        long long* dbg = nullptr;
+        if (getenv("WLK_ATTN_CLOCKS")) {
+            WLK_HIP(hipMalloc(reinterpret_cast<void**>(&dbg), 8 * 4096 * sizeof(long long)));
+            WLK_HIP(hipMemset(dbg, 0, 8 * 4096 * sizeof(long long)));
+            g_attn_dbg_clock = dbg;
+        }
         go();
         WLK_HIP(hipStreamSynchronize(st));
         hipEvent_t e0, e1;
@@ -169,6 +175,25 @@ int wlk_diag_encoder_attention_time(int t, int d, int n_head, int k_splits, int 
         float ms = 0.f;
         WLK_HIP(hipEventElapsedTime(&ms, e0, e1));
         *us_per_launch = 1e3f * ms / (float)reps;
+        if (dbg) {
+            g_attn_dbg_clock = nullptr;
+            std::vector<long long> h(8 * 4096);
+            WLK_HIP(hipMemcpy(h.data(), dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            double pro = 0, loop = 0, mer = 0, wk = 0, wv = 0, sm = 0;
+            long long t0 = 0, t1 = 0;
+            int n = 0;
+            for (int i = 0; i < 4096; ++i) {
+                if (!h[8 * i + 7]) continue;
+                if (!n || h[8 * i] < t0) t0 = h[8 * i];
+                if (!n || h[8 * i + 3] > t1) t1 = h[8 * i + 3];
+                pro += h[8 * i + 1] - h[8 * i]; loop += h[8 * i + 2] - h[8 * i + 1]; mer += h[8 * i + 3] - h[8 * i + 2];
+                wk += h[8 * i + 4]; wv += h[8 * i + 5]; sm += h[8 * i + 6];
+                ++n;
+            }
+            if (n) fprintf(stderr, "[attn clocks] %d workgroups (wave 0): prologue %.0f, key loop %.0f (K waits %.0f, V waits %.0f, softmax %.0f), "
+                           "merge %.0f ticks (mean); first start -> last end %lld ticks\n", n, pro / n, loop / n, wk / n, wv / n, sm / n, mer / n, t1 - t0);
+            (void)hipFree(dbg);
+        }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         (void)hipStreamDestroy(st);
