@@ -845,7 +845,11 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
         GemmArgs q;
         q.lda = d; q.W = L.xqw; q.bias = L.xqb; q.C = s->dq; q.ldc = d; q.M = R; q.N = d; q.K = d;
         q.flags = kGemmScaleCols; q.scale = scale; q.scale_cols = d;
-        if (fused) {
+        // decode steps: the split cross-attention kernel derives its head's query values itself (same arithmetic) - one
+        // launch less per layer
+        const bool fold_xq = fused && R <= 8 && !s->debug && cross_split_folds_query(d);
+        if (fold_xq) {
+        } else if (fused) {
             q.A = s->dx; q.ln_gamma = L.lnxw; q.ln_beta = L.lnxb;
             launch_gemv(c, q, "dec_lnx_xq");
         } else {
@@ -887,6 +891,9 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
             ca.ring_rows = s->ring_rows;
             ca.n_beam = s->beam;
             ca.qk_debug = s->debug ? s->qk_debug + (size_t)i * s->max_rows * H * T : nullptr;
+            if (fold_xq) {
+                ca.xq_x = s->dx; ca.xq_w = L.xqw; ca.xq_b = L.xqb; ca.xq_gamma = L.lnxw; ca.xq_beta = L.lnxb; ca.xq_scale = scale;
+            }
             if (R <= 8 && !s->debug) {
                 float* sc = s->xsplit;
                 float* pm = sc + (size_t)8 * H * T;

@@ -314,8 +314,19 @@ struct CrossAttnArgs {
     // step_rows[r].ring at step_rows[r].ring_row (one beam per row)
     const StepRow* step_rows = nullptr;
     long kv_off = 0;
+    // decode steps (split kernel only): the query projection folded into the kernel's prologue - q is ignored and every
+    // workgroup derives its head's 64 query values itself, q_h = scale * (Wq[64 h .. 64 h + 64, :] . LN(x_row) + b),
+    // with the single-row GEMV's arithmetic (gemv1_f32_kernel: lane-strided fmaf chains, xor-shuffle folds), so the
+    // values are bit-identical to the separate dec_lnx_xq launch this replaces
+    const float* xq_x = nullptr;       // [rows][d] residual stream
+    const float* xq_w = nullptr;       // [d][d]
+    const float* xq_b = nullptr;
+    const float* xq_gamma = nullptr;
+    const float* xq_beta = nullptr;
+    float xq_scale = 1.f;
 };
 void launch_decoder_cross_attention(const LaunchCtx& ctx, const CrossAttnArgs& a);
+bool cross_split_folds_query(int d);   // can the split kernel take the query projection (d % 256 == 0, d <= 2048)?
 // decode steps: keys split over several workgroups per (row, head) + merge; scratch layout is
 // [scores rows*H*T | pm rows*H*S | pl rows*H*S | po rows*H*S*64] (cross_split_scratch_floats)
 void launch_decoder_cross_attention_split(const LaunchCtx& ctx, const CrossAttnArgs& a, float* scores, float* pm,

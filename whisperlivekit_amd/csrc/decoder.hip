@@ -9,6 +9,8 @@
 // reductions for the softmax, and keeping scores in LDS.
 #include <cstddef>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace wlk {
@@ -434,6 +436,8 @@ constexpr int kCrossSplit = 8;
 static_assert(kCrossSplit == kCrossSplitWays, "gemv1's merged operand load assumes the same split count");
 constexpr int kCrossUnroll = 12;   // key-row loads in flight per wave: covers ceil(1500/8)=188 keys / 16
 
+// UB = float4 chunks of K per lane in the folded query projection (d <= 256 UB floats); 0 = q comes from memory
+template <int UB>
 __global__ __launch_bounds__(256) void cross_split_kernel(CrossAttnArgs a, float* __restrict__ scores,
                                                           float* __restrict__ pm, float* __restrict__ pl,
                                                           float* __restrict__ po) {
@@ -446,14 +450,12 @@ __global__ __launch_bounds__(256) void cross_split_kernel(CrossAttnArgs a, float
     const int sub = lane & 15, kq = lane >> 4;
     const int chunk = (a.T + kCrossSplit - 1) / kCrossSplit;
     const int k_lo = ks * chunk, k_hi = min(a.T, k_lo + chunk);
-    if (tid < 64) qs[tid] = a.q[(long)row * a.d + head * 64 + tid];
-    __syncthreads();
-    const float4 q4 = reinterpret_cast<const float4*>(qs)[sub];
     const float* kbase = a.step_rows ? a.step_rows[row].cross_kv + a.kv_off : a.k;
     const float* kb = kbase + head * 64 + sub * 4;
     const float* vb = (a.step_rows ? kbase + a.d : a.v) + head * 64 + sub * 4;
     float* srow = scores + ((long)row * a.n_head + head) * a.T;
 
+    // the key rows do not depend on the query: all of them are requested before the query is derived / fetched
     float4 kk[kCrossUnroll];
 #pragma unroll
     for (int u = 0; u < kCrossUnroll; ++u) {
@@ -462,6 +464,92 @@ __global__ __launch_bounds__(256) void cross_split_kernel(CrossAttnArgs a, float
         const float4 t = *reinterpret_cast<const float4*>(kb + (long)(ok ? j : k_lo) * a.ldkv);
         kk[u] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if constexpr (UB == 0) {
+        if (tid < 64) qs[tid] = a.q[(long)row * a.d + head * 64 + tid];
+    } else {
+        // q_h = scale * (Wq[64 head + i, :] . LN(x_row) + b), i = 0..63: wave w derives i = 16 w .. 16 w + 15.  Statement for
+        // statement gemv1_f32_kernel's arithmetic (fused LayerNorm statistics over lane-strided scalars, lane-strided
+        // float4 fmaf chains, xor-shuffle folds), which is also what every row of the multi-row GEMV computes.
+        const int K = a.d, K4 = K >> 2;
+        const float* xrow = a.xq_x + (long)row * K;
+        float4 x[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int c = lane + 64 * u;
+            x[u] = *reinterpret_cast<const float4*>(xrow + (c < K4 ? c : 0) * 4);
+        }
+        {
+            float v[UB * 4];
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < UB * 4; ++i) {
+                const int c = lane + 64 * i;
+                v[i] = c < K ? xrow[c] : 0.f;
+                sum += v[i];
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+            const float mean = sum / (float)K;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < UB * 4; ++i) {
+                const float t = (lane + 64 * i) < K ? v[i] - mean : 0.f;
+                sq += t * t;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+            const float rstd = 1.0f / sqrtf(sq / (float)K + 1e-5f);
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int c = lane + 64 * u;
+                const int cc = (c < K4 ? c : 0) * 4;
+                const float4 ga = *reinterpret_cast<const float4*>(a.xq_gamma + cc);
+                const float4 be = *reinterpret_cast<const float4*>(a.xq_beta + cc);
+                x[u].x = (x[u].x - mean) * rstd * ga.x + be.x;
+                x[u].y = (x[u].y - mean) * rstd * ga.y + be.y;
+                x[u].z = (x[u].z - mean) * rstd * ga.z + be.z;
+                x[u].w = (x[u].w - mean) * rstd * ga.w + be.w;
+            }
+        }
+        constexpr int NPASS = UB <= 2 ? 4 : (UB <= 4 ? 2 : 1);      // outputs whose weight rows are in flight together
+#pragma unroll
+        for (int i0 = 0; i0 < 16; i0 += NPASS) {
+            float4 w[NPASS][UB];
+#pragma unroll
+            for (int r = 0; r < NPASS; ++r) {
+                const int n = head * 64 + wave * 16 + i0 + r;
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int c = lane + 64 * u;
+                    w[r][u] = *reinterpret_cast<const float4*>(a.xq_w + (long)n * K + (c < K4 ? c : 0) * 4);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NPASS; ++r) {
+                float acc = 0.f;
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    if (lane + 64 * u < K4) {
+                        acc = fmaf(w[r][u].x, x[u].x, acc);
+                        acc = fmaf(w[r][u].y, x[u].y, acc);
+                        acc = fmaf(w[r][u].z, x[u].z, acc);
+                        acc = fmaf(w[r][u].w, x[u].w, acc);
+                    }
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+                if (lane == 0) {
+                    const int n = head * 64 + wave * 16 + i0 + r;
+                    float v = acc;
+                    if (a.xq_b) v += a.xq_b[n];
+                    v *= a.xq_scale;
+                    qs[wave * 16 + i0 + r] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const float4 q4 = reinterpret_cast<const float4*>(qs)[sub];
     float mx = -INFINITY;
 #pragma unroll
     for (int u = 0; u < kCrossUnroll; ++u) {
@@ -562,8 +650,16 @@ void launch_decoder_cross_attention_split(const LaunchCtx& ctx, const CrossAttnA
     if ((a.T + kCrossSplit - 1) / kCrossSplit > kCrossUnroll * 16) throw std::invalid_argument("cross-attention: T too large");
     {
         KernelScope ks(ctx, "dec_cross_split", 4.0 * a.rows * (double)a.T * a.d, 4.0 * 2.0 * a.rows * (double)a.T * a.d);
-        hipLaunchKernelGGL(cross_split_kernel, dim3(a.rows, a.n_head, kCrossSplit), dim3(256), 0, ctx.stream, a, scores,
-                           pm, pl, po);
+        const dim3 grid(a.rows, a.n_head, kCrossSplit);
+        if (a.xq_w) {
+            if (!cross_split_folds_query(a.d)) throw std::invalid_argument("cross-attention: cannot fold the query projection");
+            const int ub = a.d / 256;
+            if (ub <= 2) hipLaunchKernelGGL(cross_split_kernel<2>, grid, dim3(256), 0, ctx.stream, a, scores, pm, pl, po);
+            else if (ub <= 4) hipLaunchKernelGGL(cross_split_kernel<4>, grid, dim3(256), 0, ctx.stream, a, scores, pm, pl, po);
+            else hipLaunchKernelGGL(cross_split_kernel<8>, grid, dim3(256), 0, ctx.stream, a, scores, pm, pl, po);
+        } else {
+            hipLaunchKernelGGL(cross_split_kernel<0>, grid, dim3(256), 0, ctx.stream, a, scores, pm, pl, po);
+        }
         WLK_HIP(hipGetLastError());
     }
     if (merge) {   // beam-1 steps fold the merge into the out-projection GEMV (GemmArgs::mg_*)
@@ -571,6 +667,17 @@ void launch_decoder_cross_attention_split(const LaunchCtx& ctx, const CrossAttnA
         hipLaunchKernelGGL(cross_merge_kernel, dim3(a.rows, a.n_head), dim3(256), 0, ctx.stream, a, scores, pm, pl, po);
         WLK_HIP(hipGetLastError());
     }
+}
+// Opt-in (WLK_XQ_FOLD=1).  Measured on MI355X, base.en, alternating runs on one box (profiles/r03_ab_xq_fold.txt): with the
+// fold a stream runs 141.2 / 142.0 audio-s/s, without it 144.7 / 146.4 - the launch it saves (46 instead of 52 per
+// step) is cheaper than 64 workgroups each pulling their head's 128 KB of Wq through L2 in front of their keys.  All
+// golden streams are bit-identical either way (the fold reproduces the GEMV's arithmetic).
+bool cross_split_folds_query(int d) {
+    static const bool on = [] {
+        const char* e = getenv("WLK_XQ_FOLD");
+        return e && e[0] == '1';
+    }();
+    return on && d % 256 == 0 && d >= 256 && d <= 2048;
 }
 size_t cross_split_scratch_floats(int rows, int n_head, int T) {
     return (size_t)rows * n_head * ((size_t)T + kCrossSplit * (2 + 64));

@@ -129,7 +129,8 @@ void wlk_engine::enqueue_decoder(int R, bool from_block) {
         GemmArgs qq;
         qq.A = x; qq.lda = d; qq.W = L.xqw; qq.bias = L.xqb; qq.C = q; qq.ldc = d; qq.M = R; qq.N = d; qq.K = d;
         qq.flags = kGemmScaleCols; qq.scale = scale; qq.scale_cols = d; qq.ln_gamma = L.lnxw; qq.ln_beta = L.lnxb;
-        launch_gemv(c, qq, "dec_lnx_xq");
+        const bool fold_xq = cross_split_folds_query(d);      // the split kernel derives the query values itself
+        if (!fold_xq) launch_gemv(c, qq, "dec_lnx_xq");
         CrossAttnArgs ca{};
         ca.q = q; ca.k = nullptr; ca.v = nullptr; ca.ldkv = (long)D.n_text_layer * 2 * d; ca.out = att;
         ca.rows = R; ca.d = d; ca.n_head = H; ca.T = T;
@@ -137,6 +138,9 @@ void wlk_engine::enqueue_decoder(int R, bool from_block) {
         ca.ring = nullptr; ca.ring_row = nullptr; ca.beam_of_row = nullptr;
         ca.ring_rows = ctx_len + kAlignWindow; ca.n_beam = 1; ca.qk_debug = nullptr;
         ca.step_rows = rows_dev; ca.kv_off = (long)i * 2 * d;
+        if (fold_xq) {
+            ca.xq_x = x; ca.xq_w = L.xqw; ca.xq_b = L.xqb; ca.xq_gamma = L.lnxw; ca.xq_beta = L.lnxb; ca.xq_scale = scale;
+        }
         launch_decoder_cross_attention_split(c, ca, sc, pm, pl, po, true);
         GemmArgs xo;
         xo.A = att; xo.lda = d; xo.W = L.xoutw; xo.bias = L.xoutb; xo.C = x; xo.ldc = d; xo.M = R; xo.N = d; xo.K = d;
