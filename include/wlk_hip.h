@@ -298,6 +298,21 @@ int wlk_diag_linear(const float* a, int64_t lda, int64_t a_floats, const float* 
  * (previous frame), -1 in row 0 / column 0 - the array dtw_cpu hands to `backtrace` (:58-79).  Same strict comparisons
  * (ties go left) and one fp32 add per cell.  n_rows <= 1024.  Host pointers; synchronous. */
 int wlk_dtw(int device, const float* x, int32_t n_rows, int32_t n_cols, int8_t* trace);
+/* Encode a log-mel SEGMENT instead of the session's audio: `mel` is [n_mels][3000] as `whisper.transcribe()` slices it
+ * out of the file's log-mel and hands it to the model / to `find_alignment` (whisperlivekit/whisper/transcribe.py,
+ * timing.py:163-171).  Runs encoder + cross-K/V; the session then decodes against it like after wlk_encode.  Host
+ * pointer, synchronous upload. */
+int wlk_encode_mel(wlk_session* s, const float* mel, int32_t n_frames);
+/* The device half of `find_alignment` (whisperlivekit/whisper/timing.py:163-218) on an encoded beam-1 session:
+ * `tokens` = [sot sequence (n_sot ids), <|notimestamps|>, text tokens, <|endoftext|>] (n_tokens ids).  One decoder pass
+ * over them; token_probs[i] = softmax(logits[n_sot + i, :eot])[text token i]; the alignment heads' cross-attention
+ * scores -> softmax over the first num_frames / 2 positions (x qk_scale) -> z-score over the token axis -> median-7
+ * along the frames -> head mean -> rows [n_sot, n_tokens - 1) negated = the cost matrix [n_text + 1][num_frames / 2]
+ * (copied to `cost` when not NULL) -> dtw: `trace` receives (n_text + 2) x (num_frames / 2 + 1) step codes as wlk_dtw
+ * returns them.  Walking the path back and cutting it into words stays on the host (timing.py:216-243).  The session
+ * needs a new prefill afterwards (its alignment window holds this call's scores). */
+int wlk_find_alignment(wlk_session* s, const int64_t* tokens, int32_t n_tokens, int32_t n_sot, int32_t eot,
+                       int32_t num_frames, float qk_scale, float* cost, int8_t* trace, float* token_probs);
 
 /* kernel-tuning probe: average microseconds per launch over `reps` back-to-back launches of one linear layer on
  * device-resident pseudo-random operands (same `force_gemv` meaning as wlk_diag_linear) */

@@ -51,7 +51,11 @@ def main(out_md, out_json, dirs):
             r["mfma_util"] = r["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * r["avg_us_under_pmc"] * 1e-6 * 2.4e9)
         rows[k] = r
     order = sorted(rows, key=lambda k: -rows[k]["avg_us_under_pmc"] * rows[k]["launches_seen"])
-    json.dump({k: rows[k] for k in order}, open(out_json, "w"), indent=1)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from export_profile import provenance
+    js = {k: rows[k] for k in order}
+    js["_provenance"] = provenance()
+    json.dump(js, open(out_json, "w"), indent=1)
     lines = ["# rocprofv3 PMC passes over `python bench.py` (per-kernel means per launch)", "",
              "FETCH_SIZE/WRITE_SIZE are KiB; HBM read = FETCH_SIZE x 1024 x 2 (gfx950 half-count correction, MI355X_MICROARCH.md), "
              "write = WRITE_SIZE x 1024 (uncalibrated). Durations are under counter collection (slower than the timed runs).", "",

@@ -8,6 +8,14 @@ import sqlite3
 import sys
 
 
+def provenance():
+    """Where and when: the commit the measured tree was built from (GRAFT_GIT_HEAD is exported by the job script: the GPU
+    box has no .git) and the time of the export."""
+    import os
+    import time
+    return dict(git_head=os.environ.get("GRAFT_GIT_HEAD", "unknown"), exported=time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()))
+
+
 def main(db, out, title):
     c = sqlite3.connect(db)
     rows = c.execute("select name,total_calls,total_duration,average,percentage from top_kernels").fetchall()
@@ -23,6 +31,7 @@ def main(db, out, title):
     open(out, "w").write("\n".join(lines) + "\n")
     import json
     js = {name: dict(calls=int(calls), total_us=float(tot), avg_us=float(avg), pct=float(pct)) for name, calls, tot, avg, pct in rows}
+    js["_provenance"] = provenance()
     json.dump(js, open(out.rsplit(".", 1)[0] + ".json", "w"), indent=0)   # bench.py reads avg_us of the dominant kernel
     print(out, "written;", len(rows), "kernels")
 

@@ -8,8 +8,10 @@ import numpy as np
 import pytest
 
 import helpers as H
+import helpers
 from oracle import timing_oracle
 from whisperlivekit_amd import timing
+from whisperlivekit_amd.dims import ALIGNMENT_HEADS, MODEL_DIMS
 
 KAT = H.golden_json("word_timing_kat.json")
 
@@ -96,3 +98,46 @@ def test_oracle_alignment_cost_matches_reference(case):
     np.testing.assert_array_equal(path, np.array(case["path"]))
     got = timing.word_timings(path[0], path[1], case["words"], case["word_tokens"], probs)
     assert [(t.word, t.start, t.end) for t in got] == [(w["word"], w["start"], w["end"]) for w in case["timings"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", KAT["find_alignment"], ids=lambda c: c["text"].strip()[:12])
+def test_hip_find_alignment_matches_the_reference(case):
+    """The device half of find_alignment (wlk_encode_mel + wlk_find_alignment) on the seeded micro Whisper the reference
+    ran: the cost matrix it handed to its dtw (2e-5), the SAME warping path, the token probabilities, and through the
+    host tail the same words with the same times."""
+    from whisperlivekit_amd.engine import HipWhisperModel
+    dims = MODEL_DIMS["micro.en"]
+    model = HipWhisperModel.from_state_dict(dims, helpers.synth_sd("micro.en", 0), ALIGNMENT_HEADS["micro.en"], device=0)
+    sess = model.new_session(beam=1, batched=False)
+    try:
+        mel = np.random.default_rng(case["mel_seed"]).standard_normal((dims.n_mels, 3000)).astype(np.float32)
+        sess.encode_mel(mel)
+        tokens = [*case["sot_sequence"], case["no_timestamps"], *case["text_tokens"], case["eot"]]
+        trace, probs, cost = sess.find_alignment(tokens, len(case["sot_sequence"]), case["eot"], case["num_frames"], want_cost=True)
+        want = np.array(case["matrix"], dtype=np.float32).reshape(case["matrix_shape"])
+        assert cost.shape == want.shape
+        np.testing.assert_allclose(cost, want, rtol=0, atol=2e-5)
+        np.testing.assert_array_equal(timing.backtrace(trace), np.array(case["path"]))
+        np.testing.assert_allclose(probs, case["text_token_probs"], rtol=2e-4, atol=1e-9)
+
+        class Tok:       # what find_alignment needs of a tokenizer, with the word split the reference computed
+            sot_sequence, no_timestamps, eot = case["sot_sequence"], case["no_timestamps"], case["eot"]
+
+            @staticmethod
+            def split_to_word_tokens(_tokens):
+                return case["words"], case["word_tokens"]
+
+        got = timing.find_alignment(sess, Tok, case["text_tokens"], mel, case["num_frames"])
+        assert [t.word for t in got] == [w["word"] for w in case["timings"]]
+        np.testing.assert_array_equal([t.start for t in got], [w["start"] for w in case["timings"]])
+        np.testing.assert_array_equal([t.end for t in got], [w["end"] for w in case["timings"]])
+        np.testing.assert_allclose([t.probability for t in got], [w["probability"] for w in case["timings"]], rtol=2e-4)
+        # the session keeps working as a streaming session afterwards: a fresh encode + prefill
+        sess.append(np.zeros(16000, np.float32))
+        sess.encode()
+        sess.decode(np.array([[50257, 50362, 1000]]), first=True, sot_index=0)
+        sess.select([], [], [], 2, 50)
+    finally:
+        sess.close()
+        model.close()

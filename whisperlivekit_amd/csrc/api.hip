@@ -439,6 +439,7 @@ int wlk_session_destroy(wlk_session* s) {
         if (e) (void)hipGraphExecDestroy(e);
     if (s->topk_scratch) (void)hipFree(s->topk_scratch);
     if (s->pcm16_dev) (void)hipFree(s->pcm16_dev);
+    if (s->wa_buf) (void)hipFree(s->wa_buf);
     if (s->esplit) (void)hipFree(s->esplit);
     if (s->pinned) (void)hipHostFree(s->pinned);
     if (s->dec_stage) (void)hipHostFree(s->dec_stage);
@@ -640,7 +641,7 @@ extern "C++" std::string wlk_encode_precheck(const wlk_session* s, const wlk_mod
 }
 
 extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const LaunchCtx& c,
-                                   std::vector<int>& content_out) {
+                                   std::vector<int>& content_out, bool mel_given) {
     const int B = (int)group.size();
     if (B < 1 || B > kMaxBatch) throw std::invalid_argument("encode: bad group size");
     wlk_model* m = group[0]->m;
@@ -650,6 +651,10 @@ extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const
     for (int i = 0; i < B; ++i) {
         wlk_session* s = group[i];
         if (s->m != m) throw std::invalid_argument("encode: sessions of different models in one group");
+        if (mel_given) {           // the caller put a 3000-frame log-mel segment into mel_t (word_align.hip)
+            content_out[i] = D.n_audio_ctx;
+            continue;
+        }
         const int N = s->audio_len;
         const int n_total = (N + kPadSamples) / kHop;               // stft frames minus the dropped last one
         int n_active = N > 0 ? (N + kNFft / 2 + kHop - 1) / kHop : 0;  // frames that see a non-zero sample
@@ -860,7 +865,7 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
         const int* ranks_l = m->n_align > 0 ? m->head_rank + (size_t)i * H : nullptr;
         bool merged_xout = false;
         GemmArgs xo_mg;   // carries the split-form operand description to the out projection when merged_xout
-        if (R > 8 && !s->debug) {
+        if ((R > 8 || s->align_raw_scores) && !s->debug) {
             // prefill: MFMA flash kernel shares every K/V tile between 32 query rows
             FlashArgs fa;
             fa.q = s->dq; fa.ldq = d;
@@ -919,7 +924,7 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
         launch_linear(c, xo, "dec_xout");
         transformer_mlp(c, L, s->dx, s->dh, s->dmlp, R, d, "dec_ln2", "dec_fc1", "dec_fc2");
     }
-    if (scores_dumped && m->n_align > 0)
+    if (scores_dumped && m->n_align > 0 && !s->align_raw_scores)     // find_alignment normalises the raw scores itself
         launch_ring_softmax(c, s->ring, s->ring_row, s->beam_of_row, m->all_ranks, m->n_align, R, s->ring_rows, s->beam, T);
     // final LayerNorm + vocabulary projection only for the rows the policy reads
     GemmArgs lg;

@@ -220,6 +220,11 @@ struct wlk_session {
     uint64_t step_ns = 0, step_launch_ns = 0, step_count = 0;   // WLK_STEP_TIMING=1: printed when the session is destroyed
 
     wlk::LaunchCtx ctx() { return wlk::LaunchCtx{stream, prof_on ? &prof : nullptr}; }
+    // word-timestamp alignment (word_align.hip): the prefill leaves the alignment heads' raw scores in the window, and
+    // its workspace (grown on demand)
+    bool align_raw_scores = false;
+    float* wa_buf = nullptr;
+    size_t wa_cap = 0;
     wlk_engine* engine = nullptr;   // set by wlk_engine_attach: single-token steps run batched with the other attached sessions
 };
 
@@ -278,7 +283,9 @@ int wlk_step_select(wlk_session* s, int64_t token, const int32_t* adj_ids, const
 int wlk_select_first(wlk_session* s, int no_speech_token, const int32_t* adj_row, const int32_t* adj_ids,
                      const float* adj_deltas, int n_adj, int k, int content_mel_len, float* no_speech_host,
                      float* top_logprobs_host, int32_t* top_ids_host, int32_t* frames_host);
-void wlk_encode_group(const std::vector<wlk_session*>& group, const wlk::LaunchCtx& c, std::vector<int>& content_out);
+// mel_given: mel_t of every session already holds the log-mel to encode (wlk_encode_mel); the mel kernels are skipped
+void wlk_encode_group(const std::vector<wlk_session*>& group, const wlk::LaunchCtx& c, std::vector<int>& content_out,
+                      bool mel_given = false);
 // host-side preconditions of one session's encode (model, frame capacity); empty string = fine.  The encode lane asks
 // this per request before it stacks requests into one chain.
 std::string wlk_encode_precheck(const wlk_session* s, const wlk_model* m);

@@ -271,6 +271,33 @@ class HipSession:
         _lib.check(self.lib.wlk_encode(self._h, C.byref(cml)))
         return cml.value
 
+    def encode_mel(self, mel: np.ndarray) -> None:
+        """Encode a [n_mels, 3000] log-mel segment as whisper.transcribe() / find_alignment hand it to the model
+        (instead of the session's own audio): encoder + cross-K/V."""
+        mel = np.ascontiguousarray(_as_f32(mel))
+        if mel.shape != (self.model.dims.n_mels, 3000):
+            raise ValueError(f"encode_mel: expected [{self.model.dims.n_mels}, 3000], got {mel.shape}")
+        _lib.check(self.lib.wlk_encode_mel(self._h, mel.ctypes.data_as(C.POINTER(C.c_float)), 3000))
+
+    def find_alignment(self, tokens: Sequence[int], n_sot: int, eot: int, num_frames: int, qk_scale: float = 1.0,
+                       want_cost: bool = False):
+        """Device half of whisper/timing.py:find_alignment on the encoded session.  ``tokens`` = [sot sequence (n_sot
+        ids), <|notimestamps|>, text tokens, <|endoftext|>].  -> (dtw step codes [(n_text + 2), num_frames // 2 + 1],
+        token probabilities [n_text], cost matrix [n_text + 1, num_frames // 2] or None)."""
+        toks = np.ascontiguousarray(np.asarray(tokens, dtype=np.int64))
+        n_text = len(toks) - n_sot - 2
+        if n_text < 1:
+            raise ValueError("find_alignment: no text tokens")
+        f = num_frames // 2
+        trace = np.empty((n_text + 2, f + 1), dtype=np.int8)
+        probs = np.empty(n_text, dtype=np.float32)
+        cost = np.empty((n_text + 1, f), dtype=np.float32) if want_cost else None
+        _lib.check(self.lib.wlk_find_alignment(
+            self._h, toks.ctypes.data_as(C.POINTER(C.c_int64)), len(toks), int(n_sot), int(eot), int(num_frames),
+            float(qk_scale), cost.ctypes.data_as(C.POINTER(C.c_float)) if want_cost else None,
+            trace.ctypes.data_as(C.POINTER(C.c_int8)), probs.ctypes.data_as(C.POINTER(C.c_float))))
+        return trace, probs, cost
+
     def decode(self, tokens: np.ndarray, first: bool, sot_index: int = 0) -> None:
         t = np.ascontiguousarray(tokens, dtype=np.int64)
         if t.ndim != 2:

@@ -102,6 +102,30 @@ def word_timings(text_indices, time_indices, words: Sequence[str], word_tokens: 
     return out
 
 
+def find_alignment(session, tokenizer, text_tokens: Sequence[int], mel, num_frames: int, *, medfilt_width: int = 7,
+                   qk_scale: float = 1.0) -> List[WordTiming]:
+    """whisper/timing.py:163-243 with the model replaced by a HIP session (engine.HipSession, beam 1): the decoder pass,
+    token probabilities, attention normalisation and the DTW recurrence run on the GPU (wlk_find_alignment); the path
+    is walked back and cut into words here.  ``mel`` is the [n_mels, 3000] segment the reference passes (None: the
+    session is already encoded, e.g. from its own audio).  ``tokenizer`` needs ``sot_sequence``, ``no_timestamps``,
+    ``eot`` and ``split_to_word_tokens`` (the reference's Tokenizer or this package's)."""
+    if medfilt_width != 7:
+        raise ValueError("find_alignment: the device kernel implements the reference's default median width 7")
+    text_tokens = [int(t) for t in text_tokens]
+    if len(text_tokens) == 0:
+        return []
+    if mel is not None:
+        if hasattr(mel, "detach"):
+            mel = mel.detach().cpu().numpy()
+        session.encode_mel(np.asarray(mel))
+    sot = [int(t) for t in tokenizer.sot_sequence]
+    tokens = [*sot, int(tokenizer.no_timestamps), *text_tokens, int(tokenizer.eot)]
+    trace, probs, _ = session.find_alignment(tokens, len(sot), int(tokenizer.eot), int(num_frames), qk_scale)
+    text_indices, time_indices = backtrace(trace)
+    words, word_tokens = tokenizer.split_to_word_tokens(text_tokens + [int(tokenizer.eot)])
+    return word_timings(text_indices, time_indices, words, word_tokens, probs.tolist())
+
+
 def merge_punctuations(alignment: List[WordTiming], prepended: str = PREPEND_PUNCTUATIONS,
                        appended: str = APPEND_PUNCTUATIONS) -> None:
     """timing.py:245-276, in place: opening punctuation joins the word after it (scanning backwards, so runs chain),
