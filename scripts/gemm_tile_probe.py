@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROBLEMS = [("fc1", 1500, 2048, 512, 1), ("qkv", 1500, 1536, 512, 4), ("fc2", 1500, 512, 2048, 2), ("out", 1500, 512, 512, 2),
-            ("fc1x8", 12000, 2048, 512, 1), ("fc2x8", 12000, 512, 2048, 2)]
+            ("conv2", 1500, 512, 1536, 3), ("fc2x2", 3000, 512, 2048, 2)]
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)
     from whisperlivekit_amd import _lib
@@ -26,8 +26,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 
 print("config".ljust(16) + " | ".join(t.ljust(19) for t, *_ in PROBLEMS))
 configs = [("64x64 kernel", None, 3)]
-for ks in (64, 103, 104):       # 64: compiler-scheduled k-split, 2 x 64-deep slabs; 103 / 104: k-pipe, ring of 3 / 4 32-deep slabs
-    for tm, tn in ((3, 4), (3, 3), (3, 2), (3, 1), (2, 4), (2, 2), (4, 2)):
+for ks in (64, 103, 104, 206):  # 64: compiler-scheduled k-split, 2 x 64-deep slabs; 103 / 104: k-pipe, ring of 3 / 4 32-deep slabs;
+    for tm, tn in ((3, 4), (3, 3), (3, 2), (3, 1), (2, 4), (2, 2), (4, 2)):   # 206: two slabs per trip, ring of 6
+        if ks == 206 and (tm, tn) not in ((3, 1), (2, 2)):
+            continue
         configs.append((f"{tm}x{tn} ks{ks}", f"{tm},{tn},{ks},0", 0))
 for name, force, mode in configs:
     env = dict(os.environ)

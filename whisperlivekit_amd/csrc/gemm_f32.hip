@@ -693,8 +693,12 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_ksplit_kernel(GemmArgs g) {
 // drains everything before the fold reuses LDS.
 // -------------------------------------------------------------------------------------------------
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <int TM, int TN, int NB>
+// NB = ring slots (32-deep slabs), STEPS = slabs per trip (= per barrier).  Thin tiles take STEPS = 2: a trip of 96 x 32 is
+// only 12 MFMAs (768 cycles) per slab, and the ~180 cycles per trip in which the wave cannot feed the matrix pipe (the
+// barrier, the fragment-read issue, DMA issue slots longer than an MFMA's shadow, loop control) were 19 % of its loop.
+template <int TM, int TN, int NB, int STEPS>
 struct KPipeCfg {
+    static_assert(NB % STEPS == 0 && NB / STEPS >= 2, "the ring holds whole trips, at least two");
     static constexpr int BM = 32 * TM, BN = 32 * TN, KS = 32;
     static constexpr int A_PIECES = BM / 8, W_PIECES = BN / 8;                   // 1 KiB pieces per slab (8 rows x 128 B)
     static constexpr int PIECES_PER_WAVE = (A_PIECES + W_PIECES) / 4;
@@ -717,10 +721,29 @@ __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N < 0, "add the vmcnt literal");
 }
 
-template <int TM, int TN, int NB>
+// s_waitcnt lgkmcnt(0) tied to the N fragment registers it makes valid (in/out operands: no MFMA that reads them can be
+// scheduled above the wait)
+template <int N>
+__device__ __forceinline__ void wait_lgkm_tied(f32x4v* f) {
+    static_assert(N >= 2 && N <= 8, "operand list");
+    if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]));
+    else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]));
+    else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+    else if constexpr (N == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]));
+    else if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]));
+    else if constexpr (N == 7)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]));
+}
+
+template <int TM, int TN, int NB, int STEPS>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kpipe_kernel(GemmArgs g) {
-    using Cfg = KPipeCfg<TM, TN, NB>;
-    constexpr int BM = Cfg::BM, BN = Cfg::BN, NP = Cfg::PIECES_PER_WAVE, KS = 32, D = NB - 1;
+    using Cfg = KPipeCfg<TM, TN, NB, STEPS>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, NP = Cfg::PIECES_PER_WAVE, KS = 32;
+    constexpr int DT = NB / STEPS - 1;                  // trips of DMA in flight beyond the one being multiplied
+    constexpr int NF = TM + TN, NFT = STEPS * NF;       // fragment registers (float4) per slab / per trip
+    static_assert(NFT <= 8, "fragment operand list");
     extern __shared__ __attribute__((aligned(1024))) float lds[];
     const long long t_start = g.dbg_clock ? (long long)__builtin_readcyclecounter() : 0;
     const int lane = threadIdx.x & 63;
@@ -756,53 +779,35 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kpipe_kernel(GemmArgs g) {
         else src[i] = g.W + (long)min(n0 + row_local, g.N - 1) * g.K + chunk * 4;
     }
     const int nslab = g.K / KS;
-    auto issue_piece = [&](auto I, int kt, int buf) {     // slab kt (clamped) -> ring buffer buf
+    auto issue_piece = [&](auto I, int slab, int slot) {     // slab (clamped) -> ring slot
         constexpr int i = decltype(I)::value;
         const int j = wave + 4 * i;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long)min(kt, nslab - 1) * KS),
-                                         (__attribute__((address_space(3))) void*)(lds + buf * Cfg::SLAB_FLOATS + j * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long)min(slab, nslab - 1) * KS),
+                                         (__attribute__((address_space(3))) void*)(lds + slot * Cfg::SLAB_FLOATS + j * 256), 16, 0, 0);
     };
 
-    // fragment byte addresses inside a ring buffer: wave w owns chunks 2w, 2w + 1 of every row's 128-byte line
+    // fragment byte addresses inside a ring slot: wave w owns chunks 2w, 2w + 1 of every row's 128-byte line
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
     const int c0 = 2 * wave + (lane >> 5);
-    unsigned a_addr[TM], w_addr[TN];
+    unsigned f_addr[NF];
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         const int r = 32 * t + (lane & 31);
-        a_addr[t] = lds_base + (unsigned)(((r >> 3) * 64 + (r & 7) * 8 + (c0 ^ ((r >> 1) & 7))) * 16);
+        f_addr[t] = lds_base + (unsigned)(((r >> 3) * 64 + (r & 7) * 8 + (c0 ^ ((r >> 1) & 7))) * 16);
     }
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
         const int r = 32 * t + (lane & 31);
-        w_addr[t] = lds_base + (unsigned)(Cfg::A_PIECES * 1024 + ((r >> 3) * 64 + (r & 7) * 8 + (c0 ^ ((r >> 1) & 7))) * 16);
+        f_addr[TM + t] = lds_base + (unsigned)(Cfg::A_PIECES * 1024 + ((r >> 3) * 64 + (r & 7) * 8 + (c0 ^ ((r >> 1) & 7))) * 16);
     }
-    auto read_frags = [&](f32x4v (&fa)[TM], f32x4v (&fb)[TN], int buf) {
-        const unsigned off = (unsigned)buf * (unsigned)(Cfg::SLAB_FLOATS * 4);
+    // fragments of trip `trip` (slabs trip STEPS + s in slot (trip STEPS + s) % NB) -> f[s NF + t]
+    auto read_frags = [&](f32x4v (&f)[NFT], int trip) {
 #pragma unroll
-        for (int t = 0; t < TM; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[t]) : "v"(a_addr[t] + off));
+        for (int s = 0; s < STEPS; ++s) {
+            const unsigned off = (unsigned)((trip * STEPS + s) % NB) * (unsigned)(Cfg::SLAB_FLOATS * 4);
 #pragma unroll
-        for (int t = 0; t < TN; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[t]) : "v"(w_addr[t] + off));
-    };
-    auto wait_frags = [&](f32x4v (&fa)[TM], f32x4v (&fb)[TN]) {   // lgkmcnt(0), tied to the registers it makes valid
-        static_assert(TM + TN <= 8, "operand list");
-        if constexpr (TM == 3 && TN == 4)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));
-        else if constexpr (TM == 3 && TN == 3)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]));
-        else if constexpr (TM == 3 && TN == 2)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb[0]), "+v"(fb[1]));
-        else if constexpr (TM == 3 && TN == 1)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb[0]));
-        else if constexpr (TM == 2 && TN == 4)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));
-        else if constexpr (TM == 2 && TN == 2)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]), "+v"(fb[1]));
-        else if constexpr (TM == 4 && TN == 2)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]));
-        else if constexpr (TM == 2 && TN == 1)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]));
-        else static_assert(TM < 0, "add the operand list of this tile");
+            for (int t = 0; t < NF; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(f[s * NF + t]) : "v"(f_addr[t] + off));
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -813,55 +818,60 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kpipe_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    constexpr int NMF = 4 * TM * TN;                     // MFMAs per trip
+    constexpr int NMF = 4 * STEPS * TM * TN;             // MFMAs per trip
     constexpr int HEAD = NMF / 2;                        // ... in front of the barrier
-    constexpr int GAP = HEAD / NP >= 1 ? HEAD / NP : 1;  // one DMA piece every GAP MFMAs of the head
-    static_assert(NP <= HEAD, "more DMA pieces than head MFMAs");
+    constexpr int NPT = STEPS * NP;                      // DMA pieces per wave per trip
+    constexpr int GAP = HEAD / NPT >= 1 ? HEAD / NPT : 1;   // one DMA piece every GAP MFMAs of the head
+    static_assert(NPT <= HEAD, "more DMA pieces than head MFMAs");
 
     // residual / bias values first: they are older than every DMA piece, so the counted waits below cover them, and they
     // land during the first trips (see ksplit_fold_store)
     EpilogueOperands<TM, TN> eo;
     ksplit_fetch_epilogue<TM, TN>(g, eo, wave, lane, m0, n0, gR);
-    // prologue: slabs 0 .. D-1 in flight, slab 0 landed and read
-    static_for<D>([&](auto S) {
+    // prologue: trips 0 .. DT-1 in flight, trip 0 landed and read
+    static_for<DT * STEPS>([&](auto S) {
         constexpr int sl = decltype(S)::value;
-        static_for<NP>([&](auto I) { issue_piece(I, sl, sl); });
+        static_for<NP>([&](auto I) { issue_piece(I, sl, sl % NB); });
     });
-    wait_vmcnt<(D - 1) * NP>();
+    wait_vmcnt<(DT - 1) * NPT>();
     __builtin_amdgcn_s_barrier();
-    f32x4v fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-    read_frags(fa0, fb0, 0);
-    wait_frags(fa0, fb0);
+    f32x4v f0[NFT], f1[NFT];
+    read_frags(f0, 0);
+    wait_lgkm_tied<NFT>(f0);
 
-    // one trip: MFMAs of slab kt from (fa, fb); DMA of slab kt + D; reads of slab kt + 1 into (na, nb)
-    auto trip = [&](f32x4v (&fa)[TM], f32x4v (&fb)[TN], f32x4v (&na)[TM], f32x4v (&nb)[TN], int kt) {
-        const int dma_buf = (kt + D) % NB, next_buf = (kt + 1) % NB;
+    // one trip: MFMAs of trip `tt` from f; DMA of trip tt + DT; reads of trip tt + 1 into fn
+    auto trip = [&](f32x4v (&f)[NFT], f32x4v (&fn)[NFT], int tt) {
+        auto mfma_at = [&](auto X) {
+            constexpr int x = decltype(X)::value;
+            constexpr int s = x / (4 * TM * TN), c = (x / (TM * TN)) & 3, q = x % (TM * TN), i = q / TN, j = q % TN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[s * NF + i][c], f[s * NF + TM + j][c], acc[i][j], 0, 0, 0);
+        };
         static_for<HEAD>([&](auto X) {
             constexpr int x = decltype(X)::value;
-            constexpr int c = x / (TM * TN), q = x % (TM * TN), i = q / TN, j = q % TN;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][c], fb[j][c], acc[i][j], 0, 0, 0);
-            if constexpr (x % GAP == GAP - 1 && x / GAP < NP) issue_piece(std::integral_constant<int, x / GAP>{}, kt + D, dma_buf);
+            mfma_at(X);
+            if constexpr (x % GAP == GAP - 1 && x / GAP < NPT) {
+                constexpr int pc = x / GAP, st = pc / NP;
+                const int slab = (tt + DT) * STEPS + st;
+                issue_piece(std::integral_constant<int, pc % NP>{}, slab, slab % NB);
+            }
         });
         __builtin_amdgcn_sched_barrier(0);
-        wait_vmcnt<(D - 1) * NP>();
+        wait_vmcnt<(DT - 1) * NPT>();
         __builtin_amdgcn_s_barrier();
-        read_frags(na, nb, next_buf);
+        read_frags(fn, tt + 1);
         __builtin_amdgcn_sched_barrier(0);
-        static_for<NMF - HEAD>([&](auto X) {
-            constexpr int x = HEAD + decltype(X)::value;
-            constexpr int c = x / (TM * TN), q = x % (TM * TN), i = q / TN, j = q % TN;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][c], fb[j][c], acc[i][j], 0, 0, 0);
-        });
+        static_for<NMF - HEAD>([&](auto X) { mfma_at(std::integral_constant<int, HEAD + decltype(X)::value>{}); });
         __builtin_amdgcn_sched_barrier(0);
-        wait_frags(na, nb);
+        wait_lgkm_tied<NFT>(fn);
     };
     const long long t_loop = g.dbg_clock ? (long long)__builtin_readcyclecounter() : 0;
-    int kt = 0;
-    for (; kt + 1 < nslab; kt += 2) {
-        trip(fa0, fb0, fa1, fb1, kt);
-        trip(fa1, fb1, fa0, fb0, kt + 1);
+    const int ntrip = nslab / STEPS;                     // launch_gemm only sends K % 64 == 0 here
+    int tt = 0;
+    for (; tt + 1 < ntrip; tt += 2) {
+        trip(f0, f1, tt);
+        trip(f1, f0, tt + 1);
     }
-    if (kt < nslab) trip(fa0, fb0, fa1, fb1, kt);
+    if (tt < ntrip) trip(f0, f1, tt);
     wait_vmcnt<0>();
     __syncthreads();
     const long long t_fold = g.dbg_clock ? (long long)__builtin_readcyclecounter() : 0;
@@ -873,28 +883,36 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kpipe_kernel(GemmArgs g) {
     }
 }
 
-template <int TM, int TN, int NB>
+// (Two variants of this kernel were measured in round 3 and removed again - profiles/r03_gemm_kpipe_variants.txt: TWO slabs per
+// trip / barrier (ring of 6) and DMA issued by four dedicated LOADER waves instead of the compute waves.  Neither moves
+// the 96 x 32 loop off 944 cycles per slab (768 of MFMA): that tile needs 32 KB per slab per CU = 8.8 TB/s chip-wide out
+// of L2 at the rate it runs, i.e. the thin tile sits on the L2 -> LDS bandwidth, not on issue slots or barriers.)
+template <int TM, int TN, int NB, int STEPS>
 static void launch_kpipe(const LaunchCtx& ctx, const GemmArgs& g) {
-    using Cfg = KPipeCfg<TM, TN, NB>;
+    using Cfg = KPipeCfg<TM, TN, NB, STEPS>;
     static_assert(Cfg::LDS_BYTES <= 160 * 1024, "ring does not fit the 160 KiB LDS");
     static std::atomic<uint64_t> configured{0};
     int dev = 0;
     WLK_HIP(hipGetDevice(&dev));
     if (!(configured.load(std::memory_order_acquire) >> (dev & 63) & 1)) {
-        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_kpipe_kernel<TM, TN, NB>),
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_kpipe_kernel<TM, TN, NB, STEPS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
         configured.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const int tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.N + Cfg::BN - 1) / Cfg::BN;
     const int blocks = tiles_m >= 8 ? 8 * ((tiles_m + 3) / 4) * ((tiles_n + 1) / 2) : tiles_m * tiles_n;
-    hipLaunchKernelGGL((gemm_nt_f32_kpipe_kernel<TM, TN, NB>), dim3(blocks, std::max(g.batch, 1)), dim3(256), Cfg::LDS_BYTES,
+    hipLaunchKernelGGL((gemm_nt_f32_kpipe_kernel<TM, TN, NB, STEPS>), dim3(blocks, std::max(g.batch, 1)), dim3(256), Cfg::LDS_BYTES,
                        ctx.stream, g);
 }
 
-template <int NB>
-static bool dispatch_kpipe(const LaunchCtx& ctx, const GemmArgs& g, int tm, int tn) {
-#define WLK_KP(a, b) if (tm == a && tn == b) { launch_kpipe<a, b, NB>(ctx, g); return true; }
-    WLK_KP(3, 4) WLK_KP(3, 3) WLK_KP(3, 2) WLK_KP(3, 1) WLK_KP(2, 4) WLK_KP(2, 2) WLK_KP(2, 1) WLK_KP(4, 2)
+// ks code of a k-pipe configuration: 100 + ring slots (103 / 104: a ring of 3 / 4 slabs, one slab per trip)
+static bool dispatch_kpipe(const LaunchCtx& ctx, const GemmArgs& g, int tm, int tn, int ks) {
+#define WLK_KP(a, b, nb, st) if (tm == a && tn == b) { launch_kpipe<a, b, nb, st>(ctx, g); return true; }
+    if (ks == 104) {
+        WLK_KP(3, 4, 4, 1) WLK_KP(3, 3, 4, 1) WLK_KP(3, 2, 4, 1) WLK_KP(3, 1, 4, 1) WLK_KP(2, 4, 4, 1) WLK_KP(2, 2, 4, 1) WLK_KP(2, 1, 4, 1) WLK_KP(4, 2, 4, 1)
+    } else if (ks == 103) {
+        WLK_KP(3, 4, 3, 1) WLK_KP(3, 3, 3, 1) WLK_KP(3, 2, 3, 1) WLK_KP(3, 1, 3, 1) WLK_KP(2, 4, 3, 1) WLK_KP(2, 2, 3, 1) WLK_KP(2, 1, 3, 1) WLK_KP(4, 2, 3, 1)
+    }
 #undef WLK_KP
     return false;
 }
@@ -917,7 +935,9 @@ static KSplitTile ksplit_tile(int M, int N, int K, bool forced = false) {
         return e && e[0] == 'c' ? 0 : 1;      // WLK_GEMM=classic: the 64x64 kernel everywhere (A/B switch)
     }();
     if (K % 64 != 0 || K < 256 || M < 512) return {0, 0, 0};
-    if (!forced && (!mode || N > 1536)) return {0, 0, 0};
+    // K >= 512: with fewer than 16 slabs the fixed cost of a launch dominates either kernel, and the one measured case
+    // (large-v3 conv1, K = 384, M = 3000) favours the 64x64 kernel (36 vs 44 us)
+    if (!forced && (!mode || N > 1536 || K < 512)) return {0, 0, 0};
     static const KSplitTile cand[] = {{3, 4, 104}, {3, 3, 104}, {3, 2, 104}, {3, 1, 104}, {2, 4, 104}, {2, 2, 104}, {2, 1, 104}, {4, 2, 104}};
     KSplitTile best{0, 0, 0};
     double best_cost = 0.0;
@@ -994,8 +1014,7 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
         }();
         const KSplitTile use = forced.tm ? forced : kt;
         bool ok;
-        if (use.ks == 104) ok = dispatch_kpipe<4>(ctx, g, use.tm, use.tn);
-        else if (use.ks == 103) ok = dispatch_kpipe<3>(ctx, g, use.tm, use.tn);
+        if (use.ks >= 100) ok = dispatch_kpipe(ctx, g, use.tm, use.tn, use.ks);
         else ok = dispatch_ksplit<64, 0>(ctx, g, use.tm, use.tn);
         if (!ok) throw std::logic_error("gemm: k-split tile without an instantiation");
         WLK_HIP(hipGetLastError());
