@@ -298,6 +298,13 @@ int wlk_diag_linear(const float* a, int64_t lda, int64_t a_floats, const float* 
  * (previous frame), -1 in row 0 / column 0 - the array dtw_cpu hands to `backtrace` (:58-79).  Same strict comparisons
  * (ties go left) and one fp32 add per cell.  n_rows <= 1024.  Host pointers; synchronous. */
 int wlk_dtw(int device, const float* x, int32_t n_rows, int32_t n_cols, int8_t* trace);
+/* `log_mel_spectrogram(audio, n_mels, padding)` of a whole recording (whisperlivekit/whisper/audio.py:110-157) as
+ * `whisper.transcribe()` computes it once per call (transcribe.py:126: padding = 30 s of zeros): STFT 400 / hop 160 with
+ * reflection at both ends of the padded signal, mel filterbank, log10, clamp at (maximum over ALL frames) - 8, (x + 4) / 4.
+ * `mel` receives [n_mels][n_frames], n_frames = (n_samples + padding) / 160; mel == NULL only reports n_frames.  Host
+ * pointers; the work runs on the session's stream, synchronously.  n_samples + padding must exceed 200. */
+int wlk_log_mel(wlk_session* s, const float* pcm, int64_t n_samples, int32_t padding, float* mel, uint64_t capacity_floats,
+                int32_t* n_frames);
 /* Encode a log-mel SEGMENT instead of the session's audio: `mel` is [n_mels][3000] as `whisper.transcribe()` slices it
  * out of the file's log-mel and hands it to the model / to `find_alignment` (whisperlivekit/whisper/transcribe.py,
  * timing.py:163-171).  Runs encoder + cross-K/V; the session then decodes against it like after wlk_encode.  Host

@@ -1,0 +1,196 @@
+"""LocalAgreement's batch Whisper: whisperlivekit_amd/transcribe.py against runs of the reference's own
+`transcribe()` (tests/golden/transcribe_kat.json.gz, scripts/gen_golden_transcribe.py: seeded micro Whisper, real
+vocabulary, seeded audio).
+
+The golden holds, besides the result dictionary, every choice the reference's GreedyDecoder made (token per row and its
+log-probability).  The test follows those choices step by step: at temperature 0 its own arg-max has to be the
+reference's token unless the two logits are within TIE_EPS of each other; at a temperature > 0 the drawn token is taken
+from the record (torch's generator is not part of the contract) and has to have the reference's log-probability.  Any
+difference in the fallback decisions, prompts, window positions or segment cuts puts the replay out of step and fails.
+
+CPU: the host logic over the oracle-backed stand-in sessions (tests/oracle_session.py).  GPU: the same checks over the
+HIP library (wlk_log_mel, wlk_encode_mel, wlk_decode, wlk_kv_reorder, wlk_find_alignment)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from whisperlivekit_amd import synth, transcribe as TR
+
+KAT = H.golden_json("transcribe_kat.json")
+TIE_EPS = H.TIE_EPS
+LOGPROB_ATOL = 5e-4
+
+
+@pytest.fixture()
+def real_vocab(tmp_path, monkeypatch):
+    monkeypatch.setenv("WLK_VOCAB_DIR", H.real_vocab_dir(tmp_path))
+    monkeypatch.setenv("WLK_SYNTHETIC_VOCAB", "0")
+
+
+def make_audio(spec):
+    if spec["kind"] == "speech_like":
+        return synth.speech_like(spec["seconds"], seed=spec["seed"])
+    if spec["kind"] == "white_noise":
+        return synth.white_noise(spec["seconds"], seed=spec["seed"])
+    return np.zeros(int(spec["seconds"] * 16000), np.float32)
+
+
+class Replay:
+    """Stands in for transcribe.choose: answers with the reference's recorded choice after checking it against the
+    logits this implementation produced."""
+
+    def __init__(self, calls):
+        self.queue = [(c["temperature"], step, lps) for c in calls if c["beam"] is None
+                      for step, lps in zip(c["steps"], c["logprobs"])]
+        self.at = 0
+        self.ties = 0
+        self.worst_logprob = 0.0
+
+    def __call__(self, logits, temperature):
+        assert self.at < len(self.queue), "more greedy steps than the reference took"
+        t, tokens, lps = self.queue[self.at]
+        assert t == pytest.approx(temperature), f"step {self.at}: temperature {temperature}, the reference was at {t}"
+        assert logits.shape[0] == len(tokens), f"step {self.at}: {logits.shape[0]} rows, the reference had {len(tokens)}"
+        logprobs = torch.log_softmax(logits.float(), dim=-1)
+        for r, (tok, lp) in enumerate(zip(tokens, lps)):
+            if lp is None:            # the row had already ended: its choice is overridden by <|endoftext|>
+                continue
+            if temperature == 0:
+                mine = int(logits[r].argmax())
+                if mine != tok:
+                    margin = float(logits[r, mine] - logits[r, tok])
+                    assert margin <= TIE_EPS * max(1.0, abs(float(logits[r, mine]))), \
+                        f"step {self.at} row {r}: arg-max {mine}, the reference chose {tok} (margin {margin:.3e})"
+                    self.ties += 1
+            err = abs(float(logprobs[r, tok]) - lp)
+            self.worst_logprob = max(self.worst_logprob, err)
+            assert err <= LOGPROB_ATOL, f"step {self.at} row {r}: log-prob of {tok} off by {err:.2e}"
+        self.at += 1
+        return torch.tensor(tokens, dtype=torch.int64)
+
+
+def check_case(case, model, monkeypatch):
+    replay = Replay(case["calls"])
+    monkeypatch.setattr(TR, "choose", replay)
+    kwargs = dict(case["kwargs"])
+    if isinstance(kwargs.get("temperature"), list):
+        kwargs["temperature"] = tuple(kwargs["temperature"])
+    got = TR.transcribe(model, make_audio(case["audio"]), **kwargs)
+    want = case["result"]
+    assert replay.at == len(replay.queue), f"{len(replay.queue) - replay.at} recorded greedy steps were not reached"
+    assert got["language"] == want["language"]
+    assert got["text"] == want["text"]
+    assert len(got["segments"]) == len(want["segments"])
+    for g, w in zip(got["segments"], want["segments"]):
+        assert set(g) == set(w), (sorted(g), sorted(w))
+        for key in ("id", "seek", "text", "tokens", "temperature", "compression_ratio"):
+            assert g[key] == w[key], (w["id"], key, g[key], w[key])
+        for key in ("start", "end"):
+            assert g[key] == pytest.approx(w[key], abs=1e-9), (w["id"], key, g[key], w[key])
+        assert g["avg_logprob"] == pytest.approx(w["avg_logprob"], abs=LOGPROB_ATOL)
+        assert g["no_speech_prob"] == pytest.approx(w["no_speech_prob"], rel=2e-3, abs=1e-8)
+        if "words" in w:
+            assert [x["word"] for x in g["words"]] == [x["word"] for x in w["words"]], w["id"]
+            for a, b in zip(g["words"], w["words"]):
+                assert (a["start"], a["end"]) == (b["start"], b["end"]), (w["id"], a, b)
+                assert a["probability"] == pytest.approx(b["probability"], rel=2e-3, abs=1e-7)
+    return replay
+
+
+@pytest.mark.parametrize("case", KAT, ids=lambda c: c["name"])
+def test_transcribe_host_logic_over_the_oracle(case, real_vocab, monkeypatch):
+    from oracle_session import OracleModel
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    check_case(case, OracleModel(case["model"], 0), monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", KAT, ids=lambda c: c["name"])
+def test_hip_transcribe_matches_the_reference(case, real_vocab, monkeypatch):
+    from whisperlivekit_amd.engine import HipWhisperModel
+    model = HipWhisperModel.synthetic(case["model"], 0, device=0)
+    try:
+        replay = check_case(case, model, monkeypatch)
+        print(f"{case['name']}: {replay.at} greedy steps followed, {replay.ties} arg-max ties, "
+              f"worst log-prob error {replay.worst_logprob:.2e}")
+    finally:
+        for s in model.__dict__.get("_batch_rows").sessions.values():
+            s.close()
+        model.close()
+
+
+@pytest.mark.gpu
+def test_hip_log_mel_matches_the_oracle():
+    """wlk_log_mel on whole recordings (ragged lengths, with and without the 30 s padding, a padding shorter than the
+    reflection) against the oracle's restatement of whisper/audio.py:110-157."""
+    from oracle import whisper_oracle as wo
+    from whisperlivekit_amd.engine import HipWhisperModel
+    from whisperlivekit_amd.melbank import mel_filterbank
+    model = HipWhisperModel.synthetic("micro.en", 0, device=0)
+    sess = model.new_session(beam=1, batched=False)
+    filters = torch.from_numpy(np.array(mel_filterbank(80)))
+    try:
+        for seconds, padding, seed in ((41.0, 480000, 1), (0.31, 480000, 2), (3.0, 0, 3), (1.234, 100, 4), (30.0, 480000, 5)):
+            audio = synth.speech_like(seconds, seed=seed)
+            got = sess.log_mel(audio, padding=padding)
+            want = wo.log_mel_spectrogram(torch.from_numpy(audio), filters, padding=padding).numpy()
+            assert got.shape == want.shape, (seconds, padding, got.shape, want.shape)
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-4, err_msg=f"{seconds} s, padding {padding}")
+    finally:
+        sess.close()
+        model.close()
+
+
+# ---- the wrapper under the reference's own LocalAgreement policy (build container only) --------------------------------
+def _reference_available():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import ref_stubs
+    return ref_stubs
+
+
+@pytest.mark.reference
+def test_wrapper_under_the_reference_local_agreement_policy(real_vocab):
+    """The reference's OnlineASRProcessor (local_agreement/online_asr.py, unmodified) driven once over the reference's
+    WhisperASR with the seeded micro Whisper and once over HipWhisperASR (oracle-backed model on CPU): the same committed
+    words with the same times after every chunk.  Greedy only (temperature 0): the draws of the fallback temperatures are
+    covered by the replayed goldens above."""
+    ref_stubs = _reference_available()
+    if not ref_stubs.reference_available():
+        pytest.skip("reference tree not present")
+    ref_stubs.install(synthetic_vocab=False)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import gen_golden
+    from oracle_session import OracleModel
+    from whisperlivekit.local_agreement.backends import WhisperASR
+    from whisperlivekit.local_agreement.online_asr import OnlineASRProcessor
+    from whisperlivekit_amd.local_agreement import HipWhisperASR
+
+    class RefASR(WhisperASR):
+        def load_model(self, *a, **k):
+            return gen_golden.build_reference_model("micro.en", 0)
+
+    def configure(asr):
+        asr.transcribe_kargs = {"temperature": 0.0, "vad": True}
+        asr.tokenizer, asr.confidence_validation = None, False
+        asr.buffer_trimming, asr.buffer_trimming_sec = "segment", 6
+        return asr
+
+    ref = OnlineASRProcessor(configure(RefASR(lan="en", model_size="micro.en")), logfile=None)
+    mine = OnlineASRProcessor(configure(HipWhisperASR(lan="en", hip_model=OracleModel("micro.en", 0))), logfile=None)
+    audio = synth.speech_like(14.0, seed=21)
+    committed = 0
+    for lo in range(0, len(audio), 32000):
+        chunk = audio[lo:lo + 32000]
+        outs = []
+        for proc in (ref, mine):
+            proc.insert_audio_chunk(chunk)
+            tokens, upto = proc.process_iter()
+            outs.append(([(t.start, t.end, t.text) for t in tokens], upto, len(proc.audio_buffer), proc.buffer_time_offset))
+        assert outs[0] == outs[1], f"after {lo / 16000 + 2:.0f} s"
+        committed += len(outs[0][0])
+    assert committed > 0

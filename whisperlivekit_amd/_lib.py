@@ -147,6 +147,8 @@ def _declare(lib: C.CDLL) -> None:
                                    cint, cint, p]),
         "wlk_dtw": (cint, [cint, C.POINTER(C.c_float), C.c_int32, C.c_int32, C.POINTER(C.c_int8)]),
         "wlk_encode_mel": (cint, [C.c_void_p, C.POINTER(C.c_float), C.c_int32]),
+        "wlk_log_mel": (cint, [C.c_void_p, C.POINTER(C.c_float), C.c_int64, C.c_int32, C.POINTER(C.c_float), C.c_uint64,
+                               C.POINTER(C.c_int32)]),
         "wlk_find_alignment": (cint, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                       C.POINTER(C.c_float), C.POINTER(C.c_int8), C.POINTER(C.c_float)]),
         "wlk_diag_linear_time": (cint, [cint, cint, cint, cint, cint, cint, C.POINTER(C.c_float)]),
@@ -177,7 +179,7 @@ EXPORTED_SYMBOLS = (
     "wlk_vad_weights_floats", "wlk_vad_tensor_lookup", "wlk_vad_tensor_name", "wlk_vad_create", "wlk_vad_destroy",
     "wlk_vad_stream_create", "wlk_vad_stream_reset", "wlk_vad_stream_run", "wlk_vad_stream_state",
     "wlk_vad_stream_destroy",
-    "wlk_dtw", "wlk_encode_mel", "wlk_find_alignment",
+    "wlk_dtw", "wlk_encode_mel", "wlk_log_mel", "wlk_find_alignment",
     "wlk_diag_last_error", "wlk_diag_linear", "wlk_diag_linear_time", "wlk_diag_linear_ln", "wlk_diag_layernorm",
     "wlk_diag_encoder_attention", "wlk_diag_encoder_attention_time",
 )

@@ -230,8 +230,15 @@ struct MelArgs {
     // computed.  head = first = 0: everything.
     int head = 0;
     int first = 0;
+    // samples of the zero-padded signal torch.stft reflects at (audio + trailing zeros): only matters when fewer than 200
+    // zeros follow the audio (wlk_log_mel with a short padding); the streaming path always has 30 s of them
+    int n_padded = 0x7fffffff;
 };
 void launch_mel(const LaunchCtx& ctx, const MelArgs& a);
+// whole-file form (whisper/audio.py:110-157 as whisper.transcribe() calls it): frames [0, n_active) through
+// mel_frame_kernel into a.logmel / a.frame_max, then out[n_mels][n_total] = (max(L, max L - 8) + 4) / 4, mel-major as the
+// reference returns it.  a.mel_t is not used.  `max_scratch` is one float.
+void launch_mel_full(const LaunchCtx& ctx, const MelArgs& a, float* max_scratch, float* out);
 void launch_pcm16_to_float(const LaunchCtx& ctx, const short* in, float* out, int n);
 
 // ---- melspec.hip (diarization front end) ---------------------------------------------------------

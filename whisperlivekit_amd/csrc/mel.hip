@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void mel_frame_kernel(MelArgs a) {
         tw[n] = a.twiddle[n];
         int j = kHop * t - kNFft / 2 + n;
         if (j < 0) j = -j;  // reflect (edge sample not repeated)
+        if (j >= a.n_padded) j = 2 * (a.n_padded - 1) - j;
         const float s = j < a.n_samples ? a.audio[j] : 0.f;
         xw[n] = s * a.window[n];
     }
@@ -109,6 +110,56 @@ void launch_mel(const LaunchCtx& ctx, const MelArgs& a) {
     {
         KernelScope ks(ctx, "mel_finish");
         hipLaunchKernelGGL(mel_finish_kernel, dim3(240), dim3(256), 0, ctx.stream, a);
+        WLK_HIP(hipGetLastError());
+    }
+}
+
+// ---- whole-file form ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mel_full_max_kernel(const float* __restrict__ frame_max, int n_active, int n_total,
+                                                           float* __restrict__ out) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    float m = n_total > n_active ? -10.0f : -INFINITY;  // frames that only see padding are exactly log10(1e-10)
+    for (int i = tid; i < n_active; i += 256) m = fmaxf(m, frame_max[i]);
+    red[tid] = m;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = red[0];
+}
+
+// 64 frames per workgroup: time-major rows in (coalesced), mel-major rows out (64-frame runs)
+__global__ __launch_bounds__(256) void mel_full_finish_kernel(const float* __restrict__ logmel, const float* __restrict__ gmax,
+                                                              int n_mels, int n_active, int n_total, float* __restrict__ out) {
+    __shared__ float tile[64 * 129];
+    const int t0 = blockIdx.x * 64, tid = threadIdx.x;
+    const float floor_v = gmax[0] - 8.0f;
+    const int ld = n_mels + 1;
+    for (int i = tid; i < 64 * n_mels; i += 256) {
+        const int r = i / n_mels, c = i - r * n_mels, t = t0 + r;
+        tile[r * ld + c] = t < n_active ? logmel[(long)t * n_mels + c] : -10.0f;
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * n_mels; i += 256) {
+        const int c = i >> 6, r = i & 63, t = t0 + r;
+        if (t < n_total) out[(long)c * n_total + t] = (fmaxf(tile[r * ld + c], floor_v) + 4.0f) / 4.0f;
+    }
+}
+
+void launch_mel_full(const LaunchCtx& ctx, const MelArgs& a, float* max_scratch, float* out) {
+    if (a.n_mels > 128) throw std::invalid_argument("log-mel: more than 128 mel bins");
+    if (a.n_active > 0) {
+        KernelScope ks(ctx, "mel_frames");
+        hipLaunchKernelGGL(mel_frame_kernel, dim3(a.n_active), dim3(256), 0, ctx.stream, a);
+        WLK_HIP(hipGetLastError());
+    }
+    if (a.n_total > 0) {
+        KernelScope ks(ctx, "mel_finish");
+        hipLaunchKernelGGL(mel_full_max_kernel, dim3(1), dim3(256), 0, ctx.stream, a.frame_max, a.n_active, a.n_total, max_scratch);
+        hipLaunchKernelGGL(mel_full_finish_kernel, dim3((a.n_total + 63) / 64), dim3(256), 0, ctx.stream, a.logmel, max_scratch,
+                           a.n_mels, a.n_active, a.n_total, out);
         WLK_HIP(hipGetLastError());
     }
 }

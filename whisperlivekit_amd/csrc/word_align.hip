@@ -185,6 +185,49 @@ int wlk_encode_mel(wlk_session* s, const float* mel, int32_t n_frames) {
     });
 }
 
+int wlk_log_mel(wlk_session* s, const float* pcm, int64_t n_samples, int32_t padding, float* mel, uint64_t capacity_floats,
+                int32_t* n_frames) {
+    if (!s || !n_frames || (mel && n_samples > 0 && !pcm)) return fail(WLK_ERR_ARG, "NULL argument");
+    if (n_samples < 0 || padding < 0 || n_samples + padding > 0x7fff0000LL) return fail(WLK_ERR_ARG, "log_mel: bad sample counts");
+    const long n_padded = n_samples + padding;
+    if (n_padded <= kNFft / 2) return fail(WLK_ERR_ARG, "log_mel: the padded signal must be longer than the 200-sample reflection");
+    wlk_model* m = s->m;
+    const int nm = m->D.n_mels;
+    const int n_total = (int)(n_padded / kHop);                   // torch.stft frames minus the dropped last one
+    *n_frames = n_total;
+    if (!mel) return WLK_OK;                                      // size query
+    if ((uint64_t)n_total * nm > capacity_floats) return fail(WLK_ERR_CAPACITY, "log_mel: output buffer too small");
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(m->device));
+        // frames whose 400-sample window sees a non-zero sample; with fewer than 200 trailing zeros the reflection at the end
+        // brings samples back in: then every frame is computed
+        long n_active = n_samples > 0 ? (n_samples + kNFft / 2 + kHop - 1) / kHop : 0;
+        if (padding < kNFft / 2 || n_active > n_total) n_active = n_samples > 0 ? n_total : 0;
+        struct Scratch {
+            float *audio = nullptr, *logmel = nullptr, *fmax = nullptr, *out = nullptr, *gmax = nullptr;
+            ~Scratch() { for (float* p : {audio, logmel, fmax, out, gmax}) if (p) (void)hipFree(p); }
+        } w;
+        w.audio = dev_alloc<float>((size_t)std::max<long>(n_padded, 1));
+        w.logmel = dev_alloc<float>((size_t)std::max<long>(n_active, 1) * nm);
+        w.fmax = dev_alloc<float>((size_t)std::max<long>(n_active, 1));
+        w.out = dev_alloc<float>((size_t)n_total * nm);
+        w.gmax = dev_alloc<float>(1);
+        WLK_HIP(hipStreamSynchronize(s->stream));
+        if (n_samples > 0) WLK_HIP(hipMemcpyAsync(w.audio, pcm, (size_t)n_samples * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        if (padding > 0) WLK_HIP(hipMemsetAsync(w.audio + n_samples, 0, (size_t)padding * sizeof(float), s->stream));
+        MelArgs ma;
+        ma.audio = w.audio; ma.n_samples = (int)n_padded; ma.n_padded = (int)n_padded;
+        ma.window = m->w("mel.window"); ma.twiddle = m->twiddle; ma.filters = m->w("mel.filters");
+        ma.filt_lo = m->filt_lo; ma.filt_hi = m->filt_hi; ma.n_mels = nm;
+        ma.logmel = w.logmel; ma.frame_max = w.fmax; ma.mel_t = nullptr;
+        ma.n_active = (int)n_active; ma.n_total = n_total;
+        launch_mel_full(s->ctx(), ma, w.gmax, w.out);
+        WLK_HIP(hipMemcpyAsync(mel, w.out, (size_t)n_total * nm * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        WLK_HIP(hipStreamSynchronize(s->stream));
+        return WLK_OK;
+    });
+}
+
 int wlk_find_alignment(wlk_session* s, const int64_t* tokens, int32_t n_tokens, int32_t n_sot, int32_t eot, int32_t num_frames,
                        float qk_scale, float* cost_host, int8_t* trace_host, float* token_probs_host) {
     if (!s || !tokens || !trace_host || !token_probs_host) return fail(WLK_ERR_ARG, "NULL argument");

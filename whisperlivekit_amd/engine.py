@@ -279,6 +279,16 @@ class HipSession:
             raise ValueError(f"encode_mel: expected [{self.model.dims.n_mels}, 3000], got {mel.shape}")
         _lib.check(self.lib.wlk_encode_mel(self._h, mel.ctypes.data_as(C.POINTER(C.c_float)), 3000))
 
+    def log_mel(self, audio: np.ndarray, padding: int = 0) -> np.ndarray:
+        """whisper/audio.py:log_mel_spectrogram(audio, n_mels, padding) of a whole recording -> [n_mels, frames]."""
+        a = np.ascontiguousarray(_as_f32(audio)).reshape(-1)
+        n = C.c_int32()
+        _lib.check(self.lib.wlk_log_mel(self._h, None, a.size, int(padding), None, 0, C.byref(n)))
+        out = np.empty((self.model.dims.n_mels, n.value), np.float32)
+        _lib.check(self.lib.wlk_log_mel(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), a.size, int(padding),
+                                        out.ctypes.data_as(C.POINTER(C.c_float)), out.size, C.byref(n)))
+        return out
+
     def find_alignment(self, tokens: Sequence[int], n_sot: int, eot: int, num_frames: int, qk_scale: float = 1.0,
                        want_cost: bool = False):
         """Device half of whisper/timing.py:find_alignment on the encoded session.  ``tokens`` = [sot sequence (n_sot

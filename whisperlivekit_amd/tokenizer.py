@@ -277,6 +277,28 @@ class WhisperTokenizer:
     def decode_with_timestamps(self, token_ids: Sequence[int], **kw) -> str:
         return self.encoding.decode(token_ids, **kw)
 
+    # -- annotation symbols the batch decoder suppresses (whisper/tokenizer.py:241-275) -----
+    _ANNOTATION_CHARS = '"#()*+/:;<=>@[\\]^_`{|}~「」『』'
+    _ANNOTATION_RUNS = ("<<", ">>", "<<<", ">>>", "--", "---", "-(", "-[", "('", '("', "((", "))", "(((", ")))", "[[", "]]",
+                        "{{", "}}", "♪♪", "♪♪♪")
+    _MUSIC_CHARS = "♩♪♫♬♭♮♯"       # U+2640..U+267F: one token or several sharing the first (the first is suppressed)
+
+    @property
+    def non_speech_tokens(self) -> Tuple[int, ...]:
+        """Ids of speaker tags / non-speech annotations ("♪♪♪", "[DAVID]", "( SPEAKING ... )"): every listed symbol that
+        is a single token with or without a leading space, the first token of the music symbols either way, and the
+        word-initial " -" / " '" (hyphens and apostrophes stay allowed inside words)."""
+        cached = self.__dict__.get("_non_speech_tokens")
+        if cached is None:
+            ids = {self.encoding.encode(" -")[0], self.encoding.encode(" '")[0]}
+            for sym in [*self._ANNOTATION_CHARS, *self._ANNOTATION_RUNS, *self._MUSIC_CHARS]:
+                for spelled in (sym, " " + sym):
+                    toks = self.encoding.encode(spelled)
+                    if len(toks) == 1 or sym in self._MUSIC_CHARS:
+                        ids.add(toks[0])
+            cached = self.__dict__["_non_speech_tokens"] = tuple(sorted(ids))
+        return cached
+
     # -- word grouping (whisper/tokenizer.py:277-332) ----------------------------------
     def split_to_word_tokens(self, tokens: Sequence[int]):
         if self.language in {"zh", "ja", "th", "lo", "my", "yue"}:
