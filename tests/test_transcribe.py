@@ -153,7 +153,7 @@ def _reference_available():
 
 
 @pytest.mark.reference
-def test_wrapper_under_the_reference_local_agreement_policy(real_vocab):
+def test_wrapper_under_the_reference_local_agreement_policy(real_vocab, monkeypatch):
     """The reference's OnlineASRProcessor (local_agreement/online_asr.py, unmodified) driven once over the reference's
     WhisperASR with the seeded micro Whisper and once over HipWhisperASR (oracle-backed model on CPU): the same committed
     words with the same times after every chunk.  Greedy only (temperature 0): the draws of the fallback temperatures are
@@ -169,6 +169,12 @@ def test_wrapper_under_the_reference_local_agreement_policy(real_vocab):
     from whisperlivekit.local_agreement.backends import WhisperASR
     from whisperlivekit.local_agreement.online_asr import OnlineASRProcessor
     from whisperlivekit_amd.local_agreement import HipWhisperASR
+
+    # the reference's tokenizer is built once per process on whichever vocabulary the first test installed: follow it
+    from whisperlivekit.whisper.tokenizer import get_tokenizer as ref_get_tokenizer
+    from whisperlivekit_amd.tokenizer import SyntheticEncoding
+    if isinstance(ref_get_tokenizer(False, language="en", task="transcribe").encoding._e, SyntheticEncoding):
+        monkeypatch.setenv("WLK_SYNTHETIC_VOCAB", "1")
 
     class RefASR(WhisperASR):
         def load_model(self, *a, **k):
