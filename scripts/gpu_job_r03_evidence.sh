@@ -3,7 +3,7 @@
 # checked against its own golden now), 8-stream kernel trace.  Outputs under gpurun_out/r03 (copied to profiles/ by hand).
 # GRAFT_GIT_HEAD is exported by the caller: the box has no .git, the exports stamp it into the JSON files.
 O=gpurun_out/r03; mkdir -p $O; R=$PWD
-S=$(date +%s); timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -6 > $O/pytest_gpu.log; echo "pytest gpu $(( $(date +%s) - S )) s: $(tail -1 $O/pytest_gpu.log)"
+S=$(date +%s); timeout 1300 python -m pytest tests -q -m gpu 2>&1 | tail -6 > $O/pytest_gpu.log; echo "pytest gpu $(( $(date +%s) - S )) s: $(tail -1 $O/pytest_gpu.log)"
 cp gpurun_out/parity_report.json $O/ 2>/dev/null
 S=$(date +%s); timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.log; echo "default bench rc=$? $(( $(date +%s) - S )) s"
 export TMPDIR=/tmp; cd /tmp
