@@ -291,6 +291,47 @@ const char* wlk_diag_last_error(void);
 int wlk_diag_linear(const float* a, int64_t lda, int64_t a_floats, const float* w, const float* bias,
                     const float* r, int64_t ldr, int m, int n, int k, int flags, float scale, int scale_cols,
                     int force_gemv, float* c);
+/* ---- NLLB-200 / M2M-100 translation network --------------------------------------------
+ * The reference loads it through the third-party `nllw` package (whisperlivekit/core.py:320-329 `load_model`,
+ * translation.py / core.py:483-493 `OnlineTranslation`), which wraps the `transformers` M2M-100 (or its CTranslate2
+ * conversion); neither is in the reference tree, so these entry points replace what that backend executes: the encoder
+ * over a source sentence, decoder steps with a KV cache, the tied vocabulary projection.  Layout and arithmetic:
+ * csrc/nllb.hip.  Packed tensor names: "shared.emb" [vocab][d], "pos.table" [n_positions][d] (the sinusoidal table of
+ * M2M100SinusoidalPositionalEmbedding, row = position id), "enc.<i>." / "dec.<i>." + ln1 / qkv (q | k | v rows) / out /
+ * [lnx / xq / xkv (k | v rows) / xout] / ln2 / fc1 / fc2 + ".w" / ".b", "enc.ln", "dec.ln". */
+typedef struct wlk_nllb_dims {
+    int32_t vocab, d_model, heads, ffn, enc_layers, dec_layers;
+    int32_t max_src, max_tgt;      /* longest source sentence / target sequence a session is sized for (<= 512 each) */
+    int32_t pad_id;                /* padding_idx: position ids start at pad_id + 1 */
+    int32_t n_positions;           /* rows of "pos.table" */
+    float embed_scale;             /* sqrt(d_model) when config.scale_embedding, else 1 */
+} wlk_nllb_dims;
+typedef struct wlk_nllb wlk_nllb;
+typedef struct wlk_nllb_session wlk_nllb_session;
+int wlk_nllb_arena_floats(const wlk_nllb_dims* dims, uint64_t* n_floats);
+int wlk_nllb_tensor_lookup(const wlk_nllb_dims* dims, const char* packed_name, uint64_t* offset_floats, uint64_t* numel);
+int wlk_nllb_tensor_name(const wlk_nllb_dims* dims, int index, const char** name);
+int wlk_nllb_create(const wlk_nllb_dims* dims, int device, wlk_nllb** out);
+int wlk_nllb_upload(wlk_nllb* m, const char* packed_name, const float* host, uint64_t numel);
+int wlk_nllb_finalize(wlk_nllb* m);
+int wlk_nllb_destroy(wlk_nllb* m);
+/* rows = hypotheses decoded side by side against one source sentence (1 = greedy, n = beams); own HIP stream */
+int wlk_nllb_session_create(wlk_nllb* m, int rows, wlk_nllb_session** out);
+int wlk_nllb_session_destroy(wlk_nllb_session* s);
+/* M2M100Encoder.forward over one unpadded sentence (n ids, host int64) + the cross-attention K/V of every decoder layer */
+int wlk_nllb_encode(wlk_nllb_session* s, const int64_t* src_ids, int32_t n);
+/* M2M100Decoder.forward + lm_head for tokens [n_rows][n_tok] (host int64); first != 0 empties the self-attention cache
+ * (the decoder prompt, e.g. [</s>, target language]); afterwards one token per row.  Logits of the last position of
+ * every row stay on the device for wlk_nllb_topk / wlk_nllb_export.  Asynchronous on the session stream. */
+int wlk_nllb_decode(wlk_nllb_session* s, const int64_t* tokens, int32_t n_rows, int32_t n_tok, int32_t first);
+/* beam bookkeeping: row i of the self-attention cache becomes the old row source_rows[i] */
+int wlk_nllb_kv_reorder(wlk_nllb_session* s, const int32_t* source_rows, int32_t n_rows);
+/* log_softmax(logits) of the latest decode, the k (<= 16) best per row, descending: [rows][k] */
+int wlk_nllb_topk(wlk_nllb_session* s, int32_t k, float* logprobs, int32_t* ids);
+/* parity exports: "logits" [rows][vocab] of the latest decode, "enc" [src_len][d_model] */
+int wlk_nllb_export(wlk_nllb_session* s, const char* what, float* host, uint64_t capacity, uint64_t* n_written);
+int wlk_nllb_sync(wlk_nllb_session* s);
+
 /* ---- word-timestamp alignment ------------------------------------------------------------------
  * Dynamic time warping of a [n_rows tokens, n_cols frames] fp32 cost matrix on `device`: replaces `dtw_cpu`
  * (whisperlivekit/whisper/timing.py:82-105; CUDA counterpart `dtw_cuda` :108-138) under `find_alignment` (:163-243).

@@ -33,6 +33,13 @@ class SfDims(C.Structure):
         ("xscale", C.c_float)]
 
 
+class NllbDims(C.Structure):
+    """wlk_nllb_dims (include/wlk_hip.h)"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "vocab", "d_model", "heads", "ffn", "enc_layers", "dec_layers", "max_src", "max_tgt", "pad_id", "n_positions")] + [
+        ("embed_scale", C.c_float)]
+
+
 class LoopParams(C.Structure):
     """wlk_loop_params (include/wlk_hip.h)"""
     _fields_ = [(n, C.c_int32) for n in (
@@ -132,6 +139,21 @@ def _declare(lib: C.CDLL) -> None:
         "wlk_sf_step": (cint, [p, p, cint, p, cint, p, cint, C.POINTER(cint), p, cint]),
         "wlk_sf_export": (cint, [p, C.c_char_p, p, u64, C.POINTER(u64)]),
         "wlk_sf_destroy": (cint, [p]),
+        "wlk_nllb_arena_floats": (cint, [C.POINTER(NllbDims), C.POINTER(u64)]),
+        "wlk_nllb_tensor_lookup": (cint, [C.POINTER(NllbDims), C.c_char_p, C.POINTER(u64), C.POINTER(u64)]),
+        "wlk_nllb_tensor_name": (cint, [C.POINTER(NllbDims), cint, C.POINTER(C.c_char_p)]),
+        "wlk_nllb_create": (cint, [C.POINTER(NllbDims), cint, C.POINTER(p)]),
+        "wlk_nllb_upload": (cint, [p, C.c_char_p, p, u64]),
+        "wlk_nllb_finalize": (cint, [p]),
+        "wlk_nllb_destroy": (cint, [p]),
+        "wlk_nllb_session_create": (cint, [p, cint, C.POINTER(p)]),
+        "wlk_nllb_session_destroy": (cint, [p]),
+        "wlk_nllb_encode": (cint, [p, p, i32]),
+        "wlk_nllb_decode": (cint, [p, p, i32, i32, i32]),
+        "wlk_nllb_kv_reorder": (cint, [p, p, i32]),
+        "wlk_nllb_topk": (cint, [p, i32, p, p]),
+        "wlk_nllb_export": (cint, [p, C.c_char_p, p, u64, C.POINTER(u64)]),
+        "wlk_nllb_sync": (cint, [p]),
         "wlk_vad_weights_floats": (cint, [C.POINTER(u64)]),
         "wlk_vad_tensor_lookup": (cint, [C.c_char_p, C.POINTER(u64), C.POINTER(u64)]),
         "wlk_vad_tensor_name": (cint, [cint, C.POINTER(C.c_char_p)]),
@@ -180,6 +202,9 @@ EXPORTED_SYMBOLS = (
     "wlk_vad_stream_create", "wlk_vad_stream_reset", "wlk_vad_stream_run", "wlk_vad_stream_state",
     "wlk_vad_stream_destroy",
     "wlk_dtw", "wlk_encode_mel", "wlk_log_mel", "wlk_find_alignment",
+    "wlk_nllb_arena_floats", "wlk_nllb_tensor_lookup", "wlk_nllb_tensor_name", "wlk_nllb_create", "wlk_nllb_upload",
+    "wlk_nllb_finalize", "wlk_nllb_destroy", "wlk_nllb_session_create", "wlk_nllb_session_destroy", "wlk_nllb_encode",
+    "wlk_nllb_decode", "wlk_nllb_kv_reorder", "wlk_nllb_topk", "wlk_nllb_export", "wlk_nllb_sync",
     "wlk_diag_last_error", "wlk_diag_linear", "wlk_diag_linear_time", "wlk_diag_linear_ln", "wlk_diag_layernorm",
     "wlk_diag_encoder_attention", "wlk_diag_encoder_attention_time",
 )

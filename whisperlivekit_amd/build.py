@@ -11,7 +11,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwlk_hip.so")
 SOURCES = ["api.hip", "gemm_f32.hip", "layernorm.hip", "mel.hip", "attention.hip", "decoder.hip", "select.hip", "diag.hip", "melspec.hip",
-           "sortformer.hip", "sortformer_api.hip", "vad.hip", "loop.hip", "engine.hip", "dtw.hip", "word_align.hip"]
+           "sortformer.hip", "sortformer_api.hip", "vad.hip", "loop.hip", "engine.hip", "dtw.hip", "word_align.hip", "nllb.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function"]
 
