@@ -112,8 +112,9 @@ def pack_hf_state_dict(cfg: NllbConfig, sd: Mapping[str, object], n_positions: i
 def synth_state_dict(cfg: NllbConfig, seed: int = 0, eos_gain: float = 2.0) -> Dict[str, np.ndarray]:
     """Seeded random parameters under the ``transformers`` names (there is no checkpoint and no network where this is
     built and measured).  Linear weights ~ N(0, 1/fan_in), biases ~ N(0, 0.02^2), LayerNorm gains ~ 1 + N(0, 0.1^2),
-    embedding ~ N(0, d_model^-1) (so that the scaled embedding has unit variance); the ``</s>`` row is scaled by
-    ``eos_gain`` so that random-weight generations end now and then."""
+    embedding ~ N(0, 0.04 / d_model) (small next to the layers' contributions: with a tied output projection a large
+    embedding makes every random-weight generation repeat its last token); the ``</s>`` row is scaled by ``eos_gain`` so
+    that generations end now and then."""
     rng = np.random.Generator(np.random.PCG64(seed))
     sd: Dict[str, np.ndarray] = {}
     d, f = cfg.d_model, cfg.ffn_dim
@@ -129,7 +130,7 @@ def synth_state_dict(cfg: NllbConfig, seed: int = 0, eos_gain: float = 2.0) -> D
         sd[name + ".weight"] = (1.0 + normal((d,), 0.1)).astype(np.float32)
         sd[name + ".bias"] = normal((d,), 0.02)
 
-    emb = normal((cfg.vocab_size, d), 1.0 / np.sqrt(d))
+    emb = normal((cfg.vocab_size, d), 0.2 / np.sqrt(d))
     emb[cfg.eos_token_id] *= np.float32(eos_gain)
     sd["model.shared.weight"] = emb
     for side, n, cross in (("encoder", cfg.encoder_layers, False), ("decoder", cfg.decoder_layers, True)):
