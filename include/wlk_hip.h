@@ -324,6 +324,10 @@ int wlk_nllb_encode(wlk_nllb_session* s, const int64_t* src_ids, int32_t n);
  * (the decoder prompt, e.g. [</s>, target language]); afterwards one token per row.  Logits of the last position of
  * every row stay on the device for wlk_nllb_topk / wlk_nllb_export.  Asynchronous on the session stream. */
 int wlk_nllb_decode(wlk_nllb_session* s, const int64_t* tokens, int32_t n_rows, int32_t n_tok, int32_t first);
+/* One single-token step per row after the prompt, with its read-out: wlk_nllb_decode(tokens, n_tok = 1, first = 0) +
+ * wlk_nllb_topk(k) as ONE graph replay (inputs read from / results written to a host-coherent block by the kernels
+ * themselves: no copy nodes).  Synchronous. */
+int wlk_nllb_step(wlk_nllb_session* s, const int64_t* tokens, int32_t n_rows, int32_t k, float* logprobs, int32_t* ids);
 /* beam bookkeeping: row i of the self-attention cache becomes the old row source_rows[i] */
 int wlk_nllb_kv_reorder(wlk_nllb_session* s, const int32_t* source_rows, int32_t n_rows);
 /* log_softmax(logits) of the latest decode, the k (<= 16) best per row, descending: [rows][k] */

@@ -144,6 +144,10 @@ class OracleNllbSession:
             self.cache = self.oracle.new_cache()
         self.last = self.oracle.decode(t, self.enc, self.cache)[:, -1]
 
+    def step(self, tokens, k=1):
+        self.decode(torch.as_tensor(tokens, dtype=torch.int64).view(-1, 1), first=False)
+        return self.topk(k)
+
     def kv_reorder(self, source_rows):
         self.oracle.reorder(self.cache, source_rows)
 

@@ -143,6 +143,21 @@ def test_hip_rows_and_reorder(micro_hip):
         for r, srcrow in enumerate([2, 0, 0]):
             one.decode(np.concatenate([prefixes[srcrow], nxt[r]])[None], first=True)
             np.testing.assert_allclose(got[r], one.logits()[0], rtol=0, atol=2e-5)
+        # the graph-replayed step (wlk_nllb_step) = decode of one token per row + top-k, after another reorder
+        many.kv_reorder([1, 1, 2])
+        lp, ids = many.step([20, 21, 22], 3)
+        hist = [np.concatenate([prefixes[0], [8]]), np.concatenate([prefixes[0], [8]]), np.concatenate([prefixes[0], [9]])]
+        for r, tok in enumerate([20, 21, 22]):
+            one.decode(np.concatenate([hist[r], [tok]])[None], first=True)
+            want_lp, want_ids = one.topk(3)
+            np.testing.assert_allclose(lp[r], want_lp[0], rtol=0, atol=2e-5)
+            assert ids[r].tolist() == want_ids[0].tolist()
+        lp2, ids2 = many.step([30, 31, 32], 3)                                # replay of the captured graph
+        for r, (a, b) in enumerate(zip([20, 21, 22], [30, 31, 32])):
+            one.decode(np.concatenate([hist[r], [a, b]])[None], first=True)
+            want_lp, want_ids = one.topk(3)
+            np.testing.assert_allclose(lp2[r], want_lp[0], rtol=0, atol=2e-5)
+            assert ids2[r].tolist() == want_ids[0].tolist()
     finally:
         one.close(); many.close()
 

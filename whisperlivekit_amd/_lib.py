@@ -150,6 +150,7 @@ def _declare(lib: C.CDLL) -> None:
         "wlk_nllb_session_destroy": (cint, [p]),
         "wlk_nllb_encode": (cint, [p, p, i32]),
         "wlk_nllb_decode": (cint, [p, p, i32, i32, i32]),
+        "wlk_nllb_step": (cint, [p, p, i32, i32, p, p]),
         "wlk_nllb_kv_reorder": (cint, [p, p, i32]),
         "wlk_nllb_topk": (cint, [p, i32, p, p]),
         "wlk_nllb_export": (cint, [p, C.c_char_p, p, u64, C.POINTER(u64)]),
@@ -204,7 +205,7 @@ EXPORTED_SYMBOLS = (
     "wlk_dtw", "wlk_encode_mel", "wlk_log_mel", "wlk_find_alignment",
     "wlk_nllb_arena_floats", "wlk_nllb_tensor_lookup", "wlk_nllb_tensor_name", "wlk_nllb_create", "wlk_nllb_upload",
     "wlk_nllb_finalize", "wlk_nllb_destroy", "wlk_nllb_session_create", "wlk_nllb_session_destroy", "wlk_nllb_encode",
-    "wlk_nllb_decode", "wlk_nllb_kv_reorder", "wlk_nllb_topk", "wlk_nllb_export", "wlk_nllb_sync",
+    "wlk_nllb_decode", "wlk_nllb_step", "wlk_nllb_kv_reorder", "wlk_nllb_topk", "wlk_nllb_export", "wlk_nllb_sync",
     "wlk_diag_last_error", "wlk_diag_linear", "wlk_diag_linear_time", "wlk_diag_linear_ln", "wlk_diag_layernorm",
     "wlk_diag_encoder_attention", "wlk_diag_encoder_attention_time",
 )

@@ -110,6 +110,20 @@ __global__ __launch_bounds__(256) void nllb_embed_kernel(const int* __restrict__
     for (int c = threadIdx.x; c < d; c += 256) x[(long)r * d + c] = e[c] * scale + p[c];
 }
 
+// single-token steps replayed from a graph: tokens [rows] and the cache offset come from a host-coherent block (no copy
+// node); workgroup 0 leaves the offset in device memory for the kernels behind it
+__global__ __launch_bounds__(256) void nllb_embed_step_kernel(const int* __restrict__ host_block, int rows,
+                                                              const float* __restrict__ emb, const float* __restrict__ pos,
+                                                              float scale, int pos0, int d, int* __restrict__ offset_dev,
+                                                              float* __restrict__ x) {
+    const int r = blockIdx.x;
+    const int tok = host_block[r], off = host_block[rows];
+    if (r == 0 && threadIdx.x == 0) *offset_dev = off;
+    const float* e = emb + (long)tok * d;
+    const float* p = pos + (long)(pos0 + off) * d;
+    for (int c = threadIdx.x; c < d; c += 256) x[(long)r * d + c] = e[c] * scale + p[c];
+}
+
 }  // namespace wlk
 
 using namespace wlk;
@@ -150,6 +164,16 @@ struct wlk_nllb_session {
     void* topk_scratch = nullptr;
     int self_len = 0;
     bool have_logits = false;
+    // graph-replayed single-token steps (wlk_nllb_step)
+    int* step_host = nullptr;          // pinned + mapped: [rows] tokens | offset
+    int* step_host_dev = nullptr;      // the same block as the device sees it
+    float* step_vals_host = nullptr;   // pinned + mapped: top-k results written by the top-k kernel itself
+    int* step_ids_host = nullptr;
+    float* step_vals_dev = nullptr;
+    int* step_ids_dev = nullptr;
+    int step_k = 1;
+    hipGraphExec_t step_exec[2] = {nullptr, nullptr};
+    int step_exec_k[2] = {0, 0};
     template <typename T>
     T* alloc(size_t n) {
         void* p = nullptr;
@@ -205,14 +229,19 @@ static void nl_encode(wlk_nllb_session* s, int S) {
     }
 }
 
-static void nl_decode(wlk_nllb_session* s, int n_tok) {
+static void nl_decode(wlk_nllb_session* s, int n_tok, bool graph_step = false) {
     wlk_nllb* m = s->m;
     const wlk_nllb_dims& D = m->D;
     const LaunchCtx c = s->ctx();
     const int d = D.d_model, H = D.heads, f = D.ffn, rows = s->rows, R = rows * n_tok, ctx_len = D.max_tgt, S = s->src_len;
     const float q_scale = 0.125f;
-    hipLaunchKernelGGL(nllb_embed_kernel, dim3(R), dim3(256), 0, s->stream, s->tokens_dev, m->emb, m->pos, D.embed_scale,
-                       D.pad_id + 1, s->offset_dev, n_tok, d, s->dx);
+    const bool fused = n_tok == 1 && gemv_applicable(R, d);
+    if (graph_step)
+        hipLaunchKernelGGL(nllb_embed_step_kernel, dim3(R), dim3(256), 0, s->stream, s->step_host_dev, rows, m->emb, m->pos,
+                           D.embed_scale, D.pad_id + 1, d, s->offset_dev, s->dx);
+    else
+        hipLaunchKernelGGL(nllb_embed_kernel, dim3(R), dim3(256), 0, s->stream, s->tokens_dev, m->emb, m->pos, D.embed_scale,
+                           D.pad_id + 1, s->offset_dev, n_tok, d, s->dx);
     WLK_HIP(hipGetLastError());
     const size_t cache_layer = (size_t)rows * ctx_len * d;
     const long ldkv = (long)D.dec_layers * 2 * d;
@@ -220,14 +249,30 @@ static void nl_decode(wlk_nllb_session* s, int n_tok) {
         const NlLayer& L = m->dec[l];
         float* kc = s->kcache[s->kv_cur] + l * cache_layer;
         float* vc = s->vcache[s->kv_cur] + l * cache_layer;
-        launch_layernorm(c, s->dx, d, L.ln1w, L.ln1b, s->dh, d, R, d, "nllb_ln1");
-        nl_linear(c, s->dh, d, L.qkvw, L.qkvb, s->dqkv, 3 * d, R, 3 * d, d, kGemmScaleCols, nullptr, 0, "nllb_dec_qkv", q_scale, d);
-        launch_kv_append(c, s->dqkv, kc, vc, rows, n_tok, s->offset_dev, d, ctx_len);
+        if (fused) {      // single-token steps: LayerNorm and the cache append ride in the weight-streaming GEMV
+            GemmArgs g;
+            g.A = s->dx; g.lda = d; g.W = L.qkvw; g.bias = L.qkvb; g.C = s->dqkv; g.ldc = 3 * d; g.M = R; g.N = 3 * d; g.K = d;
+            g.flags = kGemmScaleCols; g.scale = q_scale; g.scale_cols = d;
+            g.ln_gamma = L.ln1w; g.ln_beta = L.ln1b;
+            g.kcache = kc; g.vcache = vc; g.kv_pos = s->offset_dev; g.kv_d = d; g.kv_ctx = ctx_len;
+            launch_gemv(c, g, "nllb_ln1_qkv_kv");
+        } else {
+            launch_layernorm(c, s->dx, d, L.ln1w, L.ln1b, s->dh, d, R, d, "nllb_ln1");
+            nl_linear(c, s->dh, d, L.qkvw, L.qkvb, s->dqkv, 3 * d, R, 3 * d, d, kGemmScaleCols, nullptr, 0, "nllb_dec_qkv", q_scale, d);
+            launch_kv_append(c, s->dqkv, kc, vc, rows, n_tok, s->offset_dev, d, ctx_len);
+        }
         launch_decoder_self_attention(c, s->dqkv, kc, vc, s->datt, rows, n_tok, s->offset_dev, d, H, ctx_len);
         nl_linear(c, s->datt, d, L.outw, L.outb, s->dx, d, R, d, d, kGemmResidual, s->dx, d, "nllb_dec_out");
 
-        launch_layernorm(c, s->dx, d, L.lnxw, L.lnxb, s->dh, d, R, d, "nllb_lnx");
-        nl_linear(c, s->dh, d, L.xqw, L.xqb, s->dq, d, R, d, d, kGemmScaleCols, nullptr, 0, "nllb_dec_xq", q_scale, d);
+        if (fused) {
+            GemmArgs q;
+            q.A = s->dx; q.lda = d; q.W = L.xqw; q.bias = L.xqb; q.C = s->dq; q.ldc = d; q.M = R; q.N = d; q.K = d;
+            q.flags = kGemmScaleCols; q.scale = q_scale; q.scale_cols = d; q.ln_gamma = L.lnxw; q.ln_beta = L.lnxb;
+            launch_gemv(c, q, "nllb_lnx_xq");
+        } else {
+            launch_layernorm(c, s->dx, d, L.lnxw, L.lnxb, s->dh, d, R, d, "nllb_lnx");
+            nl_linear(c, s->dh, d, L.xqw, L.xqb, s->dq, d, R, d, d, kGemmScaleCols, nullptr, 0, "nllb_dec_xq", q_scale, d);
+        }
         CrossAttnArgs ca{};
         ca.q = s->dq;
         ca.k = s->cross_kv + (size_t)l * 2 * d;
@@ -239,11 +284,29 @@ static void nl_decode(wlk_nllb_session* s, int n_tok) {
         ca.ring_rows = 0; ca.n_beam = 1; ca.qk_debug = nullptr;
         launch_decoder_cross_attention(c, ca);
         nl_linear(c, s->datt, d, L.xoutw, L.xoutb, s->dx, d, R, d, d, kGemmResidual, s->dx, d, "nllb_dec_xout");
-        nl_ffn(c, L, s->dx, s->dh, s->dwide, R, d, f);
+        if (fused) {
+            GemmArgs g;
+            g.A = s->dx; g.lda = d; g.W = L.fc1w; g.bias = L.fc1b; g.C = s->dwide; g.ldc = f; g.M = R; g.N = f; g.K = d;
+            g.flags = kGemmRelu; g.ln_gamma = L.ln2w; g.ln_beta = L.ln2b;
+            launch_gemv(c, g, "nllb_ln2_fc1");
+            nl_linear(c, s->dwide, f, L.fc2w, L.fc2b, s->dx, d, R, d, f, kGemmResidual, s->dx, d, "nllb_fc2");
+        } else {
+            nl_ffn(c, L, s->dx, s->dh, s->dwide, R, d, f);
+        }
     }
     // final LayerNorm + tied vocabulary projection of the last fed position of every row
-    launch_layernorm(c, s->dx + (size_t)(n_tok - 1) * d, (long)n_tok * d, m->dec_lnw, m->dec_lnb, s->hsel, d, rows, d, "nllb_dec_ln");
-    nl_linear(c, s->hsel, d, m->emb, nullptr, s->logits, D.vocab, rows, D.vocab, d, 0, nullptr, 0, "nllb_logits");
+    if (fused) {
+        GemmArgs lg;
+        lg.A = s->dx; lg.lda = d; lg.W = m->emb; lg.C = s->logits; lg.ldc = D.vocab; lg.M = rows; lg.N = D.vocab; lg.K = d;
+        lg.ln_gamma = m->dec_lnw; lg.ln_beta = m->dec_lnb;
+        launch_gemv(c, lg, "nllb_lnf_logits");
+    } else {
+        launch_layernorm(c, s->dx + (size_t)(n_tok - 1) * d, (long)n_tok * d, m->dec_lnw, m->dec_lnb, s->hsel, d, rows, d, "nllb_dec_ln");
+        nl_linear(c, s->hsel, d, m->emb, nullptr, s->logits, D.vocab, rows, D.vocab, d, 0, nullptr, 0, "nllb_logits");
+    }
+    if (graph_step)      // results straight into the host-coherent block: no copy node behind the graph either
+        launch_logsoftmax_topk(c, s->logits, D.vocab, rows, s->step_k, s->step_vals_dev, s->step_ids_dev, s->topk_scratch, nullptr,
+                               nullptr, nullptr, 0);
 }
 
 }  // namespace wlk
@@ -386,6 +449,12 @@ int wlk_nllb_session_create(wlk_nllb* m, int rows, wlk_nllb_session** out) {
         s->top_vals = s->alloc<float>((size_t)rows * 16);
         s->top_ids = s->alloc<int>((size_t)rows * 16);
         s->topk_scratch = s->alloc<char>(topk_scratch_bytes(rows));
+        WLK_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->step_host), (size_t)(rows + 1) * sizeof(int), hipHostMallocMapped));
+        WLK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&s->step_host_dev), s->step_host, 0));
+        WLK_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->step_vals_host), (size_t)rows * 16 * sizeof(float), hipHostMallocMapped));
+        WLK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&s->step_vals_dev), s->step_vals_host, 0));
+        WLK_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->step_ids_host), (size_t)rows * 16 * sizeof(int), hipHostMallocMapped));
+        WLK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&s->step_ids_dev), s->step_ids_host, 0));
         *out = s.release();
         return WLK_OK;
     });
@@ -396,6 +465,10 @@ int wlk_nllb_session_destroy(wlk_nllb_session* s) {
     (void)hipSetDevice(s->m->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (void* p : s->owned) (void)hipFree(p);
+    for (auto& e : s->step_exec) if (e) (void)hipGraphExecDestroy(e);
+    if (s->step_host) (void)hipHostFree(s->step_host);
+    if (s->step_vals_host) (void)hipHostFree(s->step_vals_host);
+    if (s->step_ids_host) (void)hipHostFree(s->step_ids_host);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return WLK_OK;
@@ -450,6 +523,52 @@ int wlk_nllb_decode(wlk_nllb_session* s, const int64_t* tokens, int32_t n_rows, 
         WLK_HIP(hipStreamSynchronize(s->stream));           // `stage` is pageable
         nl_decode(s, n_tok);
         s->self_len += n_tok;
+        s->have_logits = true;
+        return WLK_OK;
+    });
+}
+
+int wlk_nllb_step(wlk_nllb_session* s, const int64_t* tokens, int32_t n_rows, int32_t k, float* logprobs, int32_t* ids) {
+    if (!s || !tokens || !logprobs || !ids) return nl_fail(WLK_ERR_ARG, "NULL argument");
+    if (!s->encoded || s->self_len == 0) return nl_fail(WLK_ERR_STATE, "wlk_nllb_step before the decoder prompt (wlk_nllb_decode first=1)");
+    if (n_rows != s->rows) return nl_fail(WLK_ERR_ARG, "n_rows must equal the session's row count");
+    if (k < 1 || k > 16) return nl_fail(WLK_ERR_ARG, "k must be 1..16");
+    const wlk_nllb_dims& D = s->m->D;
+    if (s->self_len + 1 > D.max_tgt) return nl_fail(WLK_ERR_CAPACITY, "target context exceeded");
+    if (!gemv_applicable(n_rows, D.d_model)) return nl_fail(WLK_ERR_ARG, "wlk_nllb_step: too many rows for the single-token path");
+    for (int r = 0; r < n_rows; ++r) {
+        if (tokens[r] < 0 || tokens[r] >= D.vocab) return nl_fail(WLK_ERR_ARG, "token id out of range");
+        if (tokens[r] == D.pad_id) return nl_fail(WLK_ERR_ARG, "padding inside a sequence is not supported");
+    }
+    return nl_guarded([&]() {
+        WLK_HIP(hipSetDevice(s->m->device));
+        WLK_HIP(hipStreamSynchronize(s->stream));           // the previous step's readers of the host block are done
+        for (int r = 0; r < n_rows; ++r) s->step_host[r] = (int)tokens[r];
+        s->step_host[n_rows] = s->self_len;
+        hipGraphExec_t& exec = s->step_exec[s->kv_cur];
+        if (!exec || s->step_exec_k[s->kv_cur] != k) {
+            if (exec) { WLK_HIP(hipGraphExecDestroy(exec)); exec = nullptr; }
+            s->step_k = k;
+            hipGraph_t graph = nullptr;
+            WLK_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+            try {
+                nl_decode(s, 1, /*graph_step=*/true);
+            } catch (...) {
+                (void)hipStreamEndCapture(s->stream, &graph);
+                if (graph) (void)hipGraphDestroy(graph);
+                throw;
+            }
+            WLK_HIP(hipStreamEndCapture(s->stream, &graph));
+            const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            WLK_HIP(e);
+            s->step_exec_k[s->kv_cur] = k;
+        }
+        WLK_HIP(hipGraphLaunch(exec, s->stream));
+        WLK_HIP(hipStreamSynchronize(s->stream));
+        std::memcpy(logprobs, s->step_vals_host, (size_t)n_rows * k * sizeof(float));
+        std::memcpy(ids, s->step_ids_host, (size_t)n_rows * k * sizeof(int));
+        s->self_len += 1;
         s->have_logits = true;
         return WLK_OK;
     });

@@ -219,6 +219,15 @@ class HipNllbSession:
             raise ValueError("tokens must be [rows, n_tok]")
         _lib.check(self.lib.wlk_nllb_decode(self._h, t.ctypes.data_as(C.c_void_p), t.shape[0], t.shape[1], 1 if first else 0))
 
+    def step(self, tokens: Sequence[int], k: int = 1) -> Tuple[np.ndarray, np.ndarray]:
+        """One token per row after the prompt + the k best continuations of every row, one graph replay (wlk_nllb_step)."""
+        t = np.ascontiguousarray(tokens, dtype=np.int64).reshape(-1)
+        lp = np.empty((self.rows, k), np.float32)
+        ids = np.empty((self.rows, k), np.int32)
+        _lib.check(self.lib.wlk_nllb_step(self._h, t.ctypes.data_as(C.c_void_p), t.size, k, lp.ctypes.data_as(C.c_void_p),
+                                          ids.ctypes.data_as(C.c_void_p)))
+        return lp, ids
+
     def kv_reorder(self, source_rows: Sequence[int]) -> None:
         a = np.ascontiguousarray(source_rows, dtype=np.int32)
         _lib.check(self.lib.wlk_nllb_kv_reorder(self._h, a.ctypes.data_as(C.c_void_p), a.size))
@@ -273,14 +282,18 @@ def generate(session, src_ids: Sequence[int], forced_bos_token_id: Optional[int]
     max_length = 1 + max_new_tokens
     out = [start]
     for step in range(max_new_tokens):
-        session.decode(np.asarray([out if step == 0 else out[-1:]], np.int64), first=(step == 0))
+        if step == 0:
+            session.decode(np.asarray([out], np.int64), first=True)
+            best = None
+        else:
+            best = int(session.step(out[-1:], 1)[1][0, 0])
         cur_len = len(out)
         if forced_bos_token_id is not None and cur_len == 1:
             nxt = int(forced_bos_token_id)
         elif forced_eos_token_id is not None and cur_len == max_length - 1:
             nxt = int(forced_eos_token_id)
         else:
-            nxt = int(session.topk(1)[1][0, 0])
+            nxt = best if best is not None else int(session.topk(1)[1][0, 0])
         out.append(nxt)
         if nxt == eos:
             break
