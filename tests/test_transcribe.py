@@ -117,8 +117,7 @@ def test_hip_transcribe_matches_the_reference(case, real_vocab, monkeypatch):
         print(f"{case['name']}: {replay.at} greedy steps followed, {replay.ties} arg-max ties, "
               f"worst log-prob error {replay.worst_logprob:.2e}")
     finally:
-        for s in model.__dict__.get("_batch_rows").sessions.values():
-            s.close()
+        TR.release_sessions(model)
         model.close()
 
 
@@ -200,3 +199,34 @@ def test_wrapper_under_the_reference_local_agreement_policy(real_vocab, monkeypa
         assert outs[0] == outs[1], f"after {lo / 16000 + 2:.0f} s"
         committed += len(outs[0][0])
     assert committed > 0
+
+
+@pytest.mark.gpu
+def test_hip_transcribe_is_reentrant_on_a_shared_model(real_vocab):
+    """Four threads transcribe different recordings on ONE model at once (LocalAgreement serves every connection from one
+    ASR object): each result equals the one the same call gives alone."""
+    import threading
+    from whisperlivekit_amd.engine import HipWhisperModel
+    model = HipWhisperModel.synthetic("micro.en", 0, device=0)
+    kw = dict(language="en", temperature=0.0, word_timestamps=True, logprob_threshold=None, compression_ratio_threshold=None)
+    audios = [synth.speech_like(6.0 + i, seed=40 + i) for i in range(4)]
+    try:
+        alone = [TR.transcribe(model, a, **kw) for a in audios]
+        got, errors = [None] * 4, []
+
+        def work(i):
+            try:
+                for _ in range(2):
+                    got[i] = TR.transcribe(model, audios[i], **kw)
+            except Exception as e:      # noqa: BLE001
+                errors.append(e)
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        assert got == alone
+    finally:
+        TR.release_sessions(model)
+        model.close()

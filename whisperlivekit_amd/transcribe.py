@@ -15,6 +15,7 @@ in fp32, as the reference does on its CPU).  Decoding a file name (ffmpeg) is ou
 """
 from __future__ import annotations
 
+import threading
 import warnings
 import zlib
 from dataclasses import dataclass, field, replace
@@ -88,13 +89,16 @@ def choose(logits: torch.Tensor, temperature: float) -> torch.Tensor:
     else one categorical draw per row from torch's global generator.  Module-level so that the parity tests can follow
     the reference's recorded choices step by step."""
     if temperature == 0:
-        return logits.argmax(dim=-1)
+        return torch.from_numpy(logits.numpy().argmax(axis=-1))
     return torch.distributions.Categorical(logits=logits / temperature).sample()
 
 
 # ---- the model-side handle --------------------------------------------------------------------------------------------------
 class _Rows:
-    """Sessions of one HipWhisperModel for the batch path, by row count (greedy / sampling: 1 row; best_of / beam: n)."""
+    """Sessions of one HipWhisperModel for the batch path, by row count (greedy / sampling: 1 row; best_of / beam: n).
+    One set per calling thread: the reference's `transcribe` is re-entrant on a shared model (LocalAgreement serves every
+    connection from one WhisperASR, audio_processor.py runs them in worker threads), so concurrent calls must not share
+    device state."""
 
     def __init__(self, model: HipWhisperModel):
         self.model = model
@@ -108,20 +112,49 @@ class _Rows:
         return s
 
 
+_ROWS_LOCK = threading.Lock()
+
+
 def _rows_of(model: HipWhisperModel) -> _Rows:
-    r = model.__dict__.get("_batch_rows")
-    if r is None:
-        r = model.__dict__["_batch_rows"] = _Rows(model)
+    key = threading.get_ident()
+    with _ROWS_LOCK:
+        per_thread = model.__dict__.setdefault("_batch_rows", {})
+        r = per_thread.get(key)
+        if r is None:
+            r = per_thread[key] = _Rows(model)
     return r
+
+
+def release_sessions(model: HipWhisperModel) -> None:
+    """Close the batch-path sessions every thread created on `model` (call before closing the model)."""
+    with _ROWS_LOCK:
+        per_thread = model.__dict__.pop("_batch_rows", {})
+    for rows in per_thread.values():
+        for sess in rows.sessions.values():
+            sess.close()
 
 
 def _tokenizer_for(model: HipWhisperModel, language: Optional[str], task: Optional[str]) -> WhisperTokenizer:
     return get_tokenizer(model.is_multilingual, num_languages=model.num_languages, language=language, task=task)
 
 
-def _logits(session: HipSession, rows: int, n_vocab: int, what: str = "logits_last") -> torch.Tensor:
+def _logits(session: HipSession, rows: int, n_vocab: int, what: str = "logits_last") -> np.ndarray:
     session.sync()
-    return torch.from_numpy(session.export(what, rows * n_vocab).reshape(rows, n_vocab))
+    return session.export(what, rows * n_vocab).reshape(rows, n_vocab)
+
+
+def _logsumexp(x: np.ndarray) -> np.float32:
+    m = x.max()
+    if not np.isfinite(m):
+        return np.float32(m)
+    return np.float32(m + np.log(np.exp(x - m).sum(dtype=np.float32)))
+
+
+def _log_softmax(x: np.ndarray) -> np.ndarray:
+    """F.log_softmax(logits.float(), dim=-1) row by row, single-threaded."""
+    m = x.max(axis=-1, keepdims=True)
+    z = x - m
+    return z - np.log(np.exp(z).sum(axis=-1, keepdims=True, dtype=np.float32))
 
 
 # ---- language id (decoding.py:19-77) ----------------------------------------------------------------------------------------
@@ -138,7 +171,7 @@ def detect_language(model: HipWhisperModel, mel: Optional[np.ndarray], tokenizer
         s.encode_mel(pad_or_trim(np.asarray(mel)))
     rows = s.beam
     s.decode(np.full((rows, 1), tokenizer.sot, np.int64), first=True, sot_index=0)
-    logits = _logits(s, rows, model.dims.n_vocab)[0]
+    logits = torch.from_numpy(_logits(s, rows, model.dims.n_vocab)[0])
     keep = torch.zeros(logits.shape[-1], dtype=torch.bool)
     keep[list(tokenizer.all_language_tokens)] = True
     logits[~keep] = NEG_INF
@@ -212,7 +245,10 @@ class _WindowDecoder:
         return sorted(set(sup))
 
     # -- logit rules (decoding.py:417-499), in the reference's order ------------------------------------------------------
-    def _apply_rules(self, logits: torch.Tensor, tokens: np.ndarray) -> None:
+    def _apply_rules(self, logits: np.ndarray, tokens: np.ndarray) -> np.ndarray:
+        """In place on the [rows, vocabulary] logits; -> log_softmax of the result.  numpy on purpose: these are
+        reductions over one 50k-element row per step, and torch's CPU operators hand such a row to the whole intra-op
+        thread pool (3 ms per call on a 128-thread host against 0.1 ms single-threaded)."""
         tb, eot = self.tok.timestamp_begin, self.tok.eot
         first_step = tokens.shape[1] == self.sample_begin
         if self.blank_ids is not None and first_step:
@@ -220,7 +256,7 @@ class _WindowDecoder:
         if self.suppressed is not None:
             logits[:, self.suppressed] = NEG_INF
         if self.o.without_timestamps:
-            return
+            return _log_softmax(logits)
         if self.tok.no_timestamps is not None:
             logits[:, self.tok.no_timestamps] = NEG_INF
         for k in range(tokens.shape[0]):
@@ -241,10 +277,13 @@ class _WindowDecoder:
             logits[:, :tb] = NEG_INF                    # a window opens with a timestamp ...
             if self.max_initial_ts is not None:
                 logits[:, tb + self.max_initial_ts + 1:] = NEG_INF      # ... no later than max_initial_timestamp
-        logprobs = torch.log_softmax(logits.float(), dim=-1)
+        logprobs = _log_softmax(logits)
+        changed = False
         for k in range(tokens.shape[0]):
-            if logprobs[k, tb:].logsumexp(dim=-1) > logprobs[k, :tb].max():
+            if _logsumexp(logprobs[k, tb:]) > logprobs[k, :tb].max():
                 logits[k, :tb] = NEG_INF                # timestamps as a group outweigh every text token
+                changed = True
+        return _log_softmax(logits) if changed else logprobs
 
     # -- the loop ------------------------------------------------------------------------------------------------------
     def run(self, mel_segment: Optional[np.ndarray], session: Optional[HipSession] = None) -> DecodingResult:
@@ -274,15 +313,14 @@ class _WindowDecoder:
             if i == 0 and tok.no_speech is not None:
                 no_speech = float(s.no_speech_prob(tok.no_speech)[0])
             logits = _logits(s, rows, V)
-            self._apply_rules(logits, tokens)
-            logprobs = torch.log_softmax(logits.float(), dim=-1)
+            logprobs = self._apply_rules(logits, tokens)
             if beam is not None:
-                top_lp, top_id = logprobs.topk(o.beam_size + 1, dim=-1)
+                top_lp, top_id = torch.from_numpy(logprobs).topk(o.beam_size + 1, dim=-1)
                 tokens, done, sources = beam.update(tokens, top_lp.numpy(), top_id.numpy(), sum_logprobs)
                 s.kv_reorder(sources)
             else:
-                nxt = choose(logits, o.temperature)
-                picked = logprobs[torch.arange(rows), nxt].numpy()
+                nxt = choose(torch.from_numpy(logits), o.temperature)
+                picked = logprobs[np.arange(rows), nxt.numpy()]
                 live = tokens[:, -1] != tok.eot
                 sum_logprobs += picked * live
                 nxt = np.where(live, nxt.numpy(), tok.eot)
