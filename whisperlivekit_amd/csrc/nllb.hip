@@ -143,6 +143,10 @@ struct wlk_nllb {
         if (it == index.end()) throw std::invalid_argument("unknown packed tensor " + n);
         return arena + it->second->offset;
     }
+    ~wlk_nllb() {
+        (void)hipSetDevice(device);
+        if (arena) (void)hipFree(arena);
+    }
 };
 
 struct wlk_nllb_session {
@@ -182,6 +186,16 @@ struct wlk_nllb_session {
         return static_cast<T*>(p);
     }
     LaunchCtx ctx() const { return LaunchCtx{stream, nullptr}; }
+    ~wlk_nllb_session() {        // also the clean-up of a half-built session (an allocation that threw in session_create)
+        if (m) (void)hipSetDevice(m->device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (void* p : owned) (void)hipFree(p);
+        for (auto& e : step_exec) if (e) (void)hipGraphExecDestroy(e);
+        if (step_host) (void)hipHostFree(step_host);
+        if (step_vals_host) (void)hipHostFree(step_vals_host);
+        if (step_ids_host) (void)hipHostFree(step_ids_host);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
 };
 
 namespace wlk {
@@ -413,10 +427,7 @@ int wlk_nllb_finalize(wlk_nllb* m) {
 }
 
 int wlk_nllb_destroy(wlk_nllb* m) {
-    if (!m) return WLK_OK;
-    (void)hipSetDevice(m->device);
-    if (m->arena) (void)hipFree(m->arena);
-    delete m;
+    delete m;        // sessions of the model must be destroyed first (they hold pointers into its arena)
     return WLK_OK;
 }
 
@@ -461,16 +472,7 @@ int wlk_nllb_session_create(wlk_nllb* m, int rows, wlk_nllb_session** out) {
 }
 
 int wlk_nllb_session_destroy(wlk_nllb_session* s) {
-    if (!s) return WLK_OK;
-    (void)hipSetDevice(s->m->device);
-    if (s->stream) (void)hipStreamSynchronize(s->stream);
-    for (void* p : s->owned) (void)hipFree(p);
-    for (auto& e : s->step_exec) if (e) (void)hipGraphExecDestroy(e);
-    if (s->step_host) (void)hipHostFree(s->step_host);
-    if (s->step_vals_host) (void)hipHostFree(s->step_vals_host);
-    if (s->step_ids_host) (void)hipHostFree(s->step_ids_host);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
-    delete s;
+    delete s;        // ~wlk_nllb_session releases the stream, graphs and buffers
     return WLK_OK;
 }
 
