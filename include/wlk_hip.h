@@ -374,6 +374,13 @@ int wlk_diag_linear_time(int m, int n, int k, int flags, int force_gemv, int rep
 int wlk_diag_linear_ln(const float* a, const float* w, const float* bias, const float* gamma, const float* beta,
                        int m, int n, int k, int force_gemv, float* c);
 int wlk_diag_layernorm(const float* x, const float* gamma, const float* beta, int rows, int d, float* y);
+/* test hook of the engine's stacked prefills (csrc/api.hip: wlk_prefill_group): the prefills of n encoded beam-1 sessions of
+ * one model (tokens concatenated, n_tok[i] each) as ONE launch chain; taken[i] = 0 for a session whose prompt does not
+ * qualify for the stack (nothing is done for it).  A stacked session ends up exactly as after wlk_decode(first = 1). */
+int wlk_diag_prefill_stack(wlk_session** sessions, const int64_t* tokens, const int32_t* n_tok, const int32_t* sot_index, int32_t n,
+                           int32_t* taken);
+/* prefill chains run by the engine's prefill lane and the sessions stacked in them */
+int wlk_engine_prefill_stats(wlk_model* m, uint64_t* batches, uint64_t* sessions);
 /* kernel-tuning probe: average microseconds per encoder self-attention launch (pseudo-random qkv, k_splits key ranges) */
 int wlk_diag_encoder_attention_time(int t, int d, int n_head, int k_splits, int reps, float* us_per_launch);
 /* qkv [t, 3d] with q and k pre-scaled -> softmax(q k^T) v per 64-wide head, out [t, d] */

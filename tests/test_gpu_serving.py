@@ -263,3 +263,66 @@ def test_graft_entry_smoke_runs():
     import importlib
     entry = importlib.import_module("__graft_entry__")
     entry.smoke()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_name", ["tiny.en", "base.en"])
+def test_stacked_prefills_equal_prefills_alone(model_name):
+    """The engine's stacked prefill chain (wlk_prefill_group through the diag hook) against each session's own prefill:
+    five sessions with different audio and prompts of ragged length (one too short for the stack, one past a tile
+    boundary) - logits of the last and the sot row, the alignment read-out, and the logits of a following single-token
+    step (which reads the self-attention caches the stack filled) are bit-identical."""
+    import ctypes as C
+    from whisperlivekit_amd import _lib, synth
+    from whisperlivekit_amd.engine import HipWhisperModel
+    model = HipWhisperModel.synthetic(model_name, 0)
+    lib = model.lib
+    rng = np.random.default_rng(11)
+    lengths = [9, 33, 64, 5, 150]
+    prompts = [np.concatenate([[50257, 50362], rng.integers(300, 40000, size=n - 2)]).astype(np.int64) for n in lengths]
+    sots = [0, 0, 0, 0, 0]
+    audios = [synth.speech_like(3.0 + i, seed=70 + i) for i in range(len(lengths))]
+
+    def fresh():
+        out = []
+        for a in audios:
+            s = model.new_session(beam=1, batched=False)
+            s.append(a)
+            s.encode()
+            out.append(s)
+        return out
+
+    def read_out(s, cml):
+        lp, ids, fr = s.select([], [], [], 2, cml)
+        return s.export("logits_last", model.dims.n_vocab).copy(), s.export("logits_sot", model.dims.n_vocab).copy(), lp.copy(), ids.copy(), fr.copy()
+
+    alone, stacked = fresh(), fresh()
+    try:
+        want = []
+        for s, p in zip(alone, prompts):
+            s.decode(p[None], first=True, sot_index=0)
+            first = read_out(s, 100)
+            s.decode(np.asarray([[1234]]), first=False)
+            s.sync()
+            want.append((first, s.export("logits_last", model.dims.n_vocab).copy()))
+        handles = (C.c_void_p * len(stacked))(*[s._h for s in stacked])
+        flat = np.ascontiguousarray(np.concatenate(prompts))
+        n_tok = np.asarray(lengths, np.int32)
+        sot = np.asarray(sots, np.int32)
+        taken = np.zeros(len(lengths), np.int32)
+        _lib.check(lib.wlk_diag_prefill_stack(handles, flat.ctypes.data_as(C.c_void_p), n_tok.ctypes.data_as(C.c_void_p),
+                                              sot.ctypes.data_as(C.c_void_p), len(lengths), taken.ctypes.data_as(C.c_void_p)))
+        assert taken.tolist() == [1, 1, 1, 0, 1]          # 5 tokens: the weight-streaming path of a session alone
+        stacked[3].decode(prompts[3][None], first=True, sot_index=0)
+        for i, s in enumerate(stacked):
+            got = read_out(s, 100)
+            for a, b, what in zip(got, want[i][0], ("logits_last", "logits_sot", "top log-probs", "top ids", "frames")):
+                np.testing.assert_array_equal(a, b, err_msg=f"session {i} ({lengths[i]} tokens): {what}")
+            s.decode(np.asarray([[1234]]), first=False)
+            s.sync()
+            np.testing.assert_array_equal(s.export("logits_last", model.dims.n_vocab), want[i][1],
+                                          err_msg=f"session {i}: step after the stacked prefill")
+    finally:
+        for s in alone + stacked:
+            s.close()
+        model.close()

@@ -116,6 +116,8 @@ def _declare(lib: C.CDLL) -> None:
         "wlk_engine_attach": (cint, [p]),
         "wlk_engine_detach": (cint, [p]),
         "wlk_engine_encode_stats": (cint, [p, C.POINTER(u64), C.POINTER(u64)]),
+        "wlk_engine_prefill_stats": (cint, [p, C.POINTER(u64), C.POINTER(u64)]),
+        "wlk_diag_prefill_stack": (cint, [p, p, p, p, i32, p]),
         "wlk_engine_stats": (cint, [p, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
         "wlk_job_create": (cint, [C.POINTER(LoopParams), p, cint, p, cint, p, cint, C.POINTER(p)]),
         "wlk_job_begin_step": (cint, [p, C.POINTER(i32)]),
@@ -193,7 +195,7 @@ EXPORTED_SYMBOLS = (
     "wlk_session_destroy", "wlk_session_set_debug", "wlk_audio_append", "wlk_audio_append_pcm16", "wlk_audio_append_zeros",
     "wlk_audio_drop_front", "wlk_audio_clear", "wlk_audio_len", "wlk_encode", "wlk_decode",
     "wlk_no_speech_prob", "wlk_select", "wlk_kv_reorder", "wlk_sync", "wlk_decode_until_stop", "wlk_engine_attach", "wlk_engine_detach",
-    "wlk_engine_stats", "wlk_engine_encode_stats", "wlk_job_create",
+    "wlk_engine_stats", "wlk_engine_encode_stats", "wlk_engine_prefill_stats", "wlk_diag_prefill_stack", "wlk_job_create",
     "wlk_job_begin_step", "wlk_job_no_speech", "wlk_job_adjustments", "wlk_job_consume", "wlk_job_result",
     "wlk_job_destroy", "wlk_export", "wlk_prof_begin",
     "wlk_prof_end", "wlk_melspec_create", "wlk_melspec_run", "wlk_melspec_destroy",

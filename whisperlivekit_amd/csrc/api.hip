@@ -958,6 +958,173 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
     }
 }
 
+// ---- stacked prefills (see internal.h) -----------------------------------------------------------------------------------
+extern "C++" void wlk_prefill_ws_alloc(const wlk_model* m, wlk_prefill_ws& ws, int max_sessions, int session_rows) {
+    const wlk_dims& D = m->D;
+    const size_t d = D.n_text_state, V = D.n_vocab, H = D.n_text_head;
+    ws.cap_session_rows = session_rows;
+    ws.cap_rows = max_sessions * ((session_rows + 31) / 32 * 32);
+    const size_t R = ws.cap_rows;
+    ws.dx = dev_alloc<float>(R * d);
+    ws.dh = dev_alloc<float>(R * d);
+    ws.dqkv = dev_alloc<float>(R * 3 * d);
+    ws.datt = dev_alloc<float>(R * d);
+    ws.dq = dev_alloc<float>(R * d);
+    ws.dmlp = dev_alloc<float>(R * 4 * d);
+    ws.hsel = dev_alloc<float>((size_t)2 * max_sessions * d);
+    ws.logits = dev_alloc<float>((size_t)8 * V);
+    ws.part = dev_alloc<float>(flash_split_scratch_floats((int)R, (int)H, wlk_session::kFlashSplits));
+    ws.rows_dev = reinterpret_cast<StepRow*>(dev_alloc<char>(R * sizeof(StepRow)));
+    ws.tiles_dev = reinterpret_cast<StepRow*>(dev_alloc<char>(R / 32 * sizeof(StepRow)));
+    ws.ring_row_dev = dev_alloc<int>(R);
+    ws.zeros_dev = dev_alloc<int>(R);
+    WLK_HIP(hipMemset(ws.zeros_dev, 0, R * sizeof(int)));
+    ws.pinned_bytes = R * sizeof(StepRow) + R / 32 * sizeof(StepRow) + R * sizeof(int);
+    WLK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws.pinned), ws.pinned_bytes, hipHostMallocDefault));
+}
+
+extern "C++" void wlk_prefill_ws_free(wlk_prefill_ws& ws) {
+    void* dev[] = {ws.dx, ws.dh, ws.dqkv, ws.datt, ws.dq, ws.dmlp, ws.hsel, ws.logits, ws.part, ws.rows_dev, ws.tiles_dev,
+                   ws.ring_row_dev, ws.zeros_dev};
+    for (void* p : dev)
+        if (p) (void)hipFree(p);
+    if (ws.pinned) (void)hipHostFree(ws.pinned);
+    ws = wlk_prefill_ws{};
+}
+
+extern "C++" std::string wlk_prefill_precheck(const wlk_prefill_item& it, const wlk_prefill_ws& ws) {
+    const wlk_session* s = it.s;
+    if (!s || !it.tokens) return "prefill: NULL argument";
+    const wlk_dims& D = s->m->D;
+    const int P = it.n_tok, d = D.n_text_state;
+    if (!s->encoded) return "wlk_decode before wlk_encode";
+    if (s->beam != 1 || s->debug || s->prof_on || s->align_raw_scores) return "not a plain beam-1 session";
+    if (it.sot_index < 0 || it.sot_index >= P) return "sot_index out of range";
+    if (P > D.n_text_ctx) return "text context exceeded";
+    for (int i = 0; i < P; ++i)
+        if (it.tokens[i] < 0 || it.tokens[i] >= D.n_vocab) return "token id out of range";
+    // the stack runs every GEMM on the k-wave kernel and the cross-attention with key splits: only prompts whose own
+    // prefill would make exactly these choices ride in it (bit-identical results either way)
+    if (P <= 8 || P > ws.cap_session_rows) return "prompt length outside the stacked range";
+    if (!gemm_takes_kwave(P, 3 * d, d) || !gemm_takes_kwave(P, d, d) || !gemm_takes_kwave(P, 4 * d, d) ||
+        !gemm_takes_kwave(P, d, 4 * d))
+        return "prompt too long for the k-wave GEMMs";
+    if (((P + 31) / 32) * D.n_text_head >= 256) return "prompt too long for the key-split cross-attention";
+    if (!gemv_applicable(8, d)) return "model too wide for the stacked vocabulary projection";
+    return std::string();
+}
+
+extern "C++" void wlk_prefill_group(const std::vector<wlk_prefill_item*>& items, const LaunchCtx& c, wlk_prefill_ws& ws) {
+    if (items.empty()) return;
+    wlk_model* m = items[0]->s->m;
+    const wlk_dims& D = m->D;
+    const int d = D.n_text_state, T = D.n_audio_ctx, H = D.n_text_head, V = D.n_vocab, L = D.n_text_layer;
+    const int B = (int)items.size();
+    // ---- tables: one StepRow per stacked row; a session's rows are padded to whole 32-row tiles with copies of its
+    // row 0 (same token, position, destinations: every write of a copy repeats row 0's write with the same value)
+    StepRow* rows_h = reinterpret_cast<StepRow*>(ws.pinned);
+    std::vector<int> row0(B), padded(B);
+    int R = 0;
+    for (int i = 0; i < B; ++i) {
+        row0[i] = R;
+        padded[i] = (items[i]->n_tok + 31) / 32 * 32;
+        R += padded[i];
+    }
+    if (R > ws.cap_rows) throw std::length_error("stacked prefill: more rows than the workspace holds");
+    StepRow* tiles_h = rows_h + R;
+    int* ring_row_h = reinterpret_cast<int*>(tiles_h + R / 32);
+    for (int i = 0; i < B; ++i) {
+        wlk_session* s = items[i]->s;
+        for (int p = 0; p < padded[i]; ++p) {
+            const int src = p < items[i]->n_tok ? p : 0;
+            StepRow r{};
+            r.kcache = s->kcache[s->kv_cur];
+            r.vcache = s->vcache[s->kv_cur];
+            r.cross_kv = s->cross_kv;
+            r.ring = s->ring;
+            r.token = (int)items[i]->tokens[src];
+            r.offset = src;
+            r.ring_row = src;
+            rows_h[row0[i] + p] = r;
+            ring_row_h[row0[i] + p] = src;
+            if (p % 32 == 0) tiles_h[(row0[i] + p) / 32] = r;
+        }
+    }
+    WLK_HIP(hipMemcpyAsync(ws.rows_dev, rows_h, (size_t)R * sizeof(StepRow), hipMemcpyHostToDevice, c.stream));
+    WLK_HIP(hipMemcpyAsync(ws.tiles_dev, tiles_h, (size_t)(R / 32) * sizeof(StepRow), hipMemcpyHostToDevice, c.stream));
+    WLK_HIP(hipMemcpyAsync(ws.ring_row_dev, ring_row_h, (size_t)R * sizeof(int), hipMemcpyHostToDevice, c.stream));
+
+    // ---- the chain: enqueue_decode's prefill branch (rows > 8, not fused) with stacked rows
+    launch_embed_rows(c, ws.rows_dev, m->w_tok_emb, m->w_dec_pos, ws.dx, R, d);
+    const float scale = std::pow((float)kHeadDim, -0.25f);
+    const size_t cache_layer = (size_t)D.n_text_ctx * d;       // beam 1
+    auto linear = [&](const float* A, long lda, const float* W, const float* bias, float* C, long ldc, int N, int K, int flags,
+                      const float* Rs, float sc, int sc_cols, const char* tag) {
+        GemmArgs g;
+        g.A = A; g.lda = lda; g.W = W; g.bias = bias; g.C = C; g.ldc = ldc; g.M = R; g.N = N; g.K = K;
+        g.flags = flags; g.R = Rs; g.ldr = ldc; g.scale = sc; g.scale_cols = sc_cols;
+        g.force_kwave = true;
+        launch_gemm(c, g, tag);
+    };
+    for (int i = 0; i < L; ++i) {
+        const LayerW& W = m->dec_layers[i];
+        launch_layernorm(c, ws.dx, d, W.ln1w, W.ln1b, ws.dh, d, R, d, "dec_ln1");
+        linear(ws.dh, d, W.qkvw, W.qkvb, ws.dqkv, 3 * d, 3 * d, d, kGemmScaleCols, nullptr, scale, 2 * d, "dec_qkv");
+        launch_kv_append_rows(c, ws.dqkv, ws.rows_dev, (long)(i * cache_layer), R, d);
+        launch_decoder_self_attention_rows(c, ws.dqkv, ws.rows_dev, (long)(i * cache_layer), ws.datt, R, d, H, D.n_text_ctx);
+        linear(ws.datt, d, W.outw, W.outb, ws.dx, d, d, d, kGemmResidual, ws.dx, 1.f, 0, "dec_out");
+        launch_layernorm(c, ws.dx, d, W.lnxw, W.lnxb, ws.dh, d, R, d, "dec_lnx");
+        linear(ws.dh, d, W.xqw, W.xqb, ws.dq, d, d, d, kGemmScaleCols, nullptr, scale, d, "dec_xq");
+        FlashArgs fa;
+        fa.q = ws.dq; fa.ldq = d;
+        fa.k = nullptr; fa.v = nullptr; fa.ldkv = (long)L * 2 * d;
+        fa.tile_rows = ws.tiles_dev; fa.tile_kv_off = (long)i * 2 * d; fa.tile_v_off = d;
+        fa.out = ws.datt; fa.ldo = d; fa.Tq = R; fa.Tk = T; fa.n_head = H;
+        fa.head_rank = m->n_align > 0 ? m->head_rank + (size_t)i * H : nullptr;
+        fa.ring = nullptr; fa.ring_row = ws.ring_row_dev; fa.beam_of_row = ws.zeros_dev;
+        fa.ring_rows = items[0]->s->ring_rows; fa.n_beam = 1;
+        fa.k_splits = wlk_session::kFlashSplits;
+        fa.part_o = ws.part;
+        fa.part_m = fa.part_o + (size_t)R * H * fa.k_splits * 64;
+        fa.part_l = fa.part_m + (size_t)R * H * fa.k_splits;
+        launch_prefill_cross_attention(c, fa);
+        linear(ws.datt, d, W.xoutw, W.xoutb, ws.dx, d, d, d, kGemmResidual, ws.dx, 1.f, 0, "dec_xout");
+        launch_layernorm(c, ws.dx, d, W.ln2w, W.ln2b, ws.dh, d, R, d, "dec_ln2");
+        linear(ws.dh, d, W.fc1w, W.fc1b, ws.dmlp, 4 * d, 4 * d, d, kGemmGelu, nullptr, 1.f, 0, "dec_fc1");
+        linear(ws.dmlp, 4 * d, W.fc2w, W.fc2b, ws.dx, d, d, 4 * d, kGemmResidual, ws.dx, 1.f, 0, "dec_fc2");
+    }
+    // ---- per session: the alignment heads' raw scores softmaxed in place; final LayerNorm of the last and the sot row
+    for (int i = 0; i < B; ++i) {
+        wlk_session* s = items[i]->s;
+        const int P = items[i]->n_tok;
+        if (m->n_align > 0)
+            launch_ring_softmax(c, s->ring, ws.ring_row_dev + row0[i], ws.zeros_dev, m->all_ranks, m->n_align, P, s->ring_rows, 1, T);
+        launch_layernorm(c, ws.dx + (size_t)(row0[i] + P - 1) * d, (long)(items[i]->sot_index - (P - 1)) * d, m->w_ln_w, m->w_ln_b,
+                         ws.hsel + (size_t)2 * i * d, d, 2, d, "dec_ln_f");
+    }
+    // ---- vocabulary projection: [last, sot] rows of up to four sessions per pass over the embedding (the <= 8-row
+    // weight-streaming kernel, whose per-row arithmetic does not depend on the row count), then out to the sessions
+    for (int lo = 0; lo < B; lo += 4) {
+        const int nb = std::min(4, B - lo);
+        GemmArgs lg;
+        lg.A = ws.hsel + (size_t)2 * lo * d; lg.lda = d; lg.W = m->w_tok_emb; lg.C = ws.logits; lg.ldc = V; lg.M = 2 * nb; lg.N = V;
+        lg.K = d;
+        launch_gemv(c, lg, "dec_logits");
+        for (int i = 0; i < nb; ++i)
+            WLK_HIP(hipMemcpyAsync(items[lo + i]->s->logits_last, ws.logits + (size_t)2 * i * V, (size_t)2 * V * sizeof(float),
+                                   hipMemcpyDeviceToDevice, c.stream));
+    }
+    for (int i = 0; i < B; ++i) {
+        wlk_session* s = items[i]->s;
+        s->self_len = items[i]->n_tok;
+        s->n_steps = 1;
+        s->have_sot = true;
+        s->prefill_rows = items[i]->n_tok;
+        s->last_rows = 1;
+        s->last_ntok = items[i]->n_tok;
+    }
+}
+
 int wlk_decode(wlk_session* s, const int64_t* tokens, int n_rows, int n_tok, int first, int sot_index) {
     if (!s || !tokens) return fail(WLK_ERR_ARG, "NULL argument");
     if (!s->encoded) return fail(WLK_ERR_STATE, "wlk_decode before wlk_encode");
@@ -1020,6 +1187,12 @@ int wlk_decode(wlk_session* s, const int64_t* tokens, int n_rows, int n_tok, int
             WLK_HIP(hipGraphLaunch(exec, s->stream));
         } else {
             enqueue_decode(s, c, n_rows, n_tok, first != 0, sot_index);
+            // timing probe only (scripts/eight_stream_probe.py): the prefill chain enqueued again - same inputs, same
+            // buffers, same results - to measure what one prefill chain costs under load (the bound on what
+            // stacking the sessions' prefills could save)
+            static const int prefill_repeat = [] { const char* e = getenv("WLK_PROBE_PREFILL_REPEAT"); return e ? atoi(e) : 1; }();
+            if (first)
+                for (int rep = 1; rep < prefill_repeat; ++rep) enqueue_decode(s, c, n_rows, n_tok, true, sot_index);
         }
         WLK_HIP(hipEventRecord(s->dec_stage_ev, s->stream));
         s->dec_stage_used = true;

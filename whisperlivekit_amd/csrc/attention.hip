@@ -82,14 +82,17 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
     float m_run = -INFINITY, l_run = 0.f;
 
     // staging map: per iteration 128 keys x 64 floats for K and for V = 2048 float4 each, 8 per thread
-    const float* kbase = ak + head * 64;
-    const float* vbase = av + head * 64;
+    // stacked prefills: this query tile's session supplies the keys / values and the alignment window
+    const float* const tk = a.tile_rows ? a.tile_rows[qt_idx].cross_kv + a.tile_kv_off : ak;
+    const float* kbase = tk + head * 64;
+    const float* vbase = (a.tile_rows ? tk + a.tile_v_off : av) + head * 64;
     // alignment-head score dump (decoder prefill only)
     const int rank = a.head_rank ? a.head_rank[head] : -1;
     float* dump = nullptr;
     if (rank >= 0 && q0 + lq < a.Tq) {
         const int row = q0 + lq;
-        dump = a.ring + (((long)rank * a.n_beam + a.beam_of_row[row]) * a.ring_rows + a.ring_row[row]) * (long)T;
+        if (a.tile_rows) dump = a.tile_rows[qt_idx].ring + ((long)rank * a.ring_rows + a.ring_row[row]) * (long)T;
+        else dump = a.ring + (((long)rank * a.n_beam + a.beam_of_row[row]) * a.ring_rows + a.ring_row[row]) * (long)T;
     }
     float4 rk[8], rv[8];
     auto fetch = [&](int it) {

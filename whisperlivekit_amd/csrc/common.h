@@ -280,6 +280,11 @@ struct FlashArgs {
     float* part_m = nullptr;
     float* part_l = nullptr;
     long long* dbg_clock = nullptr;   // probe only (enc_attention_pw_kernel): 8 s_memtime figures per workgroup
+    // stacked prefills of several sessions (engine.hip): query tile t (32 stacked rows, all of ONE session) takes its
+    // keys / values from tile_rows[t].cross_kv + tile_kv_off (values tile_v_off floats further) and dumps alignment
+    // scores into tile_rows[t].ring (one beam); ring_row[] stays indexed by the stacked row
+    const StepRow* tile_rows = nullptr;
+    long tile_kv_off = 0, tile_v_off = 0;
 };
 extern long long* g_attn_dbg_clock;   // set by the timing probe (diag.hip); nullptr otherwise
 size_t flash_split_scratch_floats(int rows, int n_head, int k_splits);
@@ -301,6 +306,8 @@ void launch_decoder_self_attention_rows(const LaunchCtx& ctx, const float* qkv, 
                                         float* out, int n_rows, int d, int n_head, int ctx_len);
 void launch_kv_append(const LaunchCtx& ctx, const float* qkv, float* kc, float* vc, int n_rows, int n_tok,
                       const int* offset_dev, int d, int ctx_len);
+// stacked prefills: row r appends its k / v to rows[r].kcache / vcache + layer_off at position rows[r].offset
+void launch_kv_append_rows(const LaunchCtx& ctx, const float* qkv, const StepRow* rows, long layer_off, int n_rows, int d);
 void launch_decoder_self_attention(const LaunchCtx& ctx, const float* qkv, const float* kc, const float* vc,
                                    float* out, int n_rows, int n_tok, const int* offset_dev, int d, int n_head,
                                    int ctx_len);

@@ -147,6 +147,24 @@ void launch_kv_append(const LaunchCtx& ctx, const float* qkv, float* kc, float* 
     WLK_HIP(hipGetLastError());
 }
 
+__global__ __launch_bounds__(256) void kv_append_rows_kernel(const float* __restrict__ qkv, const StepRow* __restrict__ rows,
+                                                             long layer_off, int d) {
+    const int row = blockIdx.x;
+    const StepRow sr = rows[row];
+    const float* src = qkv + (long)row * 3 * d;
+    const long dst = layer_off + (long)sr.offset * d;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        sr.kcache[dst + c] = src[d + c];
+        sr.vcache[dst + c] = src[2 * d + c];
+    }
+}
+
+void launch_kv_append_rows(const LaunchCtx& ctx, const float* qkv, const StepRow* rows, long layer_off, int n_rows, int d) {
+    KernelScope ks(ctx, "dec_kv_append");
+    hipLaunchKernelGGL(kv_append_rows_kernel, dim3(n_rows), dim3(256), 0, ctx.stream, qkv, rows, layer_off, d);
+    WLK_HIP(hipGetLastError());
+}
+
 // ---------------------------------------------------------------------------------------------
 // Self-attention over the growing KV cache, one 256-thread workgroup per (query row, head).
 // Causal: row p of the fed block sees cache positions 0..offset+p (model.py:164-166 adds

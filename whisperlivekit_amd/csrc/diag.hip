@@ -6,6 +6,7 @@
 
 #include "../../include/wlk_hip.h"
 #include "common.h"
+#include "internal.h"
 
 using namespace wlk;
 
@@ -142,6 +143,45 @@ int wlk_diag_layernorm(const float* x, const float* gamma, const float* beta, in
         launch_layernorm(ctx, X.p, d, G.p, Bt.p, Y.p, d, rows, d, "diag_ln");
         WLK_HIP(hipDeviceSynchronize());
         WLK_HIP(hipMemcpy(y, Y.p, (size_t)rows * d * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+
+int wlk_diag_prefill_stack(wlk_session** sessions, const int64_t* tokens, const int32_t* n_tok, const int32_t* sot_index, int32_t n,
+                           int32_t* taken) {
+    if (!sessions || !tokens || !n_tok || !sot_index || !taken || n < 1 || n > kMaxBatch) {
+        set_last_error("prefill_stack: bad arguments");
+        return WLK_ERR_ARG;
+    }
+    return run([&]() {
+        wlk_model* m = sessions[0]->m;
+        WLK_HIP(hipSetDevice(m->device));
+        wlk_prefill_ws ws;
+        wlk_prefill_ws_alloc(m, ws, kMaxBatch, std::min(256, (int)m->D.n_text_ctx));
+        hipStream_t st = nullptr;
+        try {
+            WLK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            std::vector<wlk_prefill_item> items(n);
+            std::vector<wlk_prefill_item*> stack;
+            const int64_t* t = tokens;
+            for (int i = 0; i < n; ++i) {
+                items[i].s = sessions[i];
+                items[i].tokens = t;
+                items[i].n_tok = n_tok[i];
+                items[i].sot_index = sot_index[i];
+                t += n_tok[i];
+                WLK_HIP(hipStreamSynchronize(sessions[i]->stream));
+                taken[i] = sessions[i]->m == m && wlk_prefill_precheck(items[i], ws).empty() ? 1 : 0;
+                if (taken[i]) stack.push_back(&items[i]);
+            }
+            wlk_prefill_group(stack, LaunchCtx{st, nullptr}, ws);
+            WLK_HIP(hipStreamSynchronize(st));
+        } catch (...) {
+            if (st) (void)hipStreamDestroy(st);
+            wlk_prefill_ws_free(ws);
+            throw;
+        }
+        (void)hipStreamDestroy(st);
+        wlk_prefill_ws_free(ws);
     });
 }
 

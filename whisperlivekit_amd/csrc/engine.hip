@@ -44,6 +44,11 @@ struct EncodeReq {
     std::string err;
 };
 
+struct PrefillReq {
+    wlk_prefill_item item;
+    bool done = false;
+};
+
 constexpr int kEngineAdjCap = 8192;
 
 }  // namespace
@@ -90,6 +95,17 @@ struct wlk_engine {
     int gather_us = 0;
     std::atomic<uint64_t> n_enc_batches{0}, n_enc_sessions{0};   // written by the lane workers, read by the stats calls
     void run_encodes(int lane);
+    // prefill lane: the prefills (first decoder pass of an infer) of the attached sessions that are waiting at the same
+    // time run as one stacked launch chain (wlk_prefill_group): every session used to run its own ~80-launch chain,
+    // re-streaming the decoder weights, and those chains are what 8 streams on one GPU spent a quarter of their time in
+    hipStream_t pre_stream = nullptr;
+    std::thread pre_worker;
+    std::condition_variable cv_pre_work, cv_pre_done;
+    std::deque<PrefillReq*> pre_submitted;
+    bool batch_prefills = true;
+    wlk_prefill_ws pre_ws;
+    std::atomic<uint64_t> n_pre_batches{0}, n_pre_sessions{0};
+    void run_prefills();
     std::atomic<uint64_t> n_iterations{0}, n_rows{0}, n_batched{0}, n_batched_rows{0};
 
     void run();
@@ -524,6 +540,54 @@ void wlk_engine::run_encodes(int lane) {
     }
 }
 
+void wlk_engine::run_prefills() {
+    (void)hipSetDevice(m->device);
+    const LaunchCtx c{pre_stream, nullptr};
+    for (;;) {
+        std::vector<PrefillReq*> batch;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_pre_work.wait(lk, [&] { return quit || !pre_submitted.empty(); });
+            if (quit && pre_submitted.empty()) return;
+            int rows = 0;
+            while (!pre_submitted.empty() && (int)batch.size() < kMaxBatch) {
+                const int padded = (pre_submitted.front()->item.n_tok + 31) / 32 * 32;
+                if (rows + padded > pre_ws.cap_rows) break;
+                rows += padded;
+                batch.push_back(pre_submitted.front());
+                pre_submitted.pop_front();
+            }
+        }
+        auto run = [&](const std::vector<PrefillReq*>& reqs) {
+            int rc = WLK_OK;
+            std::string err;
+            try {
+                std::vector<wlk_prefill_item*> items;
+                for (PrefillReq* r : reqs) items.push_back(&r->item);
+                wlk_prefill_group(items, c, pre_ws);
+                WLK_HIP(hipStreamSynchronize(pre_stream));
+            } catch (const std::exception& e) {
+                rc = dynamic_cast<const HipError*>(&e) ? WLK_ERR_HIP : WLK_ERR_STATE;
+                err = e.what();
+            }
+            for (PrefillReq* r : reqs) {
+                r->item.rc = rc;
+                r->item.err = err;
+            }
+            return rc;
+        };
+        if (run(batch) != WLK_OK && batch.size() > 1)
+            for (PrefillReq* r : batch) run({r});        // once more one by one: only the session(s) that fail report it
+        n_pre_batches.fetch_add(1, std::memory_order_relaxed);
+        n_pre_sessions.fetch_add(batch.size(), std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (PrefillReq* r : batch) r->done = true;
+        }
+        cv_pre_done.notify_all();
+    }
+}
+
 // ---- lifetime -----------------------------------------------------------------------------------------------
 static wlk_engine* engine_create(wlk_model* m) {
     const wlk_dims& D = m->D;
@@ -550,6 +614,9 @@ static wlk_engine* engine_create(wlk_model* m) {
     for (auto& st : e->enc_streams) WLK_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_lo));
     if (const char* g = std::getenv("WLK_BATCH_ENCODE")) e->batch_encodes = !(g[0] == '0');
     if (const char* g = std::getenv("WLK_ENCODE_GATHER_US")) e->gather_us = std::max(0, std::atoi(g));
+    if (const char* g = std::getenv("WLK_BATCH_PREFILL")) e->batch_prefills = !(g[0] == '0');
+    WLK_HIP(hipStreamCreateWithPriority(&e->pre_stream, hipStreamNonBlocking, prio ? prio_hi : prio_lo));
+    if (e->batch_prefills) wlk_prefill_ws_alloc(m, e->pre_ws, kMaxBatch, std::min(256, (int)D.n_text_ctx));
     const size_t R = 8, d = D.n_text_state, T = D.n_audio_ctx, V = D.n_vocab;
     e->x = dev_alloc<float>(R * d);
     e->qkv = dev_alloc<float>(R * 3 * d);
@@ -584,6 +651,7 @@ static wlk_engine* engine_create(wlk_model* m) {
     raw->worker = std::thread([raw] { raw->run(); });
     for (int lane = 0; lane < (int)raw->enc_streams.size(); ++lane)
         raw->enc_workers.emplace_back([raw, lane] { raw->run_encodes(lane); });
+    raw->pre_worker = std::thread([raw] { raw->run_prefills(); });
     return raw;
 }
 
@@ -596,12 +664,16 @@ void wlk_engine_destroy_for_model(wlk_model* m) {
     }
     e->cv_work.notify_all();
     e->cv_enc_work.notify_all();
+    e->cv_pre_work.notify_all();
+    if (e->pre_worker.joinable()) e->pre_worker.join();
     if (e->worker.joinable()) e->worker.join();
     for (auto& w : e->enc_workers)
         if (w.joinable()) w.join();
     for (auto& st : e->enc_streams)
         if (st) (void)hipStreamDestroy(st);
     (void)hipSetDevice(m->device);
+    if (e->pre_stream) (void)hipStreamDestroy(e->pre_stream);
+    wlk_prefill_ws_free(e->pre_ws);
     float* fl[] = {e->x, e->qkv, e->att, e->q, e->mlp, e->logits, e->xsplit, e->z, e->attn_last, e->res_dev};
     for (float* p : fl)
         if (p) (void)hipFree(p);
@@ -672,6 +744,31 @@ int wlk_engine_encode(wlk_session* s, int* content_mel_len) {
     return req.rc;
 }
 
+int wlk_engine_prefill(wlk_session* s, const int64_t* tokens, int n_tok, int sot_index) {
+    wlk_engine* e = s->engine;
+    // alone on this GPU there is nothing to stack with: the session runs its own chain without the hand-off
+    if (!e || !e->batch_prefills || e->in_loop.load(std::memory_order_relaxed) <= 1) return 1;
+    PrefillReq req;
+    req.item.s = s;
+    req.item.tokens = tokens;
+    req.item.n_tok = n_tok;
+    req.item.sot_index = sot_index;
+    if (!wlk_prefill_precheck(req.item, e->pre_ws).empty()) return 1;      // wlk_decode reports what is wrong, if anything
+    // the lane runs on its own stream: what this session still has in flight on its stream must be in place first
+    if (hipStreamSynchronize(s->stream) != hipSuccess) return fail(WLK_ERR_HIP, "prefill: the session's stream failed");
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        e->pre_submitted.push_back(&req);
+    }
+    e->cv_pre_work.notify_one();
+    {
+        std::unique_lock<std::mutex> lk(e->mu);
+        e->cv_pre_done.wait(lk, [&] { return req.done; });
+    }
+    if (req.item.rc != WLK_OK) set_last_error(req.item.err);
+    return req.item.rc;
+}
+
 void wlk_engine_loop_enter(wlk_session* s) {
     if (s->engine) s->engine->in_loop.fetch_add(1, std::memory_order_relaxed);
 }
@@ -714,6 +811,14 @@ int wlk_engine_encode_stats(wlk_model* m, uint64_t* batches, uint64_t* sessions)
     std::lock_guard<std::mutex> lk(m->engine_mu);
     if (batches) *batches = m->engine ? m->engine->n_enc_batches.load(std::memory_order_relaxed) : 0;
     if (sessions) *sessions = m->engine ? m->engine->n_enc_sessions.load(std::memory_order_relaxed) : 0;
+    return WLK_OK;
+}
+
+int wlk_engine_prefill_stats(wlk_model* m, uint64_t* batches, uint64_t* sessions) {
+    if (!m) return fail(WLK_ERR_ARG, "model is NULL");
+    std::lock_guard<std::mutex> lk(m->engine_mu);
+    if (batches) *batches = m->engine ? m->engine->n_pre_batches.load(std::memory_order_relaxed) : 0;
+    if (sessions) *sessions = m->engine ? m->engine->n_pre_sessions.load(std::memory_order_relaxed) : 0;
     return WLK_OK;
 }
 

@@ -94,6 +94,28 @@ inline T* dev_alloc_zero(size_t n, hipStream_t s) {
 }  // namespace wlk
 
 struct wlk_engine;
+struct wlk_session;
+struct wlk_model;
+
+// ---- stacked prefills (api.hip: wlk_prefill_group; engine.hip: the prefill lane) -----------------------------------
+// Workspace of one stacked prefill chain: activations of all stacked rows, the row / tile tables, read-out staging.
+struct wlk_prefill_ws {
+    int cap_rows = 0;             // stacked rows (each session padded to whole 32-row query tiles) the buffers hold
+    int cap_session_rows = 0;     // longest prompt of one session taken into a stack
+    float *dx = nullptr, *dh = nullptr, *dqkv = nullptr, *datt = nullptr, *dq = nullptr, *dmlp = nullptr, *hsel = nullptr,
+          *logits = nullptr, *part = nullptr;
+    wlk::StepRow *rows_dev = nullptr, *tiles_dev = nullptr;
+    int *ring_row_dev = nullptr, *zeros_dev = nullptr;
+    char* pinned = nullptr;       // host staging of the tables
+    size_t pinned_bytes = 0;
+};
+struct wlk_prefill_item {
+    wlk_session* s = nullptr;
+    const int64_t* tokens = nullptr;
+    int n_tok = 0, sot_index = 0;
+    int rc = 0;
+    std::string err;
+};
 
 // ------------------------------------------------------------------------------------------------
 // model
@@ -290,7 +312,21 @@ void wlk_encode_group(const std::vector<wlk_session*>& group, const wlk::LaunchC
 // this per request before it stacks requests into one chain.
 std::string wlk_encode_precheck(const wlk_session* s, const wlk_model* m);
 
+// The prefills (first decoder pass of an infer: all prompt tokens at once) of several beam-1 sessions of one model as
+// ONE launch chain on c.stream: rows of all sessions stacked for the LayerNorms and GEMMs (shared weights), per-row
+// session pointers for the cache append / self-attention, per-query-tile session pointers for the cross-attention.
+// Every row goes through the kernels and the arithmetic of a prefill of its session alone (wlk_decode, first = 1), so the
+// results are bit-identical to it.  wlk_prefill_precheck: empty = this request can ride in a stack (otherwise the
+// caller runs wlk_decode).  Leaves each session as wlk_decode(first = 1) leaves it; throws on launch failures.
+std::string wlk_prefill_precheck(const wlk_prefill_item& it, const wlk_prefill_ws& ws);
+void wlk_prefill_group(const std::vector<wlk_prefill_item*>& items, const wlk::LaunchCtx& c, wlk_prefill_ws& ws);
+void wlk_prefill_ws_alloc(const wlk_model* m, wlk_prefill_ws& ws, int max_sessions, int session_rows);
+void wlk_prefill_ws_free(wlk_prefill_ws& ws);
+
 // engine.hip
+// the prefill of an attached session through the engine's prefill lane (stacked with the prefills other sessions have
+// waiting); 1 = not taken (the caller runs wlk_decode itself); blocks until this session's prefill is done
+int wlk_engine_prefill(wlk_session* s, const int64_t* tokens, int n_tok, int sot_index);
 bool wlk_engine_batches_encodes(const wlk_session* s);
 int wlk_engine_encode(wlk_session* s, int* content_mel_len);      // blocks until this session's encode is done
 namespace wlk { struct DecodeJob; }

@@ -275,7 +275,11 @@ int wlk_decode_until_stop(wlk_session* s, const int64_t* tokens, int n_tok, cons
             }
             if (rc != 1) return rc;
         }
-        if (int rc = wlk_decode(s, feed, 1, first ? (int)job.seq.size() : 1, first ? 1 : 0, p->sot_index)) return rc;
+        // the prefill rides in the engine's stacked chain when other sessions are busy on this GPU (1 = not taken)
+        int taken = first ? wlk_engine_prefill(s, feed, (int)job.seq.size(), p->sot_index) : 1;
+        if (taken != WLK_OK && taken != 1) return taken;
+        if (taken == 1)
+            if (int rc = wlk_decode(s, feed, 1, first ? (int)job.seq.size() : 1, first ? 1 : 0, p->sot_index)) return rc;
         job.adjustments(ids, deltas);
         rows.assign(ids.size(), -1);
         static const bool merged_first = getenv("WLK_NO_FIRST_MERGE") == nullptr;   // A/B switch

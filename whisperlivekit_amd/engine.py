@@ -191,10 +191,14 @@ class HipWhisperModel:
         it, rows, bs, br = (int(x.value) for x in v)
         eb, es = C.c_uint64(), C.c_uint64()
         _lib.check(self.lib.wlk_engine_encode_stats(self._h, C.byref(eb), C.byref(es)))
+        pb, ps = C.c_uint64(), C.c_uint64()
+        _lib.check(self.lib.wlk_engine_prefill_stats(self._h, C.byref(pb), C.byref(ps)))
         return dict(iterations=it, rows=rows, batched_steps=bs, batched_rows=br,
                     mean_rows_per_batched_step=round(br / bs, 3) if bs else None,
                     encode_batches=int(eb.value), encoded_sessions=int(es.value),
-                    mean_sessions_per_encode_batch=round(es.value / eb.value, 3) if eb.value else None)
+                    mean_sessions_per_encode_batch=round(es.value / eb.value, 3) if eb.value else None,
+                    prefill_batches=int(pb.value), stacked_prefills=int(ps.value),
+                    mean_sessions_per_prefill_batch=round(ps.value / pb.value, 3) if pb.value else None)
 
     def close(self) -> None:
         if self._h:
