@@ -103,6 +103,7 @@ struct wlk_engine {
     std::condition_variable cv_pre_work, cv_pre_done;
     std::deque<PrefillReq*> pre_submitted;
     bool batch_prefills = true;
+    int pre_gather_us = 0;
     wlk_prefill_ws pre_ws;
     std::atomic<uint64_t> n_pre_batches{0}, n_pre_sessions{0};
     void run_prefills();
@@ -549,6 +550,14 @@ void wlk_engine::run_prefills() {
             std::unique_lock<std::mutex> lk(mu);
             cv_pre_work.wait(lk, [&] { return quit || !pre_submitted.empty(); });
             if (quit && pre_submitted.empty()) return;
+            if (pre_gather_us > 0) {
+                // optional gather window (WLK_PREFILL_GATHER_US): hold the launch briefly while other sessions of this GPU
+                // are still in their encode, i.e. about to arrive with their prefill
+                const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(pre_gather_us);
+                while (!quit && (int)pre_submitted.size() < std::min(kMaxBatch, in_loop.load(std::memory_order_relaxed)) &&
+                       cv_pre_work.wait_until(lk, deadline) != std::cv_status::timeout) {
+                }
+            }
             int rows = 0;
             while (!pre_submitted.empty() && (int)batch.size() < kMaxBatch) {
                 const int padded = (pre_submitted.front()->item.n_tok + 31) / 32 * 32;
@@ -615,6 +624,7 @@ static wlk_engine* engine_create(wlk_model* m) {
     if (const char* g = std::getenv("WLK_BATCH_ENCODE")) e->batch_encodes = !(g[0] == '0');
     if (const char* g = std::getenv("WLK_ENCODE_GATHER_US")) e->gather_us = std::max(0, std::atoi(g));
     if (const char* g = std::getenv("WLK_BATCH_PREFILL")) e->batch_prefills = !(g[0] == '0');
+    if (const char* g = std::getenv("WLK_PREFILL_GATHER_US")) e->pre_gather_us = std::max(0, std::atoi(g));
     WLK_HIP(hipStreamCreateWithPriority(&e->pre_stream, hipStreamNonBlocking, prio ? prio_hi : prio_lo));
     if (e->batch_prefills) wlk_prefill_ws_alloc(m, e->pre_ws, kMaxBatch, std::min(256, (int)D.n_text_ctx));
     const size_t R = 8, d = D.n_text_state, T = D.n_audio_ctx, V = D.n_vocab;
