@@ -174,7 +174,9 @@ int wlk_decode_until_stop(wlk_session* s, const int64_t* tokens, int n_tok, cons
  * (whisperlivekit/core.py:246-271, audio_processor.py:543-551), each issuing its own launch chain per token.  Sessions
  * attached here hand the single-token steps of wlk_decode_until_stop to ONE worker per GPU that advances every loop
  * currently in its decode phase in one launch chain (rows = sessions; weights are streamed once per step for all of
- * them; per-row arithmetic and its order are those of a session running alone).  Beam-1 sessions only. */
+ * them; per-row arithmetic and its order are those of a session running alone).  The prefills (first decoder pass of an
+ * infer) that are waiting at the same time run as one stacked chain as well (csrc/api.hip: wlk_prefill_group), bit-identical
+ * to a session's own prefill.  Beam-1 sessions only. */
 int wlk_engine_attach(wlk_session* s);
 int wlk_engine_detach(wlk_session* s);
 /* encode launch chains run by the engine and the sessions encoded in them (concurrent wlk_encode calls of attached
