@@ -19,6 +19,38 @@
 
 namespace wlk {
 
+namespace {
+struct UtilStream {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+};
+UtilStream g_util[64];
+UtilStream& util_of_current_device() {
+    int dev = 0;
+    WLK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) throw std::invalid_argument("device index out of range");
+    return g_util[dev];
+}
+}  // namespace
+
+void copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    if (bytes == 0) return;
+    UtilStream& u = util_of_current_device();
+    std::lock_guard<std::mutex> lk(u.mu);
+    if (!u.stream) WLK_HIP(hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking));
+    WLK_HIP(hipMemcpyAsync(dst, src, bytes, kind, u.stream));
+    WLK_HIP(hipStreamSynchronize(u.stream));
+}
+
+void memset_sync(void* dst, int value, size_t bytes) {
+    if (bytes == 0) return;
+    UtilStream& u = util_of_current_device();
+    std::lock_guard<std::mutex> lk(u.mu);
+    if (!u.stream) WLK_HIP(hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking));
+    WLK_HIP(hipMemsetAsync(dst, value, bytes, u.stream));
+    WLK_HIP(hipStreamSynchronize(u.stream));
+}
+
 // ------------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------------
@@ -188,12 +220,12 @@ int wlk_model_create(const wlk_dims* dims, int device, float* arena_dev, wlk_mod
         } else {
             m->arena = dev_alloc<float>(m->arena_floats);
             m->owns_arena = true;
-            WLK_HIP(hipMemset(m->arena, 0, m->arena_floats * sizeof(float)));
+            memset_sync(m->arena, 0, m->arena_floats * sizeof(float));
         }
         std::vector<double> tw(kNFft);
         for (int i = 0; i < kNFft; ++i) tw[i] = std::cos(2.0 * M_PI * (double)i / (double)kNFft);
         m->twiddle = dev_alloc<double>(kNFft);
-        WLK_HIP(hipMemcpy(m->twiddle, tw.data(), kNFft * sizeof(double), hipMemcpyHostToDevice));
+        copy_sync(m->twiddle, tw.data(), kNFft * sizeof(double), hipMemcpyHostToDevice);
         m->filt_lo = dev_alloc<int>(dims->n_mels);
         m->filt_hi = dev_alloc<int>(dims->n_mels);
         m->head_rank = dev_alloc<int>((size_t)dims->n_text_layer * dims->n_text_head);
@@ -202,11 +234,11 @@ int wlk_model_create(const wlk_dims* dims, int device, float* arena_dev, wlk_mod
         {
             std::vector<int> iota((size_t)dims->n_text_layer * dims->n_text_head);
             for (size_t i = 0; i < iota.size(); ++i) iota[i] = (int)i;
-            WLK_HIP(hipMemcpy(m->all_ranks, iota.data(), iota.size() * sizeof(int), hipMemcpyHostToDevice));
+            copy_sync(m->all_ranks, iota.data(), iota.size() * sizeof(int), hipMemcpyHostToDevice);
         }
         m->layer_rank_count.assign(dims->n_text_layer, 0);
         std::vector<int> none((size_t)dims->n_text_layer * dims->n_text_head, -1);
-        WLK_HIP(hipMemcpy(m->head_rank, none.data(), none.size() * sizeof(int), hipMemcpyHostToDevice));
+        copy_sync(m->head_rank, none.data(), none.size() * sizeof(int), hipMemcpyHostToDevice);
         *out = m.release();
         return WLK_OK;
     });
@@ -231,7 +263,7 @@ int wlk_model_upload(wlk_model* m, const char* packed_name, const float* host, u
             return fail(WLK_ERR_ARG, std::string("size mismatch for ") + packed_name + ": expected " +
                                          std::to_string(it->second->numel) + ", got " + std::to_string(numel));
         WLK_HIP(hipSetDevice(m->device));
-        WLK_HIP(hipMemcpy(m->arena + it->second->offset, host, numel * sizeof(float), hipMemcpyHostToDevice));
+        copy_sync(m->arena + it->second->offset, host, numel * sizeof(float), hipMemcpyHostToDevice);
         return WLK_OK;
     });
 }
@@ -249,11 +281,11 @@ int wlk_model_set_alignment_heads(wlk_model* m, const int32_t* pairs, int n_pair
             rank[(size_t)l * H + h] = i;
         }
         WLK_HIP(hipSetDevice(m->device));
-        WLK_HIP(hipMemcpy(m->head_rank, rank.data(), rank.size() * sizeof(int), hipMemcpyHostToDevice));
+        copy_sync(m->head_rank, rank.data(), rank.size() * sizeof(int), hipMemcpyHostToDevice);
         std::vector<int> compact((size_t)L * H, -1);
         m->layer_rank_count.assign(L, 0);
         for (int i = 0; i < n_pairs; ++i) compact[(size_t)pairs[2 * i] * H + m->layer_rank_count[pairs[2 * i]]++] = i;
-        WLK_HIP(hipMemcpy(m->layer_ranks, compact.data(), compact.size() * sizeof(int), hipMemcpyHostToDevice));
+        copy_sync(m->layer_ranks, compact.data(), compact.size() * sizeof(int), hipMemcpyHostToDevice);
         m->align_pairs.assign(pairs, pairs + 2 * n_pairs);
         m->n_align = n_pairs;
         return WLK_OK;
@@ -268,7 +300,7 @@ int wlk_model_finalize(wlk_model* m) {
         // received the weights by broadcast derive the same table
         const int nm = m->D.n_mels;
         std::vector<float> f((size_t)nm * kNFreq);
-        WLK_HIP(hipMemcpy(f.data(), m->w("mel.filters"), f.size() * sizeof(float), hipMemcpyDeviceToHost));
+        copy_sync(f.data(), m->w("mel.filters"), f.size() * sizeof(float), hipMemcpyDeviceToHost);
         std::vector<int> lo(nm), hi(nm);
         for (int i = 0; i < nm; ++i) {
             int a = kNFreq, b = 0;
@@ -281,8 +313,8 @@ int wlk_model_finalize(wlk_model* m) {
             lo[i] = a;
             hi[i] = b;
         }
-        WLK_HIP(hipMemcpy(m->filt_lo, lo.data(), nm * sizeof(int), hipMemcpyHostToDevice));
-        WLK_HIP(hipMemcpy(m->filt_hi, hi.data(), nm * sizeof(int), hipMemcpyHostToDevice));
+        copy_sync(m->filt_lo, lo.data(), nm * sizeof(int), hipMemcpyHostToDevice);
+        copy_sync(m->filt_hi, hi.data(), nm * sizeof(int), hipMemcpyHostToDevice);
         m->enc_layers.clear();
         m->dec_layers.clear();
         for (int i = 0; i < m->D.n_audio_layer; ++i) m->enc_layers.push_back(layer_weights(m, "enc", i, false));
@@ -292,10 +324,10 @@ int wlk_model_finalize(wlk_model* m) {
             if (!m->xkv_all_w) m->xkv_all_w = dev_alloc<float>(Ld * 2 * d * da);
             if (!m->xkv_all_b) m->xkv_all_b = dev_alloc<float>(Ld * 2 * d);
             for (size_t i = 0; i < Ld; ++i) {
-                WLK_HIP(hipMemcpy(m->xkv_all_w + i * 2 * d * da, m->dec_layers[i].xkvw, 2 * d * da * sizeof(float),
-                                  hipMemcpyDeviceToDevice));
-                WLK_HIP(hipMemcpy(m->xkv_all_b + i * 2 * d, m->dec_layers[i].xkvb, 2 * d * sizeof(float),
-                                  hipMemcpyDeviceToDevice));
+                copy_sync(m->xkv_all_w + i * 2 * d * da, m->dec_layers[i].xkvw, 2 * d * da * sizeof(float),
+                                  hipMemcpyDeviceToDevice);
+                copy_sync(m->xkv_all_b + i * 2 * d, m->dec_layers[i].xkvb, 2 * d * sizeof(float),
+                                  hipMemcpyDeviceToDevice);
             }
         }
         m->w_tok_emb = m->w("dec.tok_emb");
@@ -978,7 +1010,7 @@ extern "C++" void wlk_prefill_ws_alloc(const wlk_model* m, wlk_prefill_ws& ws, i
     ws.tiles_dev = reinterpret_cast<StepRow*>(dev_alloc<char>(R / 32 * sizeof(StepRow)));
     ws.ring_row_dev = dev_alloc<int>(R);
     ws.zeros_dev = dev_alloc<int>(R);
-    WLK_HIP(hipMemset(ws.zeros_dev, 0, R * sizeof(int)));
+    memset_sync(ws.zeros_dev, 0, R * sizeof(int));
     ws.pinned_bytes = R * sizeof(StepRow) + R / 32 * sizeof(StepRow) + R * sizeof(int);
     WLK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws.pinned), ws.pinned_bytes, hipHostMallocDefault));
 }
@@ -1460,7 +1492,7 @@ static int copy_out(wlk_session* s, const float* dev, uint64_t n, float* host, u
     if (n_written) *n_written = n;
     if (n > cap) return fail(WLK_ERR_CAPACITY, "export buffer too small: need " + std::to_string(n) + " floats");
     WLK_HIP(hipStreamSynchronize(s->stream));
-    WLK_HIP(hipMemcpy(host, dev, n * sizeof(float), hipMemcpyDeviceToHost));
+    copy_sync(host, dev, n * sizeof(float), hipMemcpyDeviceToHost);
     return WLK_OK;
 }
 
@@ -1477,7 +1509,7 @@ int wlk_export(wlk_session* s, const char* what, float* host, uint64_t capacity,
             if (n > capacity) return fail(WLK_ERR_CAPACITY, "export buffer too small");
             std::vector<float> tm(n);
             WLK_HIP(hipStreamSynchronize(s->stream));
-            WLK_HIP(hipMemcpy(tm.data(), s->mel_t + D.n_mels, n * sizeof(float), hipMemcpyDeviceToHost));
+            copy_sync(tm.data(), s->mel_t + D.n_mels, n * sizeof(float), hipMemcpyDeviceToHost);
             for (int t = 0; t < kMelFrames; ++t)
                 for (int mm = 0; mm < D.n_mels; ++mm) host[(size_t)mm * kMelFrames + t] = tm[(size_t)t * D.n_mels + mm];
             return WLK_OK;
@@ -1507,8 +1539,8 @@ int wlk_export(wlk_session* s, const char* what, float* host, uint64_t capacity,
                 if (n > capacity) return fail(WLK_ERR_CAPACITY, "export buffer too small");
                 WLK_HIP(hipStreamSynchronize(s->stream));
                 for (int b = 0; b < s->beam; ++b)
-                    WLK_HIP(hipMemcpy(host + (size_t)b * s->self_len * d, base + (size_t)b * D.n_text_ctx * d,
-                                      (size_t)s->self_len * d * sizeof(float), hipMemcpyDeviceToHost));
+                    copy_sync(host + (size_t)b * s->self_len * d, base + (size_t)b * D.n_text_ctx * d,
+                                      (size_t)s->self_len * d * sizeof(float), hipMemcpyDeviceToHost);
                 return WLK_OK;
             }
             if (kind == "xattn_w") {  // beam 0 window rows of one alignment head: prefill rows then single slots
@@ -1520,10 +1552,10 @@ int wlk_export(wlk_session* s, const char* what, float* host, uint64_t capacity,
                 if (n > capacity) return fail(WLK_ERR_CAPACITY, "export buffer too small");
                 const float* base = s->ring + (size_t)idx * s->beam * s->ring_rows * T;
                 WLK_HIP(hipStreamSynchronize(s->stream));
-                if (pre) WLK_HIP(hipMemcpy(host, base, (size_t)pre * T * sizeof(float), hipMemcpyDeviceToHost));
+                if (pre) copy_sync(host, base, (size_t)pre * T * sizeof(float), hipMemcpyDeviceToHost);
                 if (ns)
-                    WLK_HIP(hipMemcpy(host + (size_t)pre * T, base + (size_t)D.n_text_ctx * T, (size_t)ns * T * sizeof(float),
-                                      hipMemcpyDeviceToHost));
+                    copy_sync(host + (size_t)pre * T, base + (size_t)D.n_text_ctx * T, (size_t)ns * T * sizeof(float),
+                                      hipMemcpyDeviceToHost);
                 return WLK_OK;
             }
         }
@@ -1572,11 +1604,11 @@ int wlk_melspec_create(int device, int n_fft, int win_length, int hop, int n_mel
             if (b == 0) a = 0;
             lo[i] = a; hi[i] = b;
         }
-        WLK_HIP(hipMemcpy(m->window, window, win_length * sizeof(float), hipMemcpyHostToDevice));
-        WLK_HIP(hipMemcpy(m->filters, filters, (size_t)n_mels * nf * sizeof(float), hipMemcpyHostToDevice));
-        WLK_HIP(hipMemcpy(m->twiddle, tw.data(), n_fft * sizeof(double), hipMemcpyHostToDevice));
-        WLK_HIP(hipMemcpy(m->lo, lo.data(), n_mels * sizeof(int), hipMemcpyHostToDevice));
-        WLK_HIP(hipMemcpy(m->hi, hi.data(), n_mels * sizeof(int), hipMemcpyHostToDevice));
+        copy_sync(m->window, window, win_length * sizeof(float), hipMemcpyHostToDevice);
+        copy_sync(m->filters, filters, (size_t)n_mels * nf * sizeof(float), hipMemcpyHostToDevice);
+        copy_sync(m->twiddle, tw.data(), n_fft * sizeof(double), hipMemcpyHostToDevice);
+        copy_sync(m->lo, lo.data(), n_mels * sizeof(int), hipMemcpyHostToDevice);
+        copy_sync(m->hi, hi.data(), n_mels * sizeof(int), hipMemcpyHostToDevice);
         *out = m.release();
         return WLK_OK;
     });

@@ -33,6 +33,13 @@ void set_last_error(const std::string& msg);
 
 // optional per-kernel HIP-event timing (wlk_prof_begin/end)
 struct Profiler;
+// Blocking copies / fills that stay off the legacy (NULL) stream: hipMemcpy / hipMemset make the legacy stream depend on
+// every other stream, and HIP refuses that ("would make the legacy stream depend on a capturing blocking stream") while
+// ANOTHER thread is capturing one of the step graphs - which sessions of other threads do at any time.  These run on a
+// per-device utility stream and wait for it (api.hip).
+void copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+void memset_sync(void* dst, int value, size_t bytes);
+
 struct LaunchCtx {
     hipStream_t stream = nullptr;
     Profiler* prof = nullptr;

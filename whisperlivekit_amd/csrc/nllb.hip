@@ -372,7 +372,7 @@ int wlk_nllb_create(const wlk_nllb_dims* dims, int device, wlk_nllb** out) {
         m->layout = nl_layout(*dims, &m->arena_floats);
         for (const auto& s : m->layout) m->index[s.name] = &s;
         WLK_HIP(hipMalloc(reinterpret_cast<void**>(&m->arena), m->arena_floats * sizeof(float)));
-        WLK_HIP(hipMemset(m->arena, 0, m->arena_floats * sizeof(float)));
+        memset_sync(m->arena, 0, m->arena_floats * sizeof(float));
         *out = m.release();
         return WLK_OK;
     });
@@ -387,7 +387,7 @@ int wlk_nllb_upload(wlk_nllb* m, const char* packed_name, const float* host, uin
             return nl_fail(WLK_ERR_ARG, std::string("size mismatch for ") + packed_name + ": expected " +
                                             std::to_string(it->second->numel) + ", got " + std::to_string(numel));
         WLK_HIP(hipSetDevice(m->device));
-        WLK_HIP(hipMemcpy(m->arena + it->second->offset, host, numel * sizeof(float), hipMemcpyHostToDevice));
+        copy_sync(m->arena + it->second->offset, host, numel * sizeof(float), hipMemcpyHostToDevice);
         m->finalized = false;
         return WLK_OK;
     });

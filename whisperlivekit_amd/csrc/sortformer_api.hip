@@ -262,7 +262,7 @@ int wlk_sf_create(const wlk_sf_dims* dims, int device, wlk_sortformer** out) {
         WLK_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
         wlk_sortformer* p = m.get();
         m->arena = sf_alloc(p, m->arena_floats);
-        WLK_HIP(hipMemset(m->arena, 0, m->arena_floats * sizeof(float)));
+        memset_sync(m->arena, 0, m->arena_floats * sizeof(float));
         const wlk_sf_dims& D = m->D;
         const size_t L = D.max_frames, d = D.fc_d_model, dt = D.tf_d_model, C = D.sub_channels;
         const size_t T1 = sf_sub_len(D.max_feat_frames), F1 = sf_sub_len(D.n_mels);
@@ -296,7 +296,7 @@ int wlk_sf_upload(wlk_sortformer* m, const char* packed_name, const float* host,
             return sf_fail(WLK_ERR_ARG, std::string("size mismatch for ") + packed_name + ": expected " +
                                             std::to_string(it->second->numel) + ", got " + std::to_string(numel));
         WLK_HIP(hipSetDevice(m->device));
-        WLK_HIP(hipMemcpy(m->arena + it->second->offset, host, numel * sizeof(float), hipMemcpyHostToDevice));
+        copy_sync(m->arena + it->second->offset, host, numel * sizeof(float), hipMemcpyHostToDevice);
         m->finalized = false;
         return WLK_OK;
     });
@@ -411,7 +411,7 @@ int wlk_sf_export(wlk_sortformer* m, const char* what, float* host, uint64_t cap
         else if (!strcmp(what, "tf_out")) { src = m->tx; n = (uint64_t)m->last_T * m->D.tf_d_model; }
         else return sf_fail(WLK_ERR_ARG, std::string("unknown export ") + what);
         if (n > capacity) return sf_fail(WLK_ERR_CAPACITY, "export buffer too small");
-        WLK_HIP(hipMemcpy(host, src, n * sizeof(float), hipMemcpyDeviceToHost));
+        copy_sync(host, src, n * sizeof(float), hipMemcpyDeviceToHost);
         if (n_written) *n_written = n;
         return WLK_OK;
     });

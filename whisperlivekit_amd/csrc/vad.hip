@@ -242,7 +242,7 @@ int wlk_vad_create(int device, const float* packed_host, uint64_t n_floats, wlk_
         auto m = std::make_unique<wlk_vad>();
         m->device = device;
         WLK_HIP(hipMalloc(reinterpret_cast<void**>(&m->arena), n_floats * sizeof(float)));
-        WLK_HIP(hipMemcpy(m->arena, packed_host, n_floats * sizeof(float), hipMemcpyHostToDevice));
+        copy_sync(m->arena, packed_host, n_floats * sizeof(float), hipMemcpyHostToDevice);
         const float* a = m->arena;
         auto at = [&](int i) { return a + vad_offset(i); };
         m->W = VadWeights{at(0), at(1), at(2), at(3), at(4), at(5), at(6), at(7), at(8), at(9), at(10), at(11), at(12),
@@ -321,8 +321,8 @@ int wlk_vad_stream_state(wlk_vad_stream* s, float* h_host, float* c_host) {
     return vad_guarded([&]() {
         WLK_HIP(hipSetDevice(s->m->device));
         WLK_HIP(hipStreamSynchronize(s->stream));
-        WLK_HIP(hipMemcpy(h_host, s->state, kVadHid * sizeof(float), hipMemcpyDeviceToHost));
-        WLK_HIP(hipMemcpy(c_host, s->state + kVadHid, kVadHid * sizeof(float), hipMemcpyDeviceToHost));
+        copy_sync(h_host, s->state, kVadHid * sizeof(float), hipMemcpyDeviceToHost);
+        copy_sync(c_host, s->state + kVadHid, kVadHid * sizeof(float), hipMemcpyDeviceToHost);
         return WLK_OK;
     });
 }

@@ -290,9 +290,9 @@ int wlk_find_alignment(wlk_session* s, const int64_t* tokens, int32_t n_tokens, 
         launch_dtw(s->stream, cost, N, F, trace_t, trace);
         // results: three copies behind one synchronisation (host buffers are the caller's: pageable, so synchronous)
         WLK_HIP(hipStreamSynchronize(s->stream));
-        WLK_HIP(hipMemcpy(trace_host, trace, n_trace, hipMemcpyDeviceToHost));
-        WLK_HIP(hipMemcpy(token_probs_host, probs, (size_t)n_text * sizeof(float), hipMemcpyDeviceToHost));
-        if (cost_host) WLK_HIP(hipMemcpy(cost_host, cost, n_cost * sizeof(float), hipMemcpyDeviceToHost));
+        copy_sync(trace_host, trace, n_trace, hipMemcpyDeviceToHost);
+        copy_sync(token_probs_host, probs, (size_t)n_text * sizeof(float), hipMemcpyDeviceToHost);
+        if (cost_host) copy_sync(cost_host, cost, n_cost * sizeof(float), hipMemcpyDeviceToHost);
         // the window no longer holds what the streaming read-out expects: the next decode of this session must be a prefill
         s->n_steps = 0;
         s->self_len = 0;
