@@ -49,9 +49,11 @@ def _new_proc(asr):
     ("micro.en", ["micro_12s", "micro_34s_evict", "micro_neverfire", "micro_12s", "micro_34s_evict", "micro_neverfire",
                   "micro_12s", "micro_12s"]),
 ])
-def test_eight_threads_share_one_model(model_name, cases):
+def test_eight_threads_share_one_model(model_name, cases, monkeypatch):
     """8 threads replay 8 golden streams simultaneously on ONE HipWhisperModel: every session's decisions equal the
-    reference's, and equal (bit for bit: token ids, frames, emitted words) what the same session yields when run alone."""
+    reference's, and equal (bit for bit: token ids, frames, emitted words) what the same session yields when run alone.
+    The prefill lane is opened from two busy sessions on (default nine) so that stacked prefills are part of the run."""
+    monkeypatch.setenv("WLK_PREFILL_MIN_SESSIONS", "2")
     from whisperlivekit_amd.backend import HipSimulStreamingASR
     from whisperlivekit_amd.engine import HipWhisperModel
     for c in cases:
@@ -101,6 +103,8 @@ def test_eight_threads_share_one_model(model_name, cases):
             p.close()
     stats = model.engine_stats()
     assert stats["batched_steps"] > 0 and stats["mean_rows_per_batched_step"] >= 2.0, stats   # the loops really shared steps
+    if MODEL_DIMS[model_name].n_text_state >= 256:      # narrower models never qualify for the stacked chain (k-wave GEMMs)
+        assert stats["stacked_prefills"] > 0, stats
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, f"engine_stats_{model_name}.json"), "w") as fh:
