@@ -100,6 +100,24 @@ def check_case(case, model, monkeypatch):
     return replay
 
 
+def test_categorical_draw_is_torchs():
+    """The sampling step of the fallback temperatures: same tokens and the same generator state afterwards as
+    torch.distributions.Categorical(logits=...).sample() (decoding.py:277), masked entries included."""
+    rng = np.random.default_rng(0)
+    for seed in range(120):
+        x = torch.from_numpy((rng.standard_normal((1 + seed % 3, 51864)) * 3).astype(np.float32))
+        x[0, 100:40000] = float("-inf")
+        t = (0.2, 0.4, 0.6, 0.8, 1.0)[seed % 5]
+        torch.manual_seed(seed)
+        want = torch.distributions.Categorical(logits=x / t).sample()
+        after_want = torch.rand(1)
+        torch.manual_seed(seed)
+        got = TR.choose(x.clone(), t)
+        after_got = torch.rand(1)
+        assert got.tolist() == want.tolist(), seed
+        assert float(after_got) == float(after_want), seed
+
+
 @pytest.mark.parametrize("case", KAT, ids=lambda c: c["name"])
 def test_transcribe_host_logic_over_the_oracle(case, real_vocab, monkeypatch):
     from oracle_session import OracleModel

@@ -6,9 +6,9 @@ rules, greedy, sampling and beam search, ranking), ``detect_language()`` = ``dec
 What runs where: the log-mel of the whole recording (``wlk_log_mel``), the encoder and cross-K/V of each window
 (``wlk_encode_mel``), every decoder step with its KV cache (``wlk_decode`` / ``wlk_kv_reorder``), the no-speech probability
 and the device half of the word alignment (``wlk_find_alignment``) are HIP kernels.  The per-step logit rules are a handful
-of masked fills and one log-softmax over the vocabulary row the step produced; they run on that row on the host with the
-same torch CPU operators the reference applies (and the same ``Categorical`` draw, so a seeded run consumes the generator
-exactly as the reference does).  There is no CPU model path: without the library / a GPU the first call raises.
+of masked fills and one log-softmax over the vocabulary row the step produced; they run on that row on the host
+(single-threaded numpy; the sampling draw takes its random numbers from torch's global generator exactly as the reference's
+``Categorical.sample()`` does, so a seeded run consumes the generator as the reference does).  There is no CPU model path: without the library / a GPU the first call raises.
 
 Same keyword names, defaults and result dictionary as the reference; ``fp16`` is accepted and ignored (the path computes
 in fp32, as the reference does on its CPU).  Decoding a file name (ffmpeg) is outside the path: ``audio`` is samples.
@@ -90,7 +90,20 @@ def choose(logits: torch.Tensor, temperature: float) -> torch.Tensor:
     the reference's recorded choices step by step."""
     if temperature == 0:
         return torch.from_numpy(logits.numpy().argmax(axis=-1))
-    return torch.distributions.Categorical(logits=logits / temperature).sample()
+    return _categorical_draw(logits.numpy() / np.float32(temperature))
+
+
+def _categorical_draw(scaled: np.ndarray) -> torch.Tensor:
+    """``Categorical(logits=scaled).sample()`` with the same consumption of torch's global generator and the same result:
+    a single draw per row goes through ``torch.multinomial``'s one-sample path, argmax(p / q) with q ~ Exp(1) drawn per
+    vocabulary entry.  Only the exponentials come from torch (that is the generator's part); the softmax, the division and
+    the arg-max are single-threaded numpy - torch hands each of these 50k-element rows to its whole intra-op pool (34 ms
+    per draw on a 128-thread host).  tests/test_transcribe.py::test_categorical_draw_is_torchs pins the equivalence."""
+    m = scaled.max(axis=-1, keepdims=True)
+    e = np.exp(scaled - m)
+    p = e / e.sum(axis=-1, keepdims=True, dtype=np.float32)
+    q = torch.empty(p.shape, dtype=torch.float32).exponential_(1)
+    return torch.from_numpy((p / q.numpy()).argmax(axis=-1))
 
 
 # ---- the model-side handle --------------------------------------------------------------------------------------------------
