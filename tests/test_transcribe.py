@@ -248,3 +248,28 @@ def test_hip_transcribe_is_reentrant_on_a_shared_model(real_vocab):
     finally:
         TR.release_sessions(model)
         model.close()
+
+
+def test_sessions_of_ended_threads_are_released(real_vocab):
+    """The batch path keeps its sessions per calling thread; the entry of a thread that has ended is closed and dropped the
+    next time another thread asks for its own."""
+    import threading
+    from oracle_session import OracleModel
+    model = OracleModel("micro.en", 0)
+    closed = []
+    created = []
+
+    def make(beam=1, max_audio_seconds=64.0, batched=None, _orig=model.new_session):
+        s = _orig(beam, max_audio_seconds, batched)
+        s.close = lambda s=s: closed.append(s)
+        created.append(s)
+        return s
+    model.new_session = make
+    t = threading.Thread(target=lambda: TR._rows_of(model).get(1))
+    t.start(); t.join()
+    assert len(created) == 1 and not closed
+    TR._rows_of(model).get(1)                     # the main thread's first request sweeps the dead thread's entry
+    assert closed == created[:1] and len(created) == 2
+    assert list(model.__dict__["_batch_rows"]) == [threading.get_ident()]
+    TR.release_sessions(model)
+    assert closed == created

@@ -201,6 +201,10 @@ class HipWhisperModel:
                     mean_sessions_per_prefill_batch=round(ps.value / pb.value, 3) if pb.value else None)
 
     def close(self) -> None:
+        # sessions the batch path (transcribe.py) keeps per calling thread hold pointers into this model
+        for rows in (self.__dict__.pop("_batch_rows", None) or {}).values():
+            for sess in rows.sessions.values():
+                sess.close()
         if self._h:
             self.lib.wlk_model_destroy(self._h)
             self._h = C.c_void_p()

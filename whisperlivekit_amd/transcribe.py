@@ -130,11 +130,17 @@ _ROWS_LOCK = threading.Lock()
 
 def _rows_of(model: HipWhisperModel) -> _Rows:
     key = threading.get_ident()
+    stale = []
     with _ROWS_LOCK:
         per_thread = model.__dict__.setdefault("_batch_rows", {})
         r = per_thread.get(key)
         if r is None:
+            alive = {t.ident for t in threading.enumerate()}
+            stale = [per_thread.pop(k) for k in list(per_thread) if k not in alive]     # threads that have ended
             r = per_thread[key] = _Rows(model)
+    for rows in stale:
+        for sess in rows.sessions.values():
+            sess.close()
     return r
 
 
