@@ -18,6 +18,7 @@ What goes in: every `*.py` of the `whisperlivekit` package plus the small data f
 import / run time (`whisper/assets/*`: mel filterbank, rank tables; `simul_whisper/` support files).  What stays out:
 model binaries (`silero_vad_models/*`, 6.9 MB), the web front end, byte-code caches.
 """
+import gzip
 import hashlib
 import io
 import json
@@ -56,7 +57,9 @@ def stage(root: str = "/root/reference", verbose: bool = True) -> str:
                 files.append((rel, full))
     digest = hashlib.sha256()
     buf = io.BytesIO()
-    with tarfile.open(fileobj=buf, mode="w:gz", compresslevel=6) as tar:
+    # the gzip header carries a timestamp of its own: pinned to 0 like the members' (tarfile's "w:gz" would stamp now)
+    with gzip.GzipFile(filename="", fileobj=buf, mode="wb", compresslevel=6, mtime=0) as gz, \
+            tarfile.open(fileobj=gz, mode="w") as tar:
         for rel, full in files:
             with open(full, "rb") as fh:
                 data = fh.read()
