@@ -332,7 +332,7 @@ int wlk_nllb_decode(wlk_nllb_session* s, const int64_t* tokens, int32_t n_rows, 
 int wlk_nllb_step(wlk_nllb_session* s, const int64_t* tokens, int32_t n_rows, int32_t k, float* logprobs, int32_t* ids);
 /* beam bookkeeping: row i of the self-attention cache becomes the old row source_rows[i] */
 int wlk_nllb_kv_reorder(wlk_nllb_session* s, const int32_t* source_rows, int32_t n_rows);
-/* log_softmax(logits) of the latest decode, the k (<= 16) best per row, descending: [rows][k] */
+/* log_softmax(logits) of the latest decode, the k (<= 8) best per row, descending: [rows][k] */
 int wlk_nllb_topk(wlk_nllb_session* s, int32_t k, float* logprobs, int32_t* ids);
 /* parity exports: "logits" [rows][vocab] of the latest decode, "enc" [src_len][d_model] */
 int wlk_nllb_export(wlk_nllb_session* s, const char* what, float* host, uint64_t capacity, uint64_t* n_written);

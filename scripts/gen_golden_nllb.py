@@ -69,6 +69,30 @@ def main():
         cases.append((lang, max_new))
         print(f"case {ci}: src {n_src}, forced prefix {len(tgt)}, generate -> {gen.tolist()[:12]}... ({len(gen)} ids, "
               f"with forced eos {len(gen_eos)} ids, ends {int(gen_eos[-1])})")
+    # ---- beam search: a second weight set whose </s> row is loud enough for hypotheses to end (seed 0, eos_gain 6), so that the
+    # finished-slot bookkeeping, the length penalty and the three early-stopping modes all take part
+    beam_model = M2M100ForConditionalGeneration(hf_cfg).eval()
+    sd5 = {k: torch.from_numpy(v) for k, v in nllb.synth_state_dict(cfg, 0, eos_gain=6.0).items()}
+    beam_model.load_state_dict(sd5, strict=False)
+    beam_model.tie_weights()
+    beam_cases = []
+    specs = [(5, 3, 1.0, False, None, 24), (17, 3, 1.0, False, None, 24), (40, 3, 1.0, False, None, 24),
+             (9, 4, 0.6, False, None, 30), (23, 2, 1.0, True, None, 30), (12, 4, 2.0, "never", None, 16),
+             (31, 3, 1.0, False, cfg.eos_token_id, 12), (64, 5, 0.0, False, None, 20), (3, 8, 1.0, False, None, 10)]
+    for bi, (n_src, beams, lp, es, feos, max_new) in enumerate(specs):
+        src = rng.integers(4, 1900, size=n_src).astype(np.int64)
+        src[-1] = cfg.eos_token_id
+        kw = dict(forced_bos_token_id=1990 + bi, num_beams=beams, do_sample=False, max_new_tokens=max_new, length_penalty=lp,
+                  early_stopping=es)
+        if feos is not None:
+            kw["forced_eos_token_id"] = feos
+        with torch.no_grad():
+            seq = beam_model.generate(torch.from_numpy(src)[None], **kw)[0]
+        out[f"beam_src{bi}"] = src
+        out[f"beam_out{bi}"] = seq.numpy().astype(np.int64)
+        beam_cases.append((1990 + bi, beams, int(round(lp * 1000)), {False: 0, True: 1, "never": 2}[es], -1 if feos is None else feos, max_new))
+        print(f"beam case {bi}: src {n_src}, {beams} beams, length_penalty {lp}, early_stopping {es}: {seq.tolist()}")
+    out["beam_cases"] = np.asarray(beam_cases, np.int64)
     out["cases"] = np.asarray(cases, np.int64)
     path = os.path.join(ROOT, "tests", "golden", "nllb_kat.npz")
     np.savez_compressed(path, **out)

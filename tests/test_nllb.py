@@ -51,6 +51,31 @@ def test_generate_over_the_oracle_matches_transformers(micro_oracle, ci):
                          forced_eos_token_id=nllb.NLLB_MICRO.eos_token_id) == KAT[f"gen_eos{ci}"].tolist()
 
 
+N_BEAM = len(KAT["beam_cases"])
+BEAM_WEIGHTS = dict(seed=0, eos_gain=6.0)       # scripts/gen_golden_nllb.py: a </s> row loud enough for hypotheses to end
+
+
+def _beam_args(bi):
+    lang, beams, lp1000, es, feos, max_new = (int(v) for v in KAT["beam_cases"][bi])
+    return lang, dict(num_beams=beams, max_new_tokens=max_new, length_penalty=lp1000 / 1000.0,
+                      early_stopping={0: False, 1: True, 2: "never"}[es], forced_eos_token_id=None if feos < 0 else feos)
+
+
+@pytest.fixture(scope="module")
+def beam_oracle():
+    return NllbOracle(nllb.NLLB_MICRO, nllb.synth_state_dict(nllb.NLLB_MICRO, BEAM_WEIGHTS["seed"], BEAM_WEIGHTS["eos_gain"]))
+
+
+@pytest.mark.parametrize("bi", range(N_BEAM))
+def test_beam_search_over_the_oracle_matches_transformers(beam_oracle, bi):
+    """whisperlivekit_amd.nllb.beam_search against transformers' generate(num_beams = 2 .. 8): hypotheses that end early
+    and ones that run into the length limit, length penalties 0 / 0.6 / 1 / 2, the three early-stopping modes, a forced
+    last token."""
+    lang, kw = _beam_args(bi)
+    sess = OracleNllbSession(beam_oracle, kw["num_beams"])
+    assert nllb.beam_search(sess, KAT[f"beam_src{bi}"], lang, **kw) == KAT[f"beam_out{bi}"].tolist()
+
+
 def test_pack_names_cover_the_arena_layout():
     """Every packed tensor the library expects is produced by pack_hf_state_dict, with the right size (no GPU needed)."""
     import ctypes as C
@@ -119,6 +144,21 @@ def test_hip_generate_matches_transformers(micro_hip, ci):
                              forced_eos_token_id=nllb.NLLB_MICRO.eos_token_id) == KAT[f"gen_eos{ci}"].tolist()
     finally:
         sess.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bi", range(N_BEAM))
+def test_hip_beam_search_matches_transformers(bi):
+    lang, kw = _beam_args(bi)
+    model = nllb.HipNllbModel.from_hf_state_dict(
+        nllb.NLLB_MICRO, nllb.synth_state_dict(nllb.NLLB_MICRO, BEAM_WEIGHTS["seed"], BEAM_WEIGHTS["eos_gain"]), device=0,
+        max_src=92, max_tgt=64)
+    sess = model.new_session(kw["num_beams"])
+    try:
+        assert nllb.beam_search(sess, KAT[f"beam_src{bi}"], lang, **kw) == KAT[f"beam_out{bi}"].tolist()
+    finally:
+        sess.close()
+        model.close()
 
 
 @pytest.mark.gpu

@@ -534,7 +534,7 @@ int wlk_nllb_step(wlk_nllb_session* s, const int64_t* tokens, int32_t n_rows, in
     if (!s || !tokens || !logprobs || !ids) return nl_fail(WLK_ERR_ARG, "NULL argument");
     if (!s->encoded || s->self_len == 0) return nl_fail(WLK_ERR_STATE, "wlk_nllb_step before the decoder prompt (wlk_nllb_decode first=1)");
     if (n_rows != s->rows) return nl_fail(WLK_ERR_ARG, "n_rows must equal the session's row count");
-    if (k < 1 || k > 16) return nl_fail(WLK_ERR_ARG, "k must be 1..16");
+    if (k < 1 || k > 8) return nl_fail(WLK_ERR_ARG, "k must be 1..8 (the top-k kernel's limit)");
     const wlk_nllb_dims& D = s->m->D;
     if (s->self_len + 1 > D.max_tgt) return nl_fail(WLK_ERR_CAPACITY, "target context exceeded");
     if (!gemv_applicable(n_rows, D.d_model)) return nl_fail(WLK_ERR_ARG, "wlk_nllb_step: too many rows for the single-token path");
@@ -603,7 +603,7 @@ int wlk_nllb_kv_reorder(wlk_nllb_session* s, const int32_t* source_rows, int32_t
 int wlk_nllb_topk(wlk_nllb_session* s, int32_t k, float* logprobs, int32_t* ids) {
     if (!s || !logprobs || !ids) return nl_fail(WLK_ERR_ARG, "NULL argument");
     if (!s->have_logits) return nl_fail(WLK_ERR_STATE, "wlk_nllb_topk before a decode");
-    if (k < 1 || k > 16) return nl_fail(WLK_ERR_ARG, "k must be 1..16");
+    if (k < 1 || k > 8) return nl_fail(WLK_ERR_ARG, "k must be 1..8 (the top-k kernel's limit)");
     return nl_guarded([&]() {
         WLK_HIP(hipSetDevice(s->m->device));
         launch_logsoftmax_topk(s->ctx(), s->logits, s->m->D.vocab, s->rows, k, s->top_vals, s->top_ids, s->topk_scratch, nullptr,

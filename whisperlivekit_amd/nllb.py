@@ -9,8 +9,9 @@ target language code.  This module is that network behind the C ABI (``wlk_nllb_
 * :func:`pack_hf_state_dict` - a ``transformers`` checkpoint's tensors (``model.shared.weight``,
   ``model.encoder.layers.N.self_attn.q_proj.weight`` ...) into the packed arena;
 * :class:`HipNllbModel` / :class:`HipNllbSession` - encoder pass, decoder steps with KV cache, beam reorder, top-k;
-* :func:`generate` - ``GenerationMixin.generate`` for the case the translation backends use: greedy or beam search from
-  ``[decoder_start_token_id]`` with the target language forced as the first generated token and ``</s>`` ending a hypothesis.
+* :func:`generate` / :func:`beam_search` - ``GenerationMixin.generate`` for the cases the translation backends use: greedy
+  or beam search from ``[decoder_start_token_id]`` with the target language forced as the first generated token and
+  ``</s>`` ending a hypothesis.
 
 Pinned by ``transformers``' own ``M2M100ForConditionalGeneration`` on seeded weights (``scripts/gen_golden_nllb.py``,
 ``tests/golden/nllb_kat.npz``).  The streaming policy of ``nllw.OnlineTranslation`` (when to re-translate which prefix) is
@@ -272,8 +273,7 @@ def generate(session, src_ids: Sequence[int], forced_bos_token_id: Optional[int]
     target-language token as the first generated token (ForcedBOSTokenLogitsProcessor) and, when ``forced_eos_token_id``
     is given, ``</s>`` as the last allowed one (ForcedEOSTokenLogitsProcessor); stops at ``</s>``.  Returns the ids
     including the start token, as ``generate`` does.  The arg-max runs on the device (``wlk_nllb_topk``): one read-back
-    of 8 bytes per token.  Beam search is not restated (``wlk_nllb_kv_reorder`` / ``topk(k)`` are the device pieces a
-    caller's beam bookkeeping needs; ``transformers``' own procedure has no pinned answer here)."""
+    of 8 bytes per token.  Beam search: :func:`beam_search`."""
     cfg = session.model.cfg
     if session.rows != 1:
         raise ValueError("generate: greedy decoding needs a 1-row session")
@@ -298,3 +298,97 @@ def generate(session, src_ids: Sequence[int], forced_bos_token_id: Optional[int]
         if nxt == eos:
             break
     return out
+
+
+def beam_search(session, src_ids: Sequence[int], forced_bos_token_id: Optional[int] = None, *, num_beams: int,
+                max_new_tokens: int = 199, length_penalty: float = 1.0, early_stopping=False,
+                forced_eos_token_id: Optional[int] = None) -> List[int]:
+    """``model.generate(input_ids, forced_bos_token_id=..., num_beams=n, do_sample=False, max_new_tokens=...)`` of
+    ``transformers`` 5.x for one sentence (``GenerationMixin._beam_search``, generation/utils.py): per step the 2 n best
+    (beam, token) continuations by accumulated log-probability; those among the n best that end (``</s>`` or the length
+    limit) compete, with score / generated_length ** length_penalty, for the n finished slots; the n best others run on;
+    stop when no running beam can beat the worst finished one (``early_stopping=False``: judged at the current length;
+    ``"never"``: at the maximum length when the penalty favours long outputs; ``True``: as soon as n have finished).
+    Returns the best finished sequence including the start token.  The device supplies the 2 n best log-probabilities of
+    every beam row (``topk``) and reorders the caches (``kv_reorder``); the bookkeeping here is float32 like the original."""
+    cfg = session.model.cfg
+    n, K = int(num_beams), 2 * int(num_beams)
+    if n != session.rows:
+        raise ValueError(f"beam_search: the session has {session.rows} rows, num_beams = {n}")
+    if n > 8:
+        raise ValueError("beam_search: at most 8 beams (rows of a session)")
+    f32 = np.float32
+    V, eos, start, pad = cfg.vocab_size, cfg.eos_token_id, cfg.decoder_start_token_id, cfg.pad_token_id
+    prompt_len, cur_len = 1, 1
+    max_length = prompt_len + max_new_tokens
+    NEG = f32(-1.0e9)
+    run_seq = np.full((n, max_length), pad, np.int64)
+    run_seq[:, 0] = start
+    run_sc = np.full(n, NEG, f32)
+    run_sc[0] = 0.0                                  # identical beams at the start: only the first one counts
+    fin_seq, fin_sc = run_seq.copy(), np.full(n, NEG, f32)
+    fin_done, fin_len = np.zeros(n, bool), np.full(n, prompt_len)
+    unsatisfied = True
+    session.encode(src_ids)
+    while True:
+        if K <= 8:                                    # the device's top-k takes up to 8 per row
+            if cur_len == prompt_len:
+                session.decode(run_seq[:, :cur_len], first=True)
+                top_lp, top_id = session.topk(K)
+            else:
+                top_lp, top_id = session.step(run_seq[:, cur_len - 1], K)
+        else:                                         # 5 .. 8 beams: the rows' logits come back and are cut here
+            session.decode(run_seq[:, :cur_len] if cur_len == prompt_len else run_seq[:, cur_len - 1:cur_len],
+                           first=(cur_len == prompt_len))
+            lp_rows = session.logits().astype(f32)
+            lp_rows = lp_rows - _logsumexp(lp_rows)
+            top_id = np.argpartition(-lp_rows, K - 1, axis=-1)[:, :K]
+            top_lp = np.take_along_axis(lp_rows, top_id, axis=-1)
+        forced = None
+        if forced_bos_token_id is not None and cur_len == 1:
+            forced = int(forced_bos_token_id)
+        elif forced_eos_token_id is not None and cur_len == max_length - 1:
+            forced = int(forced_eos_token_id)
+        if forced is not None:                       # Forced*TokenLogitsProcessor: 0 for the token, -inf for the rest
+            top_lp = np.full((n, K), -np.inf, f32)
+            top_lp[:, 0] = 0.0
+            top_id = np.tile(np.arange(K, dtype=np.int64), (n, 1))
+            top_id[top_id == forced] = K               # the filler ids only have to differ from the forced one
+            top_id[:, 0] = forced
+        total = (top_lp.astype(f32) + run_sc[:, None]).reshape(-1)
+        flat = (np.arange(n)[:, None] * V + top_id.astype(np.int64)).reshape(-1)
+        order = np.lexsort((flat, -total))[:K]         # descending score, ties by the flattened (beam, token) index
+        cand_sc, cand_b, cand_tok = total[order], flat[order] // V, flat[order] % V
+        cand_seq = run_seq[cand_b].copy()
+        cand_seq[:, cur_len] = cand_tok
+        hits = (cand_tok == eos) | (cur_len + 1 >= max_length)
+        # the n best continuations that go on
+        going = cand_sc + hits.astype(f32) * NEG
+        keep = np.argsort(-going, kind="stable")[:n]
+        # the finished slots: candidates among the n best that just ended, against what is already there
+        ended = hits & (np.arange(K) < n)
+        score = (cand_sc / f32((cur_len + 1 - prompt_len) ** length_penalty)).astype(f32)
+        score = score + f32(bool(fin_done.all()) and early_stopping is True) * NEG
+        score = score + f32(not unsatisfied) * NEG
+        score = score + (~ended).astype(f32) * NEG
+        all_sc = np.concatenate([fin_sc, score])
+        best = np.argsort(-all_sc, kind="stable")[:n]
+        fin_seq = np.concatenate([fin_seq, cand_seq])[best]
+        fin_done = np.concatenate([fin_done, ended])[best]
+        fin_len = np.concatenate([fin_len, np.full(K, cur_len + 1)])[best]
+        fin_sc = all_sc[best]
+        run_seq, run_sc = cand_seq[keep], going[keep]
+        session.kv_reorder(cand_b[keep])
+        cur_len += 1
+        horizon = (max_length - prompt_len) if (early_stopping == "never" and length_penalty > 0.0) else (cur_len - prompt_len)
+        best_running = run_sc[0] / f32(horizon ** length_penalty)
+        worst_finished = np.where(fin_done, fin_sc.min(), NEG)
+        unsatisfied = unsatisfied and bool((best_running > worst_finished).any())
+        if not (unsatisfied and not (bool(fin_done.all()) and early_stopping is True) and not bool(hits.all())):
+            break
+    return fin_seq[0, :fin_len[0]].tolist()
+
+
+def _logsumexp(x: np.ndarray) -> np.ndarray:
+    m = x.max(axis=-1, keepdims=True)
+    return m + np.log(np.exp(x - m).sum(axis=-1, keepdims=True, dtype=np.float32))
