@@ -10,7 +10,7 @@ tests/test_nllb.py::test_oracle_matches_transformers.
 Parameters are addressed by their `transformers` names (model.encoder.layers.N.self_attn.q_proj.weight ...).
 """
 import math
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import torch
 import torch.nn.functional as F
