@@ -387,6 +387,9 @@ int wlk_engine_prefill_stats(wlk_model* m, uint64_t* batches, uint64_t* sessions
 int wlk_diag_encoder_attention_time(int t, int d, int n_head, int k_splits, int reps, float* us_per_launch);
 /* qkv [t, 3d] with q and k pre-scaled -> softmax(q k^T) v per 64-wide head, out [t, d] */
 int wlk_diag_encoder_attention(const float* qkv, int t, int d, int n_head, float* out);
+/* the VALU wave butterflies of csrc/wave_ops.h (DPP / v_permlane{16,32}_swap) against the __shfl_xor loops they replace,
+ * on one wave of 64 floats: ten rows of 64 results each (sum, max, 16-lane sum, xor 1 .. 32 exchanges, arg-max index) */
+int wlk_diag_wave_ops(const float* in64, float* out640, float* ref640);
 
 #ifdef __cplusplus
 }

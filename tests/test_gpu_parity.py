@@ -508,6 +508,24 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
     assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1])
 
 
+def test_valu_wave_butterflies_equal_the_shuffle_loops():
+    """csrc/wave_ops.h: sum / max / 16-lane sum / xor exchanges / arg-max through DPP and v_permlane{16,32}_swap against
+    the __shfl_xor loops they replace in every latency-bound kernel - bit for bit, on values whose sums round."""
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    for trial in range(8):
+        x = (rng.standard_normal(64) * 10.0 ** rng.integers(-3, 4, 64)).astype(np.float32)
+        if trial == 7:
+            x[:] = np.float32(1.5)                      # all ties: the arg-max must name lane 0
+        out = np.empty((10, 64), np.float32)
+        ref = np.empty((10, 64), np.float32)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert lib.wlk_diag_wave_ops(vp(x), vp(out), vp(ref)) == 0, lib.wlk_diag_last_error()
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), np.argwhere(out.view(np.uint32) != ref.view(np.uint32))
+        assert np.array_equal(out[8], np.roll(x, 32)) and np.array_equal(out[3], x.reshape(32, 2)[:, ::-1].reshape(-1))
+        assert out[9, 0] == float(np.argmax(x))
+
+
 def test_pcm16_upload_equals_float_upload():
     """wlk_audio_append_pcm16 == convert_pcm_to_float (audio_processor.py:416-418) + wlk_audio_append, bit for bit
     (the widening is an exact power-of-two scale), including a chunk larger than the pinned staging buffer."""

@@ -12,8 +12,11 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwlk_hip.so")
 SOURCES = ["api.hip", "gemm_f32.hip", "layernorm.hip", "mel.hip", "attention.hip", "decoder.hip", "select.hip", "diag.hip", "melspec.hip",
            "sortformer.hip", "sortformer_api.hip", "vad.hip", "loop.hip", "engine.hip", "dtw.hip", "word_align.hip", "nllb.hip"]
+# -amdgpu-kernarg-preload-count: leading scalar kernel arguments arrive in SGPRs at wave start (gfx950 firmware preloads
+# them; the compiler keeps a fallback prologue) instead of behind an s_load round trip - the decode-step kernels are
+# chains of dependent latencies, and this is the first link of every one of them
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def _hipcc() -> str:

@@ -230,6 +230,7 @@ int wlk_model_create(const wlk_dims* dims, int device, float* arena_dev, wlk_mod
         m->filt_hi = dev_alloc<int>(dims->n_mels);
         m->head_rank = dev_alloc<int>((size_t)dims->n_text_layer * dims->n_text_head);
         m->layer_ranks = dev_alloc<int>((size_t)dims->n_text_layer * dims->n_text_head);
+        m->layer_heads = dev_alloc<int>((size_t)dims->n_text_layer * dims->n_text_head);
         m->all_ranks = dev_alloc<int>((size_t)dims->n_text_layer * dims->n_text_head);
         {
             std::vector<int> iota((size_t)dims->n_text_layer * dims->n_text_head);
@@ -286,6 +287,13 @@ int wlk_model_set_alignment_heads(wlk_model* m, const int32_t* pairs, int n_pair
         m->layer_rank_count.assign(L, 0);
         for (int i = 0; i < n_pairs; ++i) compact[(size_t)pairs[2 * i] * H + m->layer_rank_count[pairs[2 * i]]++] = i;
         copy_sync(m->layer_ranks, compact.data(), compact.size() * sizeof(int), hipMemcpyHostToDevice);
+        std::vector<int> heads((size_t)L * H, 0);
+        for (int l = 0; l < L; ++l) {
+            int n = 0;
+            for (int h = 0; h < H; ++h)
+                if (rank[(size_t)l * H + h] >= 0) heads[(size_t)l * H + n++] = h;
+        }
+        copy_sync(m->layer_heads, heads.data(), heads.size() * sizeof(int), hipMemcpyHostToDevice);
         m->align_pairs.assign(pairs, pairs + 2 * n_pairs);
         m->n_align = n_pairs;
         return WLK_OK;
@@ -350,6 +358,7 @@ int wlk_model_destroy(wlk_model* m) {
     (void)hipFree(m->filt_lo);
     (void)hipFree(m->filt_hi);
     (void)hipFree(m->head_rank);
+    (void)hipFree(m->layer_heads);
     (void)hipFree(m->layer_ranks);
     (void)hipFree(m->all_ranks);
     delete m;
@@ -942,6 +951,7 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
                 if (merged_xout) {
                     xo_mg.mg_pm = pm; xo_mg.mg_pl = pl; xo_mg.mg_po = po; xo_mg.mg_scores = sc;
                     xo_mg.mg_head_rank = ranks_l; xo_mg.mg_ring = s->ring; xo_mg.mg_ring_row = s->ring_row;
+                    xo_mg.mg_side_heads = m->layer_heads + (size_t)i * H;
                     xo_mg.mg_beam_of_row = s->beam_of_row; xo_mg.mg_heads = H; xo_mg.mg_T = T;
                     xo_mg.mg_ring_rows = s->ring_rows; xo_mg.mg_n_beam = s->beam;
                     xo_mg.mg_side_blocks = ranks_l ? m->layer_rank_count[i] : 0;

@@ -182,6 +182,7 @@ struct GemmArgs {
     const float* mg_po = nullptr;        // [H][kCrossSplit][64]
     const float* mg_scores = nullptr;    // [H][T] raw scores of this layer
     const int* mg_head_rank = nullptr;   // [H] alignment rank or -1
+    const int* mg_side_heads = nullptr;  // [mg_side_blocks] the layer's alignment heads (wlk_model::layer_heads)
     float* mg_ring = nullptr;
     const int* mg_ring_row = nullptr;
     const int* mg_beam_of_row = nullptr;

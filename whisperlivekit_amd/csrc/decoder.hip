@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "wave_ops.h"
 
 namespace wlk {
 
@@ -174,14 +175,18 @@ void launch_kv_append_rows(const LaunchCtx& ctx, const float* qkv, const StepRow
 // before the first dot product is folded.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void decoder_self_attention_kernel(const float* __restrict__ qkv,
-                                                                     const float* __restrict__ kc,
-                                                                     const float* __restrict__ vc,
-                                                                     float* __restrict__ out, int n_tok,
-                                                                     const int* __restrict__ offset_p, int d,
-                                                                     int ctx_len,
+                                                                     const float* __restrict__ kc_in,
+                                                                     const float* __restrict__ vc_in,
                                                                      const StepRow* __restrict__ step_rows,
+                                                                     const int* __restrict__ offset_p, int d,
+                                                                     int ctx_len, int n_tok, float* __restrict__ out,
                                                                      long layer_off) {
-    __shared__ __attribute__((aligned(16))) float qs[64];
+    // Latency diet (round 4): the query slice comes straight from global memory (16 lanes x float4, no LDS stage and no
+    // barrier in front of the keys), and the first 128 keys AND values - a whole decode step's cache in the common case -
+    // are requested before anything is waited for; later chunks (long prompts) loop as before.  The key rows of the first
+    // chunk do not even wait for the cache length (a device scalar): rows past it are allocated cache memory whose scores
+    // are never stored.  The 16-lane dot folds and the wave reductions are VALU butterflies in the original order
+    // (wave_ops.h); the leading arguments arrive preloaded in SGPRs.  Same arithmetic, same results.
     __shared__ float sc[448 + 64];
     __shared__ float red[8];
     __shared__ __attribute__((aligned(16))) float part[16 * 64];
@@ -189,24 +194,37 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(const float
     const int sub = lane & 15, kq = lane >> 4;
     const int row = blockIdx.x;
     const int head = blockIdx.y;
+    const float4 q4 = *reinterpret_cast<const float4*>(qkv + (long)row * 3 * d + head * 64 + sub * 4);
     int offset, b, p;
+    gcf_ptr kc, vc;
     if (step_rows) {             // batched steps: one fed token per row, every row has its own cache
         offset = step_rows[row].offset;
-        kc = step_rows[row].kcache + layer_off;
-        vc = step_rows[row].vcache + layer_off;
+        kc = to_global(step_rows[row].kcache) + layer_off;
+        vc = to_global(step_rows[row].vcache) + layer_off;
         b = 0;
         p = 0;
     } else {
-        offset = *offset_p;
-        b = row / n_tok;
+        offset = *offset_p;      // requested here, needed only behind the key loads
+        kc = to_global(kc_in);
+        vc = to_global(vc_in);
+        b = n_tok == 1 ? row : row / n_tok;      // (decode steps feed one token per row: no division on their path)
         p = row - b * n_tok;
     }
+    const gcf_ptr kb = kc + (long)b * ctx_len * d + head * 64 + sub * 4;
+    const gcf_ptr vb = vc + (long)b * ctx_len * d + head * 64 + sub * 4;
+    float4 kk0[8], vv0[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int j = wave * 4 + 16 * u + kq;
+        kk0[u] = ldg4(kb + (long)(j < ctx_len ? j : 0) * d);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // the key loads go out before the wait for the cache length
     const int n_keys = offset + p + 1;
-    if (tid < 64) qs[tid] = qkv[(long)row * 3 * d + head * 64 + tid];
-    __syncthreads();
-    const float4 q4 = reinterpret_cast<const float4*>(qs)[sub];
-    const float* kb = kc + (long)b * ctx_len * d + head * 64 + sub * 4;
-    const float* vb = vc + (long)b * ctx_len * d + head * 64 + sub * 4;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int j = wave * 4 + 16 * u + kq;
+        vv0[u] = ldg4(vb + (long)(j < n_keys ? j : 0) * d);
+    }
 
     float mx = -INFINITY;
     for (int base = wave * 4; base < n_keys; base += 16 * 8) {
@@ -215,8 +233,8 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(const float
         for (int u = 0; u < 8; ++u) {
             const int j = base + 16 * u + kq;
             const bool ok = j < n_keys;
-            const float4 t = *reinterpret_cast<const float4*>(kb + (long)(ok ? j : 0) * d);
-            kk[u] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (base == wave * 4) kk[u] = kk0[u];
+            else kk[u] = ldg4(kb + (long)(ok ? j : 0) * d);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -226,18 +244,14 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(const float
             acc = fmaf(q4.y, kk[u].y, acc);
             acc = fmaf(q4.z, kk[u].z, acc);
             acc = fmaf(q4.w, kk[u].w, acc);
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            acc += __shfl_xor(acc, 4, 64);
-            acc += __shfl_xor(acc, 8, 64);
+            acc = row16_sum_1248(acc);
             if (j < n_keys) {
                 if (sub == 0) sc[j] = acc;
                 mx = fmaxf(mx, acc);
             }
         }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -247,8 +261,7 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(const float
         sc[j] = e;
         sum += e;
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    sum = wave_sum(sum);
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
     sum = (red[4] + red[5]) + (red[6] + red[7]);
@@ -263,7 +276,8 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(const float
         for (int u = 0; u < 8; ++u) {
             const int j = base + 16 * u + kq;
             const bool ok = j < n_keys;
-            vv[u] = *reinterpret_cast<const float4*>(vb + (long)(ok ? j : 0) * d);
+            if (base == wave * 4) vv[u] = vv0[u];
+            else vv[u] = ldg4(vb + (long)(ok ? j : 0) * d);
             ww[u] = ok ? sc[j] : 0.f;
         }
 #pragma unroll
@@ -290,7 +304,7 @@ void launch_decoder_self_attention(const LaunchCtx& ctx, const float* qkv, const
     if (ctx_len > 448 + 64) throw std::invalid_argument("self-attention: context too long");
     KernelScope ks(ctx, "dec_self_attention");
     hipLaunchKernelGGL(decoder_self_attention_kernel, dim3(n_rows * n_tok, n_head), dim3(256), 0, ctx.stream, qkv,
-                       kc, vc, out, n_tok, offset, d, ctx_len, (const StepRow*)nullptr, 0L);
+                       kc, vc, (const StepRow*)nullptr, offset, d, ctx_len, n_tok, out, 0L);
     WLK_HIP(hipGetLastError());
 }
 
@@ -299,7 +313,7 @@ void launch_decoder_self_attention_rows(const LaunchCtx& ctx, const float* qkv, 
     if (ctx_len > 448 + 64) throw std::invalid_argument("self-attention: context too long");
     KernelScope ks(ctx, "dec_self_attention");
     hipLaunchKernelGGL(decoder_self_attention_kernel, dim3(n_rows, n_head), dim3(256), 0, ctx.stream, qkv,
-                       (const float*)nullptr, (const float*)nullptr, out, 1, (const int*)nullptr, d, ctx_len, rows,
+                       (const float*)nullptr, (const float*)nullptr, rows, (const int*)nullptr, d, ctx_len, 1, out,
                        layer_off);
     WLK_HIP(hipGetLastError());
 }
@@ -344,9 +358,7 @@ __global__ __launch_bounds__(256) void decoder_cross_attention_kernel(CrossAttnA
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int j = base + 16 * u + kq;
-            const bool ok = j < a.T;
-            const float4 t = *reinterpret_cast<const float4*>(kb + (long)(ok ? j : 0) * a.ldkv);
-            kk[u] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            kk[u] = *reinterpret_cast<const float4*>(kb + (long)(j < a.T ? j : 0) * a.ldkv);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -356,18 +368,14 @@ __global__ __launch_bounds__(256) void decoder_cross_attention_kernel(CrossAttnA
             acc = fmaf(q4.y, kk[u].y, acc);
             acc = fmaf(q4.z, kk[u].z, acc);
             acc = fmaf(q4.w, kk[u].w, acc);
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            acc += __shfl_xor(acc, 4, 64);
-            acc += __shfl_xor(acc, 8, 64);
+            acc = row16_sum_1248(acc);
             if (j < a.T) {
                 if (sub == 0) sc[j] = acc;
                 mx = fmaxf(mx, acc);
             }
         }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -384,8 +392,7 @@ __global__ __launch_bounds__(256) void decoder_cross_attention_kernel(CrossAttnA
         sc[j] = e;
         sum += e;
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    sum = wave_sum(sum);
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
     sum = (red[4] + red[5]) + (red[6] + red[7]);
@@ -455,10 +462,24 @@ static_assert(kCrossSplit == kCrossSplitWays, "gemv1's merged operand load assum
 constexpr int kCrossUnroll = 12;   // key-row loads in flight per wave: covers ceil(1500/8)=188 keys / 16
 
 // UB = float4 chunks of K per lane in the folded query projection (d <= 256 UB floats); 0 = q comes from memory
+// Round 4 (latency diet): what the first loads need (K / V / q bases, row stride, T, d, head count) are leading scalar
+// arguments - preloaded into SGPRs at wave start - instead of fields of a by-value CrossAttnArgs that three dependent
+// s_load stages fetched before the first key row could be requested; the rest rides in CrossSplitRest.
+struct CrossSplitRest {
+    long kv_off;                // batched steps: keys / values of row r are step_rows[r].cross_kv + kv_off
+    const float* xq_x;          // folded query projection (UB > 0), see CrossAttnArgs
+    const float* xq_w;
+    const float* xq_b;
+    const float* xq_gamma;
+    const float* xq_beta;
+    float xq_scale;
+};
 template <int UB>
-__global__ __launch_bounds__(256) void cross_split_kernel(CrossAttnArgs a, float* __restrict__ scores,
-                                                          float* __restrict__ pm, float* __restrict__ pl,
-                                                          float* __restrict__ po) {
+__global__ __launch_bounds__(256) void cross_split_kernel(const float* __restrict__ k_in, const float* __restrict__ v_in,
+                                                          const float* __restrict__ q_in, long ldkv, int T, int d, int n_head,
+                                                          const StepRow* __restrict__ step_rows,
+                                                          float* __restrict__ scores, float* __restrict__ pm,
+                                                          float* __restrict__ pl, float* __restrict__ po, CrossSplitRest a) {
     __shared__ __attribute__((aligned(16))) float qs[64];
     __shared__ float sc[kCrossUnroll * 16];
     __shared__ float red[8];
@@ -466,29 +487,41 @@ __global__ __launch_bounds__(256) void cross_split_kernel(CrossAttnArgs a, float
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = blockIdx.x, head = blockIdx.y, ks = blockIdx.z;
     const int sub = lane & 15, kq = lane >> 4;
-    const int chunk = (a.T + kCrossSplit - 1) / kCrossSplit;
-    const int k_lo = ks * chunk, k_hi = min(a.T, k_lo + chunk);
-    const float* kbase = a.step_rows ? a.step_rows[row].cross_kv + a.kv_off : a.k;
-    const float* kb = kbase + head * 64 + sub * 4;
-    const float* vb = (a.step_rows ? kbase + a.d : a.v) + head * 64 + sub * 4;
-    float* srow = scores + ((long)row * a.n_head + head) * a.T;
+    const int chunk = (T + kCrossSplit - 1) / kCrossSplit;
+    const int k_lo = ks * chunk, k_hi = min(T, k_lo + chunk);
+    const gcf_ptr kbase = to_global(step_rows ? step_rows[row].cross_kv + a.kv_off : k_in);
+    const gcf_ptr kb = kbase + head * 64 + sub * 4;
+    const gcf_ptr vb = (step_rows ? kbase + d : to_global(v_in)) + head * 64 + sub * 4;
+    float* srow = scores + ((long)row * n_head + head) * T;
 
+    // every lane fetches its float4 of the query itself (16 distinct addresses per wave): no LDS stage, no barrier; first
+    // in the queue, because loads return in order and the query is what the first dot product waits for
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (UB == 0) q4 = *reinterpret_cast<const float4*>(q_in + (long)row * d + head * 64 + sub * 4);
     // the key rows do not depend on the query: all of them are requested before the query is derived / fetched
+    // (addresses by pointer increments: one 64-bit multiply per lane instead of one per row)
+    const long row_step = 16 * ldkv;
+    const int j0 = k_lo + wave * 4 + kq;
+    const gcf_ptr k_first = kb + (long)j0 * ldkv, k_safe = kb + (long)k_lo * ldkv;
+    const long v_minus_k = vb - kb;
     float4 kk[kCrossUnroll];
 #pragma unroll
     for (int u = 0; u < kCrossUnroll; ++u) {
-        const int j = k_lo + wave * 4 + 16 * u + kq;
-        const bool ok = j < k_hi;
-        const float4 t = *reinterpret_cast<const float4*>(kb + (long)(ok ? j : k_lo) * a.ldkv);
-        kk[u] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        // (no zeroing of the rows past k_hi: their scores are never stored or folded, and a select on the loaded value
+        // lets hipcc sink each load into its own branch - twelve predicated loads with a vmcnt(0) in between)
+        kk[u] = ldg4(j0 + 16 * u < k_hi ? k_first + u * row_step : k_safe);
     }
-    if constexpr (UB == 0) {
-        if (tid < 64) qs[tid] = a.q[(long)row * a.d + head * 64 + tid];
-    } else {
+    // ... and so are the value rows (round 4: they used to be requested behind the softmax - one more memory round trip
+    // on a kernel that is nothing but round trips)
+    float4 vv[kCrossUnroll];
+#pragma unroll
+    for (int u = 0; u < kCrossUnroll; ++u)
+        vv[u] = ldg4((j0 + 16 * u < k_hi ? k_first + u * row_step : k_safe) + v_minus_k);
+    if constexpr (UB != 0) {
         // q_h = scale * (Wq[64 head + i, :] . LN(x_row) + b), i = 0..63: wave w derives i = 16 w .. 16 w + 15.  Statement for
         // statement gemv1_f32_kernel's arithmetic (fused LayerNorm statistics over lane-strided scalars, lane-strided
         // float4 fmaf chains, xor-shuffle folds), which is also what every row of the multi-row GEMV computes.
-        const int K = a.d, K4 = K >> 2;
+        const int K = d, K4 = K >> 2;
         const float* xrow = a.xq_x + (long)row * K;
         float4 x[UB];
 #pragma unroll
@@ -505,8 +538,7 @@ __global__ __launch_bounds__(256) void cross_split_kernel(CrossAttnArgs a, float
                 v[i] = c < K ? xrow[c] : 0.f;
                 sum += v[i];
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+            sum = wave_sum(sum);
             const float mean = sum / (float)K;
             float sq = 0.f;
 #pragma unroll
@@ -514,8 +546,7 @@ __global__ __launch_bounds__(256) void cross_split_kernel(CrossAttnArgs a, float
                 const float t = (lane + 64 * i) < K ? v[i] - mean : 0.f;
                 sq += t * t;
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+            sq = wave_sum(sq);
             const float rstd = 1.0f / sqrtf(sq / (float)K + 1e-5f);
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
@@ -554,8 +585,7 @@ __global__ __launch_bounds__(256) void cross_split_kernel(CrossAttnArgs a, float
                         acc = fmaf(w[r][u].w, x[u].w, acc);
                     }
                 }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+                acc = wave_sum(acc);
                 if (lane == 0) {
                     const int n = head * 64 + wave * 16 + i0 + r;
                     float v = acc;
@@ -565,9 +595,9 @@ __global__ __launch_bounds__(256) void cross_split_kernel(CrossAttnArgs a, float
                 }
             }
         }
+        __syncthreads();
+        q4 = reinterpret_cast<const float4*>(qs)[sub];
     }
-    __syncthreads();
-    const float4 q4 = reinterpret_cast<const float4*>(qs)[sub];
     float mx = -INFINITY;
 #pragma unroll
     for (int u = 0; u < kCrossUnroll; ++u) {
@@ -577,17 +607,13 @@ __global__ __launch_bounds__(256) void cross_split_kernel(CrossAttnArgs a, float
         acc = fmaf(q4.y, kk[u].y, acc);
         acc = fmaf(q4.z, kk[u].z, acc);
         acc = fmaf(q4.w, kk[u].w, acc);
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 4, 64);
-        acc += __shfl_xor(acc, 8, 64);
+        acc = row16_sum_1248(acc);
         if (j < k_hi) {
             if (sub == 0) { sc[j - k_lo] = acc; srow[j] = acc; }
             mx = fmaxf(mx, acc);
         }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -597,18 +623,11 @@ __global__ __launch_bounds__(256) void cross_split_kernel(CrossAttnArgs a, float
         sc[j] = e;
         sum += e;
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    sum = wave_sum(sum);
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
     sum = (red[4] + red[5]) + (red[6] + red[7]);
 
-    float4 vv[kCrossUnroll];
-#pragma unroll
-    for (int u = 0; u < kCrossUnroll; ++u) {
-        const int j = k_lo + wave * 4 + 16 * u + kq;
-        vv[u] = *reinterpret_cast<const float4*>(vb + (long)(j < k_hi ? j : k_lo) * a.ldkv);
-    }
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int u = 0; u < kCrossUnroll; ++u) {
@@ -621,7 +640,7 @@ __global__ __launch_bounds__(256) void cross_split_kernel(CrossAttnArgs a, float
     }
     reinterpret_cast<float4*>(part)[(wave * 4 + kq) * 16 + sub] = o;
     __syncthreads();
-    const long slot = ((long)row * a.n_head + head) * kCrossSplit + ks;
+    const long slot = ((long)row * n_head + head) * kCrossSplit + ks;
     if (tid < 64) {
         float acc = 0.f;
 #pragma unroll
@@ -669,15 +688,20 @@ void launch_decoder_cross_attention_split(const LaunchCtx& ctx, const CrossAttnA
     {
         KernelScope ks(ctx, "dec_cross_split", 4.0 * a.rows * (double)a.T * a.d, 4.0 * 2.0 * a.rows * (double)a.T * a.d);
         const dim3 grid(a.rows, a.n_head, kCrossSplit);
+        const CrossSplitRest rest{a.kv_off, a.xq_x, a.xq_w, a.xq_b, a.xq_gamma, a.xq_beta, a.xq_scale};
+#define WLK_CROSS_SPLIT(UBv)                                                                                              \
+    hipLaunchKernelGGL(cross_split_kernel<UBv>, grid, dim3(256), 0, ctx.stream, a.k, a.v, a.q, a.ldkv, a.T, a.d, a.n_head, \
+                       a.step_rows, scores, pm, pl, po, rest)
         if (a.xq_w) {
             if (!cross_split_folds_query(a.d)) throw std::invalid_argument("cross-attention: cannot fold the query projection");
             const int ub = a.d / 256;
-            if (ub <= 2) hipLaunchKernelGGL(cross_split_kernel<2>, grid, dim3(256), 0, ctx.stream, a, scores, pm, pl, po);
-            else if (ub <= 4) hipLaunchKernelGGL(cross_split_kernel<4>, grid, dim3(256), 0, ctx.stream, a, scores, pm, pl, po);
-            else hipLaunchKernelGGL(cross_split_kernel<8>, grid, dim3(256), 0, ctx.stream, a, scores, pm, pl, po);
+            if (ub <= 2) WLK_CROSS_SPLIT(2);
+            else if (ub <= 4) WLK_CROSS_SPLIT(4);
+            else WLK_CROSS_SPLIT(8);
         } else {
-            hipLaunchKernelGGL(cross_split_kernel<0>, grid, dim3(256), 0, ctx.stream, a, scores, pm, pl, po);
+            WLK_CROSS_SPLIT(0);
         }
+#undef WLK_CROSS_SPLIT
         WLK_HIP(hipGetLastError());
     }
     if (merge) {   // beam-1 steps fold the merge into the out-projection GEMV (GemmArgs::mg_*)

@@ -7,6 +7,7 @@
 #include "../../include/wlk_hip.h"
 #include "common.h"
 #include "internal.h"
+#include "wave_ops.h"
 
 using namespace wlk;
 
@@ -32,6 +33,56 @@ int run(F&& f) {
     }
 }
 }  // namespace
+
+
+// wave_ops.h against the __shfl_xor loops it replaces: out[0..9][lane] = VALU-butterfly results, ref[0..9][lane] = the
+// shuffle forms, on the same 64 floats (rows: sum, max, row16 sum 1-2-4-8, xor 1, 2, 4, 8, 16, 32, arg-max index)
+__global__ __launch_bounds__(64) void wave_ops_probe_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            float* __restrict__ ref) {
+    const int lane = threadIdx.x;
+    const float v = in[lane];
+    out[0 * 64 + lane] = wave_sum(v);
+    out[1 * 64 + lane] = wave_max(v);
+    out[2 * 64 + lane] = row16_sum_1248(v);
+    out[3 * 64 + lane] = wave_xor<1>(v);
+    out[4 * 64 + lane] = wave_xor<2>(v);
+    out[5 * 64 + lane] = wave_xor<4>(v);
+    out[6 * 64 + lane] = wave_xor<8>(v);
+    out[7 * 64 + lane] = wave_xor<16>(v);
+    out[8 * 64 + lane] = wave_xor<32>(v);
+    {
+        float bv = v;
+        int bi = lane;
+        wave_argmax(bv, bi);
+        out[9 * 64 + lane] = (float)bi;
+    }
+    float s = v, m = v, r = v;
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    r += __shfl_xor(r, 1, 64);
+    r += __shfl_xor(r, 2, 64);
+    r += __shfl_xor(r, 4, 64);
+    r += __shfl_xor(r, 8, 64);
+    ref[0 * 64 + lane] = s;
+    ref[1 * 64 + lane] = m;
+    ref[2 * 64 + lane] = r;
+    ref[3 * 64 + lane] = __shfl_xor(v, 1, 64);
+    ref[4 * 64 + lane] = __shfl_xor(v, 2, 64);
+    ref[5 * 64 + lane] = __shfl_xor(v, 4, 64);
+    ref[6 * 64 + lane] = __shfl_xor(v, 8, 64);
+    ref[7 * 64 + lane] = __shfl_xor(v, 16, 64);
+    ref[8 * 64 + lane] = __shfl_xor(v, 32, 64);
+    {
+        float bv = v;
+        int bi = lane;
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        ref[9 * 64 + lane] = (float)bi;
+    }
+}
 
 extern "C" {
 
@@ -247,6 +298,17 @@ int wlk_diag_encoder_attention(const float* qkv, int t, int d, int n_head, float
         launch_encoder_attention(ctx, Q.p, O.p, t, d, n_head, 1, S.p);
         WLK_HIP(hipDeviceSynchronize());
         WLK_HIP(hipMemcpy(out, O.p, (size_t)t * d * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+
+int wlk_diag_wave_ops(const float* in64, float* out640, float* ref640) {
+    return run([&]() {
+        DevBuf I(64, in64), O(640), R(640);
+        hipLaunchKernelGGL(wave_ops_probe_kernel, dim3(1), dim3(64), 0, nullptr, I.p, O.p, R.p);
+        WLK_HIP(hipGetLastError());
+        WLK_HIP(hipDeviceSynchronize());
+        WLK_HIP(hipMemcpy(out640, O.p, 640 * sizeof(float), hipMemcpyDeviceToHost));
+        WLK_HIP(hipMemcpy(ref640, R.p, 640 * sizeof(float), hipMemcpyDeviceToHost));
     });
 }
 

@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "wave_ops.h"
 
 namespace wlk {
 
@@ -1184,97 +1185,179 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
 // gamma/beta fetch and the weight fetch are ONE memory round trip instead of "stage x -> barrier -> read LDS".
 // The fused LayerNorm statistics use the scalar lane-strided order of layernorm_kernel (so fused == unfused bit
 // for bit) and the dot products the same fmaf order as gemv_f32_kernel: results are identical to that kernel.
-template <int UB, int RPW>
-__global__ __launch_bounds__(256) void gemv1_f32_kernel(GemmArgs g) {
+//
+// A decode step is ~50 of these launches back to back, each a few microseconds long, so what the kernel costs is its
+// chain of dependent latencies, not its bytes.  Round 4 took the chain apart (ISA of the round-3 kernel):
+//   * the by-value GemmArgs (480 bytes) was fetched by five s_load + s_waitcnt stages, one per branch that first
+//     touched a field, before the first vector load was issued -> the operands the first loads need (W, A, K, N, the
+//     LayerNorm affine, bias, residual) are leading scalar kernel arguments, which hipcc's kernarg preload
+//     (-mllvm -amdgpu-kernarg-preload-count) delivers in SGPRs at wave start; the rest sits in one small struct that is
+//     requested at the top and pinned there (WLK_PIN_S) so that the compiler cannot sink its loads into the epilogue;
+//   * gamma / beta were requested AFTER the first reduction (a second memory round trip), bias / residual / the cache
+//     position in the epilogue (a third) -> every load of the kernel is issued before the first wait;
+//   * the LayerNorm's lane-strided statistics loads were eight predicated branches -> clamped addresses + selects;
+//   * each reduction was six ds_bpermute_b32 + waits (~100 cycles each) -> VALU butterflies (wave_ops.h), same order.
+// The arithmetic is untouched: bit-identical to the round-3 kernel and to the staged kernel
+// (tests/test_gpu_parity.py::test_barrier_free_single_row_gemv_is_bit_identical_to_the_staged_kernel).
+#define WLK_PIN_S(x) asm volatile("" ::"s"(x))
+
+struct Gemv1Tail {             // needed only once the dot products are folded
+    float* C;
+    float* kcache;             // nullptr = no cache append
+    float* vcache;
+    const int* kv_pos;         // always readable (the launcher points it at the weights when there is no cache)
+    int flags;
+    float scale;
+    int scale_cols;
+    int kv_d;
+};
+struct Gemv1Merge {            // A row = cross-attention output still in split form (GemmArgs::mg_*)
+    const float* pm;
+    const float* pl;
+    const float* po;
+    const float* scores;
+    const int* head_rank;
+    const int* side_heads;     // [side_blocks] heads of this layer that are alignment heads
+    float* ring;
+    const int* ring_row;
+    const int* beam_of_row;
+    int T, ring_rows, n_beam, side_blocks;
+};
+
+template <int UB, int RPW, bool LN, bool MG>
+__global__ __launch_bounds__(256) void gemv1_f32_kernel(const float* __restrict__ W, const float* __restrict__ A, int K, int N,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ bias, const float* R, Gemv1Tail t,
+                                                        Gemv1Merge mg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int K4 = g.K >> 2;
-    const int n_groups = (g.N + RPW - 1) / RPW;
-    if (g.mg_pm && (int)blockIdx.x >= (int)gridDim.x - g.mg_side_blocks) {
-        // side job (cross_merge_kernel's tail): softmax row of the k-th alignment head of this layer -> alignment window
-        int k = (int)blockIdx.x - ((int)gridDim.x - g.mg_side_blocks), head = -1;
-        for (int h = 0; h < g.mg_heads; ++h)
-            if (g.mg_head_rank[h] >= 0 && k-- == 0) head = h;
-        if (head < 0) return;
-        const long base = (long)head * kCrossSplitWays;
-        float M = g.mg_pm[base];
+    const int K4 = K >> 2;
+    if constexpr (MG) {
+        if ((int)blockIdx.x >= (int)gridDim.x - mg.side_blocks) {
+            // side job (cross_merge_kernel's tail): softmax row of the k-th alignment head of this layer -> alignment window
+            const int head = mg.side_heads[(int)blockIdx.x - ((int)gridDim.x - mg.side_blocks)];
+            const int rank = mg.head_rank[head];
+            const int ring_row = mg.ring_row[0], beam = mg.beam_of_row[0];
+            const long base = (long)head * kCrossSplitWays;
+            float pmv[kCrossSplitWays], plv[kCrossSplitWays];
 #pragma unroll
-        for (int s = 1; s < kCrossSplitWays; ++s) M = fmaxf(M, g.mg_pm[base + s]);
-        float L = 0.f;
+            for (int s = 0; s < kCrossSplitWays; ++s) { pmv[s] = mg.pm[base + s]; plv[s] = mg.pl[base + s]; }
+            const float* srow = mg.scores + (long)head * mg.T;
+            constexpr int kMaxPer = 8;                    // score values per thread held in flight (T <= 2048)
+            float sv[kMaxPer];
 #pragma unroll
-        for (int s = 0; s < kCrossSplitWays; ++s) L += g.mg_pl[base + s] * expf(g.mg_pm[base + s] - M);
-        float* dst = g.mg_ring + (((long)g.mg_head_rank[head] * g.mg_n_beam + g.mg_beam_of_row[0]) * g.mg_ring_rows +
-                                  g.mg_ring_row[0]) * (long)g.mg_T;
-        const float* srow = g.mg_scores + (long)head * g.mg_T;
-        for (int j = threadIdx.x; j < g.mg_T; j += 256) dst[j] = expf(srow[j] - M) / L;
-        return;
+            for (int i = 0; i < kMaxPer; ++i) {
+                const int j = threadIdx.x + 256 * i;
+                sv[i] = srow[j < mg.T ? j : 0];
+            }
+            float M = pmv[0];
+#pragma unroll
+            for (int s = 1; s < kCrossSplitWays; ++s) M = fmaxf(M, pmv[s]);
+            float L = 0.f;
+#pragma unroll
+            for (int s = 0; s < kCrossSplitWays; ++s) L += plv[s] * expf(pmv[s] - M);
+            float* dst = mg.ring + (((long)rank * mg.n_beam + beam) * mg.ring_rows + ring_row) * (long)mg.T;
+#pragma unroll
+            for (int i = 0; i < kMaxPer; ++i) {
+                const int j = threadIdx.x + 256 * i;
+                if (j < mg.T) dst[j] = expf(sv[i] - M) / L;
+            }
+            for (int j = threadIdx.x + 256 * kMaxPer; j < mg.T; j += 256) dst[j] = expf(srow[j] - M) / L;
+            return;
+        }
     }
+    const int n_groups = (N + RPW - 1) / RPW;
     const int grp = blockIdx.x * 4 + wave;
     if (grp >= n_groups) return;
     const int n_base = grp * RPW;
+
+    // ---- every load of the kernel, before the first wait -------------------------------------------------------------
     float4 w[UB][RPW], x[UB];
+    [[maybe_unused]] float4 ga[UB], be[UB];
+    [[maybe_unused]] float v[UB * 4];
+    [[maybe_unused]] float pmv[UB][kCrossSplitWays], plv[UB][kCrossSplitWays];
+    [[maybe_unused]] float4 pov[UB][kCrossSplitWays];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
         const int c = lane + 64 * u;
-        const bool ok = c < K4;
+        const int cc = c < K4 ? c : 0;
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
-            w[u][r] = *reinterpret_cast<const float4*>(g.W + (long)min(n_base + r, g.N - 1) * g.K + (ok ? c : 0) * 4);
-        if (!g.mg_pm) {
-            x[u] = *reinterpret_cast<const float4*>(g.A + (ok ? c : 0) * 4);
-        } else {   // cross_merge_kernel's arithmetic for the head that owns dims 4c .. 4c+3
-            const int cc = ok ? c : 0;
+            w[u][r] = *reinterpret_cast<const float4*>(W + (long)min(n_base + r, N - 1) * K + cc * 4);
+        if constexpr (!MG) {
+            x[u] = *reinterpret_cast<const float4*>(A + cc * 4);
+        } else {   // cross_merge_kernel's operands for the head that owns dims 4c .. 4c+3
             const int head = (4 * cc) >> 6, dd = (4 * cc) & 63;
             const long base = (long)head * kCrossSplitWays;
-            float M = g.mg_pm[base];
 #pragma unroll
-            for (int s = 1; s < kCrossSplitWays; ++s) M = fmaxf(M, g.mg_pm[base + s]);
+            for (int s = 0; s < kCrossSplitWays; ++s) {
+                pmv[u][s] = mg.pm[base + s];
+                plv[u][s] = mg.pl[base + s];
+                pov[u][s] = *reinterpret_cast<const float4*>(mg.po + (base + s) * 64 + dd);
+            }
+        }
+        if constexpr (LN) {
+            ga[u] = *reinterpret_cast<const float4*>(gamma + cc * 4);
+            be[u] = *reinterpret_cast<const float4*>(beta + cc * 4);
+        }
+    }
+    if constexpr (LN) {
+#pragma unroll
+        for (int i = 0; i < UB * 4; ++i) {
+            const int c = lane + 64 * i;
+            const float f = A[c < K ? c : 0];
+            v[i] = c < K ? f : 0.f;
+        }
+    }
+    const int n_out = min(n_base + (lane < RPW ? lane : 0), N - 1);
+    const float bias_v = bias[n_out];
+    const float res_v = R[n_out];
+    const int kv_pos = *t.kv_pos;
+    WLK_PIN_S(t.C); WLK_PIN_S(t.kcache); WLK_PIN_S(t.vcache); WLK_PIN_S(t.flags); WLK_PIN_S(t.scale);
+    WLK_PIN_S(t.scale_cols); WLK_PIN_S(t.kv_d); WLK_PIN_S(kv_pos);
+
+    // ---- arithmetic (statement for statement the round-3 kernel's) ---------------------------------------------------
+    if constexpr (MG) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            float M = pmv[u][0];
+#pragma unroll
+            for (int s = 1; s < kCrossSplitWays; ++s) M = fmaxf(M, pmv[u][s]);
             float L = 0.f;
             float f[kCrossSplitWays];
 #pragma unroll
             for (int s = 0; s < kCrossSplitWays; ++s) {
-                f[s] = expf(g.mg_pm[base + s] - M);
-                L += g.mg_pl[base + s] * f[s];
+                f[s] = expf(pmv[u][s] - M);
+                L += plv[u][s] * f[s];
             }
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int s = 0; s < kCrossSplitWays; ++s) {
-                const float4 o = *reinterpret_cast<const float4*>(g.mg_po + (base + s) * 64 + dd);
+                const float4 o = pov[u][s];
                 acc.x += o.x * f[s]; acc.y += o.y * f[s]; acc.z += o.z * f[s]; acc.w += o.w * f[s];
             }
             x[u] = make_float4(acc.x / L, acc.y / L, acc.z / L, acc.w / L);
         }
     }
-    if (g.ln_gamma) {
-        float v[UB * 4];
+    if constexpr (LN) {
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < UB * 4; ++i) {
-            const int c = lane + 64 * i;
-            v[i] = c < g.K ? g.A[c] : 0.f;
-            sum += v[i];
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
-        const float mean = sum / (float)g.K;
+        for (int i = 0; i < UB * 4; ++i) sum += v[i];
+        sum = wave_sum(sum);
+        const float mean = sum / (float)K;
         float sq = 0.f;
 #pragma unroll
         for (int i = 0; i < UB * 4; ++i) {
-            const float t = (lane + 64 * i) < g.K ? v[i] - mean : 0.f;
-            sq += t * t;
+            const float d = (lane + 64 * i) < K ? v[i] - mean : 0.f;
+            sq += d * d;
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
-        const float rstd = 1.0f / sqrtf(sq / (float)g.K + 1e-5f);
+        sq = wave_sum(sq);
+        const float rstd = 1.0f / sqrtf(sq / (float)K + 1e-5f);
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const int c = lane + 64 * u;
-            const int cc = (c < K4 ? c : 0) * 4;
-            const float4 ga = *reinterpret_cast<const float4*>(g.ln_gamma + cc);
-            const float4 be = *reinterpret_cast<const float4*>(g.ln_beta + cc);
-            x[u].x = (x[u].x - mean) * rstd * ga.x + be.x;
-            x[u].y = (x[u].y - mean) * rstd * ga.y + be.y;
-            x[u].z = (x[u].z - mean) * rstd * ga.z + be.z;
-            x[u].w = (x[u].w - mean) * rstd * ga.w + be.w;
+            x[u].x = (x[u].x - mean) * rstd * ga[u].x + be[u].x;
+            x[u].y = (x[u].y - mean) * rstd * ga[u].y + be[u].y;
+            x[u].z = (x[u].z - mean) * rstd * ga[u].z + be[u].z;
+            x[u].w = (x[u].w - mean) * rstd * ga[u].w + be[u].w;
         }
     }
     float acc[RPW];
@@ -1293,27 +1376,25 @@ __global__ __launch_bounds__(256) void gemv1_f32_kernel(GemmArgs g) {
         }
     }
 #pragma unroll
-    for (int r = 0; r < RPW; ++r)
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) acc[r] += __shfl_xor(acc[r], off, 64);
+    for (int r = 0; r < RPW; ++r) acc[r] = wave_sum(acc[r]);
     if (lane < RPW) {
         const int n = n_base + lane;
-        if (n < g.N) {
-            float v = 0.f;
+        if (n < N) {
+            float o = 0.f;
 #pragma unroll
             for (int r = 0; r < RPW; ++r)
-                if (r == lane) v = acc[r];
-            if (g.bias) v += g.bias[n];
-            if ((g.flags & kGemmScaleCols) && n < g.scale_cols) v *= g.scale;
-            if (g.flags & kGemmGelu) v = gelu_erf(v);
-            if (g.flags & kGemmRelu) v = fmaxf(v, 0.f);
-            if (g.flags & kGemmSwish) v = v / (1.0f + expf(-v));
-            if (g.flags & kGemmResidual) v += g.R[n];
-            g.C[n] = v;
-            if (g.kcache && n >= g.kv_d) {
-                const long at = (long)(*g.kv_pos) * g.kv_d;
-                if (n < 2 * g.kv_d) g.kcache[at + n - g.kv_d] = v;
-                else g.vcache[at + n - 2 * g.kv_d] = v;
+                if (r == lane) o = acc[r];
+            if (bias != W) o += bias_v;                   // the launcher passes W for an absent operand
+            if ((t.flags & kGemmScaleCols) && n < t.scale_cols) o *= t.scale;
+            if (t.flags & kGemmGelu) o = gelu_erf(o);
+            if (t.flags & kGemmRelu) o = fmaxf(o, 0.f);
+            if (t.flags & kGemmSwish) o = o / (1.0f + expf(-o));
+            if (t.flags & kGemmResidual) o += res_v;
+            t.C[n] = o;
+            if (t.kcache && n >= t.kv_d) {
+                const long at = (long)kv_pos * t.kv_d;
+                if (n < 2 * t.kv_d) t.kcache[at + n - t.kv_d] = o;
+                else t.vcache[at + n - 2 * t.kv_d] = o;
             }
         }
     }
@@ -1343,15 +1424,35 @@ void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (g.M == 1 && g.K <= 2048 && rpw <= 2 && gemv1_enabled() && !g.kv_rows) {
         const int ub = (g.K / 4 + 63) / 64;
         blocks += g.mg_pm ? g.mg_side_blocks : 0;
-#define WLK_GEMV1(UBv)                                                                                             \
-    do {                                                                                                           \
-        if (rpw == 2) hipLaunchKernelGGL((gemv1_f32_kernel<UBv, 2>), dim3(blocks), dim3(256), 0, ctx.stream, g);   \
-        else hipLaunchKernelGGL((gemv1_f32_kernel<UBv, 1>), dim3(blocks), dim3(256), 0, ctx.stream, g);            \
+        // absent operands point at the weights: the kernel requests every operand up front, unconditionally
+        const float* bias = g.bias ? g.bias : g.W;
+        const float* res = (g.flags & kGemmResidual) ? g.R : g.W;
+        Gemv1Tail t{g.C, g.kcache, g.vcache, g.kcache ? g.kv_pos : reinterpret_cast<const int*>(g.W), g.flags, g.scale,
+                    g.scale_cols, g.kv_d};
+        Gemv1Merge mg{g.mg_pm, g.mg_pl, g.mg_po, g.mg_scores, g.mg_head_rank, g.mg_side_heads, g.mg_ring, g.mg_ring_row,
+                      g.mg_beam_of_row, g.mg_T, g.mg_ring_rows, g.mg_n_beam, g.mg_side_blocks};
+        if (g.mg_pm && g.mg_side_blocks > 0 && !g.mg_side_heads)
+            throw std::invalid_argument("gemv: the merged operand's side blocks need the layer's alignment head list");
+#define WLK_GEMV1_I(UBv, RPWv, LNv, MGv)                                                                                 \
+    hipLaunchKernelGGL((gemv1_f32_kernel<UBv, RPWv, LNv, MGv>), dim3(blocks), dim3(256), 0, ctx.stream, g.W, g.A, g.K, \
+                       g.N, g.ln_gamma, g.ln_beta, bias, res, t, mg)
+#define WLK_GEMV1_R(UBv, LNv, MGv)                 \
+    do {                                           \
+        if (rpw == 2) WLK_GEMV1_I(UBv, 2, LNv, MGv); \
+        else WLK_GEMV1_I(UBv, 1, LNv, MGv);        \
+    } while (0)
+#define WLK_GEMV1(UBv)                                         \
+    do {                                                       \
+        if (g.mg_pm) WLK_GEMV1_R(UBv, false, true);            \
+        else if (g.ln_gamma) WLK_GEMV1_R(UBv, true, false);    \
+        else WLK_GEMV1_R(UBv, false, false);                   \
     } while (0)
         if (ub <= 2) WLK_GEMV1(2);
         else if (ub <= 4) WLK_GEMV1(4);
         else WLK_GEMV1(8);
 #undef WLK_GEMV1
+#undef WLK_GEMV1_R
+#undef WLK_GEMV1_I
         WLK_HIP(hipGetLastError());
         return;
     }

@@ -137,6 +137,7 @@ struct wlk_model {
     int* filt_hi = nullptr;
     int* head_rank = nullptr;         // [L][H] alignment rank or -1
     int* layer_ranks = nullptr;       // [L][H] ranks of each layer's alignment heads, compacted
+    int* layer_heads = nullptr;       // [L][H] the alignment heads of each layer in ascending order, compacted
     int* all_ranks = nullptr;         // [L*H] 0, 1, 2, ...: every alignment rank in one launch
     std::vector<int> layer_rank_count;
     std::vector<int> align_pairs;     // (layer, head)*

@@ -2,11 +2,18 @@
 // d <= 1280 for every Whisper size, so a row lives in <= 20 registers per lane: one HBM read,
 // one write, two wavefront reductions.
 #include "common.h"
+#include "wave_ops.h"
 
 namespace wlk {
 
 constexpr int kLnMaxPerLane = 24;  // supports d <= 1536
 
+// NPL = elements per lane (>= ceil(d / 64)).  Round 4: every load of the kernel - the row AND gamma / beta - is requested
+// before the first wait (the affine used to be fetched behind both reductions: a second memory round trip per launch, 13
+// launches per encode), addresses are clamped instead of predicated (hipcc turns `c < d ? x[c] : 0` into one branch per
+// load), and the two reductions are VALU butterflies (wave_ops.h).  Sums run in the same order over the same values: a
+// lane's elements past d contributed exact zeros before and are simply not there now.
+template <int NPL>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
@@ -14,38 +21,53 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    if (batch > 0) {
+    if (x == nullptr) {          // batched form (x is a preloaded argument; `batch` would be one more scalar round trip)
         x = table_at(z.in, blockIdx.y);
         y = table_at(z.out, blockIdx.y);
     }
     const float* xr = x + (long)row * ldx;
-    float v[kLnMaxPerLane];
+    float v[NPL], g[NPL], b[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int c = lane + 64 * i;
+        const int cc = c < d ? c : 0;
+        v[i] = xr[cc];
+        g[i] = gamma[cc];
+        b[i] = beta[cc];
+    }
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < kLnMaxPerLane; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = c < d ? xr[c] : 0.f;
+    for (int i = 0; i < NPL; ++i) {
+        v[i] = (lane + 64 * i) < d ? v[i] : 0.f;
         sum += v[i];
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    sum = wave_sum(sum);
     const float mean = sum / (float)d;
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < kLnMaxPerLane; ++i) {
+    for (int i = 0; i < NPL; ++i) {
         const int c = lane + 64 * i;
         const float t = c < d ? v[i] - mean : 0.f;
         sq += t * t;
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    sq = wave_sum(sq);
     const float rstd = 1.0f / sqrtf(sq / (float)d + 1e-5f);
     float* yr = y + (long)row * ldy;
 #pragma unroll
-    for (int i = 0; i < kLnMaxPerLane; ++i) {
+    for (int i = 0; i < NPL; ++i) {
         const int c = lane + 64 * i;
-        if (c < d) yr[c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+        if (c < d) yr[c] = (v[i] - mean) * rstd * g[i] + b[i];
     }
+}
+
+template <typename... Args>
+static void launch_ln_by_width(int d, dim3 grid, hipStream_t stream, Args... args) {
+    const int npl = (d + 63) / 64;
+    if (npl <= 8) hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, stream, args...);
+    else if (npl <= 12) hipLaunchKernelGGL(layernorm_kernel<12>, grid, dim3(256), 0, stream, args...);
+    else if (npl <= 16) hipLaunchKernelGGL(layernorm_kernel<16>, grid, dim3(256), 0, stream, args...);
+    else if (npl <= 20) hipLaunchKernelGGL(layernorm_kernel<20>, grid, dim3(256), 0, stream, args...);
+    else hipLaunchKernelGGL(layernorm_kernel<kLnMaxPerLane>, grid, dim3(256), 0, stream, args...);
 }
 
 void launch_layernorm(const LaunchCtx& ctx, const float* x, long ldx, const float* gamma, const float* beta,
@@ -53,8 +75,7 @@ void launch_layernorm(const LaunchCtx& ctx, const float* x, long ldx, const floa
     if (rows <= 0) return;
     if (d > 64 * kLnMaxPerLane) throw std::invalid_argument("layernorm: d too large");
     KernelScope ks(ctx, tag);
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, ctx.stream, x, ldx, gamma, beta, y,
-                       ldy, rows, d, PtrTable{}, 0);
+    launch_ln_by_width(d, dim3((rows + 3) / 4), ctx.stream, x, ldx, gamma, beta, y, ldy, rows, d, PtrTable{}, 0);
     WLK_HIP(hipGetLastError());
 }
 
@@ -63,8 +84,8 @@ void launch_layernorm_batched(const LaunchCtx& ctx, const PtrTable& z, int batch
     if (rows <= 0 || batch <= 0) return;
     if (d > 64 * kLnMaxPerLane || batch > kMaxBatch) throw std::invalid_argument("layernorm: d or batch too large");
     KernelScope ks(ctx, tag);
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4, batch), dim3(256), 0, ctx.stream, (const float*)nullptr, ldx,
-                       gamma, beta, (float*)nullptr, ldy, rows, d, z, batch);
+    launch_ln_by_width(d, dim3((rows + 3) / 4, batch), ctx.stream, (const float*)nullptr, ldx, gamma, beta, (float*)nullptr,
+                       ldy, rows, d, z, batch);
     WLK_HIP(hipGetLastError());
 }
 

@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "wave_ops.h"
 
 namespace wlk {
 
@@ -19,8 +20,7 @@ constexpr int kSelThreads = 1024;
 constexpr int kMaxTopK = 8;
 
 __device__ __forceinline__ float block_max(float v, float* red) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    v = wave_max(v);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __syncthreads();
     if (lane == 0) red[wave] = v;
@@ -31,8 +31,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    v = wave_sum(v);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __syncthreads();
     if (lane == 0) red[wave] = v;
@@ -69,7 +68,7 @@ struct TopkArgs {
     float* ns_probs = nullptr;
 };
 
-__device__ __forceinline__ void topk_stage1_body(float* __restrict__ logits, int n_vocab, int k,
+__device__ __forceinline__ void topk_stage1_stream(float* __restrict__ logits, int n_vocab, int k,
                                                  SelPartial* __restrict__ parts, const int* __restrict__ adj_row,
                                                  const int* __restrict__ adj_ids, const float* __restrict__ adj_deltas,
                                                  int n_adj, int slice, int row) {
@@ -108,12 +107,7 @@ __device__ __forceinline__ void topk_stage1_body(float* __restrict__ logits, int
             const float v = x[i];
             if (!skip && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float ov = __shfl_xor(bv, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
+        wave_argmax(bv, bi);
         __syncthreads();
         if ((tid & 63) == 0) { cand_v[tid >> 6] = bv; cand_i[tid >> 6] = bi; }
         __syncthreads();
@@ -125,6 +119,105 @@ __device__ __forceinline__ void topk_stage1_body(float* __restrict__ logits, int
             out->i[round] = bi;
         }
         __syncthreads();
+    }
+}
+
+// The same slice pass with the slice held in registers (slices of up to 1024 logits: every Whisper vocabulary): ONE read
+// of the row instead of k + 2 passes over it (each pass of the streaming form is a memory round trip on a kernel that
+// starts with a cold L2), the logit adjustments ride through LDS to the thread that owns the element, and the
+// wave-level folds are VALU butterflies (wave_ops.h).  Max, exp-sum (same per-thread order: ascending index) and the
+// index-tie-broken arg-max rounds give what the streaming form gives, bit for bit.
+constexpr int kSelKeep = 4;
+__device__ __forceinline__ void topk_stage1_body(float* __restrict__ logits, int n_vocab, int k,
+                                                 SelPartial* __restrict__ parts, const int* __restrict__ adj_row,
+                                                 const int* __restrict__ adj_ids, const float* __restrict__ adj_deltas,
+                                                 int n_adj, int slice, int row) {
+    const int per = (n_vocab + kSelBlocks - 1) / kSelBlocks;
+    if (per > 256 * kSelKeep) {
+        topk_stage1_stream(logits, n_vocab, k, parts, adj_row, adj_ids, adj_deltas, n_adj, slice, row);
+        return;
+    }
+    __shared__ float red[16];
+    __shared__ float cand_v[4];
+    __shared__ int cand_i[4];
+    __shared__ float adj_buf[256 * kSelKeep];
+    const int tid = threadIdx.x;
+    const int lo = slice * per;
+    const int hi = min(n_vocab, lo + per);
+    float* x = logits + (long)row * n_vocab;
+    float xv[kSelKeep];
+#pragma unroll
+    for (int j = 0; j < kSelKeep; ++j) {
+        const int i = lo + tid + 256 * j;
+        xv[j] = x[i < hi ? i : lo];
+        adj_buf[tid + 256 * j] = 0.f;
+    }
+    __syncthreads();
+    // adjustments that fall into this slice (ids are unique per row): delivered to the owner of the element
+    for (int i = tid; i < n_adj; i += 256) {
+        const int id = adj_ids[i];
+        const int r = adj_row[i];
+        if (id >= lo && id < hi && (r < 0 || r == row)) adj_buf[id - lo] = adj_deltas[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kSelKeep; ++j) {
+        const int i = lo + tid + 256 * j;
+        const float a = adj_buf[tid + 256 * j];
+        if (a != 0.f && i < hi) {
+            xv[j] += a;
+            x[i] = xv[j];          // the row stays adjusted in memory, as wlk_select's contract says
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < kSelKeep; ++j)
+        if (lo + tid + 256 * j < hi) mx = fmaxf(mx, xv[j]);
+    mx = block_max(mx, red);
+    float sum = 0.f;
+    if (mx > -INFINITY) {
+#pragma unroll
+        for (int j = 0; j < kSelKeep; ++j)
+            if (lo + tid + 256 * j < hi) sum += expf(xv[j] - mx);
+    }
+    sum = block_sum(sum, red);
+    SelPartial* out = parts + (long)row * kSelBlocks + slice;
+    if (tid == 0) { out->mx = mx; out->sum = sum; }
+    int taken = -1;                      // round r skips what rounds < r took: every thread tracks the winners itself
+    int taken_all[kMaxTopK];
+#pragma unroll
+    for (int t = 0; t < kMaxTopK; ++t) taken_all[t] = -1;
+    for (int round = 0; round < k; ++round) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < kSelKeep; ++j) {
+            const int i = lo + tid + 256 * j;
+            if (i < hi) {
+                bool skip = false;
+#pragma unroll
+                for (int t = 0; t < kMaxTopK; ++t) skip |= (t < round && taken_all[t] == i);
+                const float v = xv[j];
+                if (!skip && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+            }
+        }
+        wave_argmax(bv, bi);
+        __syncthreads();
+        if ((tid & 63) == 0) { cand_v[tid >> 6] = bv; cand_i[tid >> 6] = bi; }
+        __syncthreads();
+        bv = cand_v[0];
+        bi = cand_i[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (cand_v[w] > bv || (cand_v[w] == bv && cand_i[w] < bi)) { bv = cand_v[w]; bi = cand_i[w]; }
+        taken = bi;
+#pragma unroll
+        for (int t = 0; t < kMaxTopK; ++t)
+            if (t == round) taken_all[t] = taken;
+        if (tid == 0) {
+            out->v[round] = bv;
+            out->i[round] = bi;
+        }
     }
 }
 
@@ -147,12 +240,9 @@ __device__ __forceinline__ void topk_stage2_body(const SelPartial* __restrict__ 
                                                  const StepHostOut host = StepHostOut{}) {
     const int lane = threadIdx.x;   // one lane per slice (the first wave of the workgroup)
     const SelPartial p = parts[(long)row * kSelBlocks + lane];
-    float mx = p.mx;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float mx = wave_max(p.mx);
     float sum = p.mx > -INFINITY ? p.sum * expf(p.mx - mx) : 0.f;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    sum = wave_sum(sum);
     const float lse = logf(sum);
     int head = 0;                   // next unconsumed candidate of this slice (its list is sorted)
     for (int round = 0; round < k; ++round) {
@@ -164,12 +254,7 @@ __device__ __forceinline__ void topk_stage2_body(const SelPartial* __restrict__ 
         if (head >= k) { bv = -INFINITY; bi = 0x7fffffff; }
         float wv = bv;
         int wi = bi;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float ov = __shfl_xor(wv, off, 64);
-            const int oi = __shfl_xor(wi, off, 64);
-            if (ov > wv || (ov == wv && oi < wi)) { wv = ov; wi = oi; }
-        }
+        wave_argmax(wv, wi);
         if (wi == bi && bi != 0x7fffffff) ++head;
         if (lane == 0) {
             top_ids[row * k + round] = wi;
@@ -277,16 +362,37 @@ __device__ __forceinline__ void align_zscore_body(AlignArgs a, int fblock, int a
                                : a.ring + ((long)(al * a.n_beam + b) * a.ring_rows) * a.T + (ok ? f : 0);
     const int n = a.prefill_rows + a.n_single;
     auto row_of = [&](int i) { return i < a.prefill_rows ? i : a.single_base + (i - a.prefill_rows); };
+    // Round 4: the thread's first kZKeep window rows (windows of up to 4 kZKeep = 96 rows: every step but those of very
+    // long prompts) are requested together and kept for the second pass - one memory round trip instead of
+    // 2 x ceil(rows / 16) dependent ones; the sums run over the same values in the same order.
+    constexpr int kZKeep = 24;
+    float w[kZKeep];
+#pragma unroll
+    for (int t = 0; t < kZKeep; ++t) {
+        const int i = rg + 4 * t;
+        w[t] = base[(long)row_of(i < n ? i : 0) * a.T];
+    }
+    const float newest = base[(long)a.newest_row * a.T];
     double sum = 0.0;
+#pragma unroll
+    for (int t = 0; t < kZKeep; ++t)
+        if (rg + 4 * t < n) sum += (double)w[t];
 #pragma unroll 4
-    for (int i = rg; i < n; i += 4) sum += (double)base[(long)row_of(i) * a.T];
+    for (int i = rg + 4 * kZKeep; i < n; i += 4) sum += (double)base[(long)row_of(i) * a.T];
     red[rg][fx] = sum;
     __syncthreads();
     const double mean = (red[0][fx] + red[1][fx] + red[2][fx] + red[3][fx]) / n;
     __syncthreads();
     double sq = 0.0;
+#pragma unroll
+    for (int t = 0; t < kZKeep; ++t) {
+        if (rg + 4 * t < n) {
+            const double d = (double)w[t] - mean;
+            sq += d * d;
+        }
+    }
 #pragma unroll 4
-    for (int i = rg; i < n; i += 4) {
+    for (int i = rg + 4 * kZKeep; i < n; i += 4) {
         const double t = (double)base[(long)row_of(i) * a.T] - mean;
         sq += t * t;
     }
@@ -294,8 +400,7 @@ __device__ __forceinline__ void align_zscore_body(AlignArgs a, int fblock, int a
     __syncthreads();
     if (rg == 0 && ok) {
         const float stdv = (float)sqrt((red[0][fx] + red[1][fx] + red[2][fx] + red[3][fx]) / n);
-        const float w = base[(long)a.newest_row * a.T];
-        a.z[((long)b * a.n_align + al) * a.T + f] = (w - (float)mean) / (stdv + 1e-8f);
+        a.z[((long)b * a.n_align + al) * a.T + f] = (newest - (float)mean) / (stdv + 1e-8f);
     }
 }
 
@@ -365,8 +470,8 @@ __global__ __launch_bounds__(256) void align_argmax_kernel(AlignArgs a) {
 // coalesced loads once, then medians / head mean / arg-max run out of LDS.
 __device__ __forceinline__ void align_argmax_lds_body(AlignArgs a, int b, const StepHostOut host = StepHostOut{}) {
     extern __shared__ __attribute__((aligned(16))) float zs[];   // [n_align][T]
-    __shared__ float bestv[1024];
-    __shared__ int besti[1024];
+    __shared__ float bestv[16];
+    __shared__ int besti[16];
     const int tid = threadIdx.x;
     if (a.rows) a.content_len = a.rows[b].content_len;
     const float* zb = a.z + (long)b * a.n_align * a.T;
@@ -392,16 +497,14 @@ __device__ __forceinline__ void align_argmax_lds_body(AlignArgs a, int b, const 
         a.attn_last[(long)b * a.T + f] = m;
         if (f < a.content_len && (m > bv || (m == bv && f < bi))) { bv = m; bi = f; }
     }
-    bestv[tid] = bv;
-    besti[tid] = bi;
+    // (value, frame) arg-max with ties to the lowest frame: order-free, so sixteen VALU butterflies + one 16-entry fold
+    // replace the ten-level LDS tree and its ten barriers
+    wave_argmax(bv, bi);
+    if ((tid & 63) == 0) { bestv[tid >> 6] = bv; besti[tid >> 6] = bi; }
     __syncthreads();
-    for (int s = 512; s >= 1; s >>= 1) {
-        if (tid < s) {
-            const float ov = bestv[tid + s];
-            const int oi = besti[tid + s];
-            if (ov > bestv[tid] || (ov == bestv[tid] && oi < besti[tid])) { bestv[tid] = ov; besti[tid] = oi; }
-        }
-        __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bestv[w] > bestv[0] || (bestv[w] == bestv[0] && besti[w] < besti[0])) { bestv[0] = bestv[w]; besti[0] = besti[w]; }
     }
     if (tid == 0) {
         const int frame = besti[0] == 0x7fffffff ? 0 : besti[0];
