@@ -36,3 +36,15 @@ for l in open(sys.argv[1] + '/ab.log'):
         print(lab, j['value'], j.get('ms_per_step'), pc.get('decisions'), pc.get('identical'), pc.get('tie_divergences'), pc.get('mismatches'))
     except Exception as e: print(lab,'ERR',l[:300])
 PY
+# per-kernel averages of the new library (rocprofv3 kernel trace of one bench pass) and the 8-stream leg, new vs r3
+R=$PWD
+export TMPDIR=/tmp; cd /tmp
+B1="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-diarization --no-eight-streams"
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof/stats -o st -- $B1 > $R/$OUT/prof_stats.log 2>&1
+cd $R
+python scripts/export_profile.py $(find $OUT/prof/stats -name "*.db" | head -1) $OUT/bench_kernel_stats.md "python bench.py --steps 1 --warmup 1 --no-eight-streams (base.en, 1 stream): rocprofv3 --kernel-trace --stats" > /dev/null 2>&1
+rm -rf $OUT/prof
+head -45 $OUT/bench_kernel_stats.md
+B8="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-diarization"
+timeout 300 $B8 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('new eight', (d.get('eight_streams') or {}).get('audio_s_per_s'), 'value', d['value'])"
+WLK_HIP_LIB=$R3 timeout 300 $B8 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('r3  eight', (d.get('eight_streams') or {}).get('audio_s_per_s'), 'value', d['value'])"

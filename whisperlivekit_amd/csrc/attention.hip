@@ -41,6 +41,7 @@ constexpr int kAttnLdsTotal = kAttnLdsFloats + QT * K_LD;            // + Q tile
 // into the session's alignment window (softmaxed in place afterwards by ring_softmax_kernel), so
 // the [H, q, 1500] QK tensor of the reference is never formed for the other heads.
 __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
+    WLK_PIN_FLASH_ARGS(a);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // batched encodes: session blockIdx.y (locals: writing into `a` would put the argument struct into scratch memory)
     const bool batched = a.batch > 0;
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void enc_attention_pw_kernel(FlashArgs a) {
+    WLK_PIN_FLASH_ARGS(a);
     extern __shared__ __attribute__((aligned(1024))) float lds[];
     const bool dbg = a.dbg_clock != nullptr;
     const long long t_start = dbg ? (long long)__builtin_readcyclecounter() : 0;
@@ -497,6 +499,7 @@ __global__ __launch_bounds__(256) void enc_attention_pw_kernel(FlashArgs a) {
 // the keys.  192 workgroups of 512 threads for base.en (one per CU on 192 CUs, two waves per SIMD).
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void enc_attention_q64x_kernel(FlashArgs a) {
+    WLK_PIN_FLASH_ARGS(a);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const bool batched = a.batch > 0;
     const float* const aq = batched ? table_at(a.z.in, blockIdx.y) : a.q;
@@ -683,6 +686,7 @@ constexpr int kAttn2Merge = NWAVE * QT * O_LD + 2 * NWAVE * QT;          // floa
 constexpr int kAttn2LdsFloats = kAttn2Stage > kAttn2Merge ? kAttn2Stage : kAttn2Merge;
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void enc_attention_q64_kernel(FlashArgs a) {
+    WLK_PIN_FLASH_ARGS(a);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const bool batched = a.batch > 0;
     const float* const aq = batched ? table_at(a.z.in, blockIdx.y) : a.q;
@@ -863,6 +867,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 // folds the k_splits partial softmax states of every (query row, head): out = sum_s e^{m_s-M} O_s / sum_s e^{m_s-M} l_s
 __global__ __launch_bounds__(64) void flash_merge_kernel(FlashArgs a) {
+    WLK_PIN_FLASH_ARGS(a);
     const int row = blockIdx.x, head = blockIdx.y, dd = threadIdx.x;
     const bool batched = a.batch > 0;
     float* const aout = batched ? table_at(a.z.out, blockIdx.z) : a.out;

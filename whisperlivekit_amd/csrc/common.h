@@ -148,6 +148,8 @@ enum GemmFlags : int {
     kGemmSwish = 16,    // x * sigmoid(x) after bias       (Conformer feed-forward)
 };
 struct GemmArgs {
+    // ---- what a kernel needs before its first operand load: one contiguous block at the start of the kernel-argument
+    // segment, fetched by ONE s_load burst at kernel entry (WLK_PIN_GEMM_ARGS) instead of a stage per first use -------
     const float* A = nullptr;
     long lda = 0;
     const float* W = nullptr;  // [N][K] row-major
@@ -161,6 +163,10 @@ struct GemmArgs {
     float scale = 1.f;
     int scale_cols = 0;
     int scale_period = 0;  // > 0: the rule is (col % scale_period) < scale_cols (several [k | v] blocks side by side)
+    // batched encodes: > 0 -> grid.y = batch, operands of z from the table `z` below (A, C, R above are ignored)
+    int batch = 0;
+    long long* dbg_clock = nullptr;  // probe only: 4 s_memtime stamps per workgroup (start, loop start, loop end, end)
+    // ---- the rest -----------------------------------------------------------------------------------------------------
     // GEMV path only (decode steps): fused pre-LayerNorm of the A rows (eps 1e-5) ...
     const float* ln_gamma = nullptr;
     const float* ln_beta = nullptr;
@@ -187,14 +193,22 @@ struct GemmArgs {
     const int* mg_ring_row = nullptr;
     const int* mg_beam_of_row = nullptr;
     int mg_heads = 0, mg_T = 0, mg_ring_rows = 0, mg_n_beam = 1, mg_side_blocks = 0;
-    // batched encodes: > 0 -> grid.y = batch, operands of z from the table (A, C, R above are ignored)
-    int batch = 0;
     PtrTable z;
-    bool force_kwave = false;
-    long long* dbg_clock = nullptr;  // probe only: 4 s_memtime stamps per workgroup (start, loop start, loop end, end)
-    int force_kernel = 0;           // diagnostics / A-B: 0 = by shape, 2 = k-wave, 3 = the 64x64 kernel, 4 = the k-split kernel
-    bool gemm_plain_loop = false;   // A/B switch: LDS fragment reads right before use instead of a group ahead   // diagnostics: take the k-wave kernel (under-filled grids) whatever the shape
+    bool force_kwave = false;            // diagnostics: take the k-wave kernel (under-filled grids) whatever the shape
+    int force_kernel = 0;                // diagnostics / A-B: 0 = by shape, 2 = k-wave, 3 = the 64x64 kernel, 4 = the k-split kernel
+    bool gemm_plain_loop = false;        // A/B switch: LDS fragment reads right before use instead of a group ahead
 };
+// First statement of every kernel that takes GemmArgs by value: the hot block above is requested together and held in
+// SGPRs from the entry block on.  Without it hipcc sinks each field's s_load into the branch that first reads it - the
+// round-3 kernels waited for five to seven dependent scalar round trips before their first operand load.
+#define WLK_PIN_S(x) asm volatile("" ::"s"(x))
+#define WLK_PIN_GEMM_ARGS(g)                                                                                                \
+    do {                                                                                                                    \
+        asm volatile("" ::"s"((g).A), "s"((g).lda), "s"((g).W), "s"((g).bias), "s"((g).C), "s"((g).ldc), "s"((g).R),        \
+                     "s"((g).ldr), "s"((g).M), "s"((g).N), "s"((g).K), "s"((g).flags), "s"((g).scale), "s"((g).scale_cols), \
+                     "s"((g).scale_period), "s"((g).batch), "s"((g).dbg_clock));                                            \
+        __builtin_amdgcn_sched_barrier(0); /* nothing of the kernel is scheduled between the loads and their one wait */    \
+    } while (0)
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag);
 bool gemm_takes_kwave(int M, int N, int K);
 bool gemm_takes_ksplit(int M, int N, int K);  // ... for the one-tile-per-CU k-split kernel (encoder-sized problems)   // launch_gemm's shape rule for the k-wave kernel (under-filled grids)
@@ -267,33 +281,44 @@ void launch_melspec(const LaunchCtx& ctx, const MelSpecArgs& a, int n_frames);
 // ---- attention.hip --------------------------------------------------------------------------
 // flash-style fp32-MFMA attention: q rows [Tq] against k/v rows [Tk], 64-wide heads, no mask
 struct FlashArgs {
+    // ---- hot block: everything a kernel needs before its first operand load, contiguous at the start of the
+    // kernel-argument segment and requested by one s_load burst at kernel entry (WLK_PIN_FLASH_ARGS) -----------------
     const float* q = nullptr; long ldq = 0;      // query row r, head h at q + r*ldq + 64h (pre-scaled)
     const float* k = nullptr; const float* v = nullptr; long ldkv = 0;  // key t at k + t*ldkv + 64h (pre-scaled)
     float* out = nullptr; long ldo = 0;
     int Tq = 0, Tk = 0, n_head = 0;
+    // batched encodes: > 0 -> grid.y = batch; q = z.in[i], k = q + z_k_off, v = q + z_v_off, out = z.out[i]
+    int batch = 0;
+    long z_k_off = 0, z_v_off = 0;
+    // key-range split (few query tiles, e.g. decoder prefill): k_splits workgroups per (q tile, head) leave
+    // partial softmax states in part_o/m/l [rows][n_head][k_splits][64|1|1]; a merge kernel folds them
+    int k_splits = 1;
+    int ring_rows = 0;
+    // stacked prefills of several sessions (engine.hip): query tile t (32 stacked rows, all of ONE session) takes its
+    // keys / values from tile_rows[t].cross_kv + tile_kv_off (values tile_v_off floats further) and dumps alignment
+    // scores into tile_rows[t].ring (one beam); ring_row[] stays indexed by the stacked row
+    const StepRow* tile_rows = nullptr;
+    long long* dbg_clock = nullptr;   // probe only (enc_attention_pw_kernel): 8 s_memtime figures per workgroup
+    // ---- the rest ---------------------------------------------------------------------------------------------------
+    long tile_kv_off = 0, tile_v_off = 0;
     // decoder prefill only: raw scores of alignment heads go to the alignment window
     const int* head_rank = nullptr;              // [n_head] rank or -1
     float* ring = nullptr;
     const int* ring_row = nullptr;               // [Tq]
     const int* beam_of_row = nullptr;            // [Tq]
-    int ring_rows = 0, n_beam = 1;
-    // key-range split (few query tiles, e.g. decoder prefill): k_splits workgroups per (q tile, head) leave
-    // partial softmax states in part_o/m/l [rows][n_head][k_splits][64|1|1]; a merge kernel folds them
-    // batched encodes: > 0 -> grid.y = batch; q = z.in[i], k = q + z_k_off, v = q + z_v_off, out = z.out[i]
-    int batch = 0;
-    long z_k_off = 0, z_v_off = 0;
-    PtrTable z;
-    int k_splits = 1;
+    int n_beam = 1;
     float* part_o = nullptr;
     float* part_m = nullptr;
     float* part_l = nullptr;
-    long long* dbg_clock = nullptr;   // probe only (enc_attention_pw_kernel): 8 s_memtime figures per workgroup
-    // stacked prefills of several sessions (engine.hip): query tile t (32 stacked rows, all of ONE session) takes its
-    // keys / values from tile_rows[t].cross_kv + tile_kv_off (values tile_v_off floats further) and dumps alignment
-    // scores into tile_rows[t].ring (one beam); ring_row[] stays indexed by the stacked row
-    const StepRow* tile_rows = nullptr;
-    long tile_kv_off = 0, tile_v_off = 0;
+    PtrTable z;
 };
+#define WLK_PIN_FLASH_ARGS(a)                                                                                              \
+    do {                                                                                                                   \
+        asm volatile("" ::"s"((a).q), "s"((a).ldq), "s"((a).k), "s"((a).v), "s"((a).ldkv), "s"((a).out), "s"((a).ldo),      \
+                     "s"((a).Tq), "s"((a).Tk), "s"((a).n_head), "s"((a).batch), "s"((a).z_k_off), "s"((a).z_v_off),         \
+                     "s"((a).k_splits), "s"((a).ring_rows), "s"((a).tile_rows), "s"((a).dbg_clock));                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    } while (0)
 extern long long* g_attn_dbg_clock;   // set by the timing probe (diag.hip); nullptr otherwise
 size_t flash_split_scratch_floats(int rows, int n_head, int k_splits);
 // encoder self-attention over qkv[T][3d] (q and k pre-scaled), out[T][d]

@@ -52,6 +52,7 @@ struct Stage {
 // 256 CUs).  Guards are branch-free (clamped address + select) so the loads stay unpredicated.
 template <int BM, int BN>
 __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel(GemmArgs g) {
+    WLK_PIN_GEMM_ARGS(g);
     constexpr int NT = 64 * (BM / 32) * (BN / 32);
     constexpr int NA = BM * 8 / NT, NW = BN * 8 / NT;
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
 // and buffer-load pipeline as the main kernel.
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gemm_nt_f32_kwave_kernel(GemmArgs g) {
+    WLK_PIN_GEMM_ARGS(g);
     constexpr int KW = 4, SLAB = BK * KW, SUB = 32 * LDS_LD;
     __shared__ __attribute__((aligned(16))) float As[2][KW * SUB];
     __shared__ __attribute__((aligned(16))) float Ws[2][KW * SUB];
@@ -540,6 +542,7 @@ struct KSplitCfg {
 // ABL (timing ablations of the probe only, results are wrong): 1 = no DMA inside the loop, 2 = no MFMA, 3 = no fragment reads
 template <int TM, int TN, int KS, int ABL = 0>
 __global__ __launch_bounds__(256) void gemm_nt_f32_ksplit_kernel(GemmArgs g) {
+    WLK_PIN_GEMM_ARGS(g);
     using Cfg = KSplitCfg<TM, TN, KS>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NP = Cfg::PIECES_PER_WAVE, HALVES = Cfg::HALVES, STEPS = KS / 32;
     extern __shared__ __attribute__((aligned(1024))) float lds[];
@@ -740,6 +743,7 @@ __device__ __forceinline__ void wait_lgkm_tied(f32x4v* f) {
 
 template <int TM, int TN, int NB, int STEPS>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kpipe_kernel(GemmArgs g) {
+    WLK_PIN_GEMM_ARGS(g);
     using Cfg = KPipeCfg<TM, TN, NB, STEPS>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NP = Cfg::PIECES_PER_WAVE, KS = 32;
     constexpr int DT = NB / STEPS - 1;                  // trips of DMA in flight beyond the one being multiplied
@@ -1051,6 +1055,7 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
 // -------------------------------------------------------------------------------------------------
 template <int MR, int RPW>
 __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
+    WLK_PIN_GEMM_ARGS(g);
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [MR][K]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1068,6 +1073,32 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
         const float4 t = *reinterpret_cast<const float4*>(g.W + (long)(ok ? n : 0) * g.K + (ok ? lane : 0) * 4);
         wpre[r] = t;
     }
+    // Round 4: the LayerNorm affine of the first 64 kLnKeep features per lane, and the epilogue operands of this wave's
+    // first output group (bias, residual, per-row cache pointers), are requested here - in flight with the activations
+    // and the first weights - instead of behind the reductions / behind the dot products (each was one more memory round
+    // trip of a kernel that is a chain of them).  Absent operands are simply not requested (uniform branches).
+    constexpr int kLnKeep = 8;
+    [[maybe_unused]] float gq[kLnKeep], bq[kLnKeep];
+    // (unconditional loads from pointers that are always readable - an absent operand points at the weights - because a
+    // load inside a branch makes hipcc wait for ALL outstanding loads where the branch joins)
+    {
+        const float* gp = g.ln_gamma ? g.ln_gamma : g.W;
+        const float* bp = g.ln_gamma ? g.ln_beta : g.W;
+#pragma unroll
+        for (int i = 0; i < kLnKeep; ++i) {
+            const int c = lane + 64 * i;
+            gq[i] = gp[c < g.K ? c : 0];
+            bq[i] = bp[c < g.K ? c : 0];
+        }
+    }
+    const int ep_r = lane / MR, ep_m = lane - ep_r * MR;           // epilogue role of this lane (lanes < RPW * MR)
+    const int ep_n0 = min(grp0 * RPW + (ep_r < RPW ? ep_r : 0), g.N - 1);
+    const int ep_mm = ep_m < g.M ? ep_m : 0;
+    const float bias0 = (g.bias ? g.bias + ep_n0 : g.W)[0];
+    const float res0 = ((g.flags & kGemmResidual) ? g.R + (long)ep_mm * g.ldr + ep_n0 : g.W)[0];
+    static_assert(sizeof(StepRow) == 64, "the dummy StepRow read below stays inside the first weight row");
+    const StepRow kv_row0 = (g.kv_rows ? g.kv_rows + ep_mm : reinterpret_cast<const StepRow*>(g.W))[0];
+    const int kv_pos0 = (g.kcache ? g.kv_pos : reinterpret_cast<const int*>(g.W))[0];
     for (int i = tid; i < MR * K4; i += 256) {
         const int m = i / K4, c = i - m * K4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1077,23 +1108,26 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
     __syncthreads();
     if (g.ln_gamma) {
         // fused LayerNorm of the staged rows; same reduction order as layernorm_kernel (lane-strided
-        // partial sums, xor-shuffle fold), so fused and unfused paths agree bit for bit
+        // partial sums, butterfly fold), so fused and unfused paths agree bit for bit
         for (int m = wave; m < g.M; m += 4) {
             float* xr = xs + m * g.K;
             float sum = 0.f;
             for (int c = lane; c < g.K; c += 64) sum += xr[c];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+            sum = wave_sum(sum);
             const float mean = sum / (float)g.K;
             float sq = 0.f;
             for (int c = lane; c < g.K; c += 64) {
                 const float t = xr[c] - mean;
                 sq += t * t;
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+            sq = wave_sum(sq);
             const float rstd = 1.0f / sqrtf(sq / (float)g.K + 1e-5f);
-            for (int c = lane; c < g.K; c += 64) xr[c] = (xr[c] - mean) * rstd * g.ln_gamma[c] + g.ln_beta[c];
+#pragma unroll
+            for (int i = 0; i < kLnKeep; ++i) {
+                const int c = lane + 64 * i;
+                if (c < g.K) xr[c] = (xr[c] - mean) * rstd * gq[i] + bq[i];
+            }
+            for (int c = lane + 64 * kLnKeep; c < g.K; c += 64) xr[c] = (xr[c] - mean) * rstd * g.ln_gamma[c] + g.ln_beta[c];
         }
         __syncthreads();
     }
@@ -1143,10 +1177,7 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
         for (int r = 0; r < RPW; ++r)
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
-                float v = acc[r][m];
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-                acc[r][m] = v;
+                acc[r][m] = wave_sum(acc[r][m]);
             }
         if (lane < RPW * MR) {
             const int r = lane / MR, m = lane - r * MR;
@@ -1158,20 +1189,21 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
 #pragma unroll
                     for (int mm = 0; mm < MR; ++mm)
                         if (rr == r && mm == m) v = acc[rr][mm];
-                if (g.bias) v += g.bias[n];
+                const bool first = grp == grp0;           // this group's epilogue operands were requested at the top
+                if (g.bias) v += first ? bias0 : g.bias[n];
                 if ((g.flags & kGemmScaleCols) && n < g.scale_cols) v *= g.scale;
                 if (g.flags & kGemmGelu) v = gelu_erf(v);
                 if (g.flags & kGemmRelu) v = fmaxf(v, 0.f);
                 if (g.flags & kGemmSwish) v = v / (1.0f + expf(-v));
-                if (g.flags & kGemmResidual) v += g.R[(long)m * g.ldr + n];
+                if (g.flags & kGemmResidual) v += first ? res0 : g.R[(long)m * g.ldr + n];
                 g.C[(long)m * g.ldc + n] = v;
                 if (g.kv_rows && n >= g.kv_d) {          // batched steps: every row has its own cache
-                    const StepRow sr = g.kv_rows[m];
+                    const StepRow sr = first ? kv_row0 : g.kv_rows[m];
                     const long at = g.kv_layer_off + (long)sr.offset * g.kv_d;
                     if (n < 2 * g.kv_d) sr.kcache[at + n - g.kv_d] = v;
                     else sr.vcache[at + n - 2 * g.kv_d] = v;
                 } else if (g.kcache && n >= g.kv_d) {
-                    const long at = ((long)m * g.kv_ctx + *g.kv_pos) * g.kv_d;
+                    const long at = ((long)m * g.kv_ctx + (first ? kv_pos0 : *g.kv_pos)) * g.kv_d;
                     if (n < 2 * g.kv_d) g.kcache[at + n - g.kv_d] = v;
                     else g.vcache[at + n - 2 * g.kv_d] = v;
                 }
@@ -1199,7 +1231,6 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
 //   * each reduction was six ds_bpermute_b32 + waits (~100 cycles each) -> VALU butterflies (wave_ops.h), same order.
 // The arithmetic is untouched: bit-identical to the round-3 kernel and to the staged kernel
 // (tests/test_gpu_parity.py::test_barrier_free_single_row_gemv_is_bit_identical_to_the_staged_kernel).
-#define WLK_PIN_S(x) asm volatile("" ::"s"(x))
 
 struct Gemv1Tail {             // needed only once the dot products are folded
     float* C;

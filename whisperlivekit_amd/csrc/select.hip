@@ -153,11 +153,14 @@ __device__ __forceinline__ void topk_stage1_body(float* __restrict__ logits, int
         adj_buf[tid + 256 * j] = 0.f;
     }
     __syncthreads();
-    // adjustments that fall into this slice (ids are unique per row): delivered to the owner of the element
-    for (int i = tid; i < n_adj; i += 256) {
-        const int id = adj_ids[i];
-        const int r = adj_row[i];
-        if (id >= lo && id < hi && (r < 0 || r == row)) adj_buf[id - lo] = adj_deltas[i];
+    // adjustments that fall into this slice (ids are unique per row): delivered to the owner of the element; a thread's
+    // three operands are requested together (clamped index), not one dependent load after the other
+    for (int i0 = 0; i0 < n_adj; i0 += 256) {
+        const int i = i0 + tid, ic = i < n_adj ? i : 0;
+        const int id = adj_ids[ic];
+        const int r = adj_row[ic];
+        const float dl = adj_deltas[ic];
+        if (i < n_adj && id >= lo && id < hi && (r < 0 || r == row)) adj_buf[id - lo] = dl;
     }
     __syncthreads();
 #pragma unroll
@@ -358,8 +361,8 @@ __device__ __forceinline__ void align_zscore_body(AlignArgs a, int fblock, int a
         a.n_single = sr.n_single;
         a.newest_row = sr.newest_row;
     }
-    const float* base = a.rows ? a.rows[b].ring + ((long)al * a.ring_rows) * a.T + (ok ? f : 0)
-                               : a.ring + ((long)(al * a.n_beam + b) * a.ring_rows) * a.T + (ok ? f : 0);
+    const gcf_ptr base = to_global(a.rows ? a.rows[b].ring + ((long)al * a.ring_rows) * a.T + (ok ? f : 0)
+                                          : a.ring + ((long)(al * a.n_beam + b) * a.ring_rows) * a.T + (ok ? f : 0));
     const int n = a.prefill_rows + a.n_single;
     auto row_of = [&](int i) { return i < a.prefill_rows ? i : a.single_base + (i - a.prefill_rows); };
     // Round 4: the thread's first kZKeep window rows (windows of up to 4 kZKeep = 96 rows: every step but those of very
@@ -373,6 +376,7 @@ __device__ __forceinline__ void align_zscore_body(AlignArgs a, int fblock, int a
         w[t] = base[(long)row_of(i < n ? i : 0) * a.T];
     }
     const float newest = base[(long)a.newest_row * a.T];
+    __builtin_amdgcn_sched_barrier(0);   // all of them in flight before the first is folded (hipcc interleaves otherwise)
     double sum = 0.0;
 #pragma unroll
     for (int t = 0; t < kZKeep; ++t)
@@ -524,7 +528,20 @@ __global__ __launch_bounds__(1024) void align_argmax_lds_kernel(AlignArgs a) { a
 // launch, workgroups pick their role from the block index.  Same device functions, same arithmetic as the four
 // separate kernels above (which remain for the configurations the fused form does not cover).
 // ---------------------------------------------------------------------------------------------
+// every field either role reads, requested by one s_load burst at kernel entry (see WLK_PIN_GEMM_ARGS)
+#define WLK_PIN_SELECT_ARGS(t, a)                                                                                           \
+    do {                                                                                                                    \
+        asm volatile("" ::"s"((t).logits), "s"((t).n_vocab), "s"((t).k), "s"((t).n_rows), "s"((t).parts), "s"((t).adj_row), \
+                     "s"((t).adj_ids), "s"((t).adj_deltas), "s"((t).n_adj), "s"((t).top_vals), "s"((t).top_ids),            \
+                     "s"((t).host.result), "s"((t).host.n_adj), "s"((t).host.seq));                                         \
+        asm volatile("" ::"s"((a).ring), "s"((a).n_align), "s"((a).n_beam), "s"((a).ring_rows), "s"((a).T),                 \
+                     "s"((a).prefill_rows), "s"((a).n_single), "s"((a).newest_row), "s"((a).single_base),                   \
+                     "s"((a).content_len), "s"((a).z), "s"((a).attn_last), "s"((a).frames), "s"((a).rows));                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    } while (0)
+
 __global__ __launch_bounds__(256) void select_stage1_kernel(TopkArgs t, AlignArgs a, int zf_blocks) {
+    WLK_PIN_SELECT_ARGS(t, a);
     const int n_topk = kSelBlocks * t.n_rows;
     if ((int)blockIdx.x < n_topk) {
         const int n_adj = t.host.n_adj ? *t.host.n_adj : t.n_adj;
@@ -538,6 +555,7 @@ __global__ __launch_bounds__(256) void select_stage1_kernel(TopkArgs t, AlignArg
 }
 
 __global__ __launch_bounds__(1024) void select_stage2_kernel(TopkArgs t, AlignArgs a) {
+    WLK_PIN_SELECT_ARGS(t, a);
     if ((int)blockIdx.x < a.n_beam) {
         align_argmax_lds_body(a, blockIdx.x, t.host);
     } else if ((int)blockIdx.x < a.n_beam + t.n_rows) {
