@@ -390,6 +390,13 @@ int wlk_diag_encoder_attention(const float* qkv, int t, int d, int n_head, float
 /* the VALU wave butterflies of csrc/wave_ops.h (DPP / v_permlane{16,32}_swap) against the __shfl_xor loops they replace,
  * on one wave of 64 floats: ten rows of 64 results each (sum, max, 16-lane sum, xor 1 .. 32 exchanges, arg-max index) */
 int wlk_diag_wave_ops(const float* in64, float* out640, float* ref640);
+/* the X3 path of the encoder's wide projections (csrc/x3.h, gemm_x3.hip: fp32 operands as three bf16 planes, six bf16
+ * MFMAs per fp32 product): C = epilogue(A W^T + bias) with both operands packed on the device; its timing probe; and the
+ * LayerNorm that writes its result in that format, unpacked again (bit-identical to wlk_diag_layernorm) */
+int wlk_diag_linear_x3(const float* a, const float* w, const float* bias, int m, int n, int k, int flags, float scale,
+                       int scale_cols, float* c);
+int wlk_diag_linear_x3_time(int m, int n, int k, int flags, int reps, float* us_per_launch);
+int wlk_diag_layernorm_x3(const float* x, const float* gamma, const float* beta, int rows, int d, float* y);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,21 @@
+#!/usr/bin/env python
+"""Average microseconds per launch: X3 wide GEMM (bf16 matrix cores, fp32 accuracy) vs the fp32-MFMA kernels launch_gemm picks,
+on the encoder's wide shapes.  GPU box only."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from whisperlivekit_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+shapes = [("base fc1", 1500, 2048, 512, 1), ("base qkv", 1500, 1536, 512, 4), ("base cross_kv", 1500, 6144, 512, 4),
+          ("small fc1", 1500, 3072, 768, 1), ("large-v3 qkv", 1500, 3840, 1280, 4), ("large-v3 fc1", 1500, 5120, 1280, 1),
+          ("8 x base fc1 rows", 12000, 2048, 512, 1)]
+for name, m, n, k, flags in shapes:
+    us3, us32 = C.c_float(), C.c_float()
+    assert lib.wlk_diag_linear_x3_time(m, n, k, flags, 50, C.byref(us3)) == 0, lib.wlk_diag_last_error()
+    assert lib.wlk_diag_linear_time(m, n, k, flags, 0, 50, C.byref(us32)) == 0
+    gf = 2.0 * m * n * k / 1e9
+    print(f"{name:20s} M{m} N{n} K{k}: x3 {us3.value:7.2f} us = {gf / us3.value * 1e3 / 1e3:6.1f} TF f32-equivalent ({6 * gf / us3.value:7.1f} TF bf16 issued) | "
+          f"fp32 mfma {us32.value:7.2f} us = {gf / us32.value:6.1f} TF | x{us32.value / us3.value:.2f}")

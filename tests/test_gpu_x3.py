@@ -1,0 +1,65 @@
+"""The X3 path (csrc/x3.h, gemm_x3.hip): the encoder's wide projections on the bf16 matrix cores at fp32 accuracy -
+operands held as three bf16 planes (hi + mid + lo == the fp32 value), six bf16 MFMAs per fp32 product.  The claim to
+check is "fp32 accuracy": against float64 the result must be as close as the fp32-MFMA kernel's (and as torch's own fp32
+GEMM, which is what the reference computes with on the CPU)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from whisperlivekit_amd import _lib
+
+pytestmark = pytest.mark.gpu
+vp = lambda a: a.ctypes.data_as(C.c_void_p)
+
+
+def _err(x, ref):
+    scale = np.abs(ref).mean()
+    d = np.abs(x.astype(np.float64) - ref)
+    return d.max() / scale, d.mean() / scale
+
+
+@pytest.mark.parametrize("M,N,K,flags", [(1500, 2048, 512, 1), (1500, 1536, 512, 4), (1500, 6144, 512, 4), (333, 1152, 384, 0),
+                                          (1500, 1280 * 3, 1280, 4), (257, 1024, 64, 1)])
+def test_x3_gemm_is_as_close_to_float64_as_the_fp32_mfma_gemm(M, N, K, flags):
+    lib = _lib.load()
+    rng = np.random.default_rng(M + N + K)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    a[:, :5] *= 40.0                                   # a few loud channels, as a residual stream has
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
+    if flags & 4:
+        ref[:, :N // 2] *= 0.5
+    if flags & 1:
+        ref = 0.5 * ref * (1.0 + torch.erf(torch.from_numpy(ref) * 0.7071067811865476).numpy())
+    c3 = np.empty((M, N), np.float32)
+    assert lib.wlk_diag_linear_x3(vp(a), vp(w), vp(bias), M, N, K, flags, 0.5, N // 2, vp(c3)) == 0, lib.wlk_diag_last_error()
+    c32 = np.empty((M, N), np.float32)
+    assert lib.wlk_diag_linear(vp(a), K, M * K, vp(w), vp(bias), None, N, M, N, K, flags, 0.5, N // 2, 0, vp(c32)) == 0
+    t = torch.from_numpy(a) @ torch.from_numpy(w).T + torch.from_numpy(bias)
+    if flags & 4:
+        t[:, :N // 2] *= 0.5
+    if flags & 1:
+        t = torch.nn.functional.gelu(t)
+    e3, e32, et = _err(c3, ref), _err(c32, ref), _err(t.numpy(), ref)
+    print(f"M{M} N{N} K{K}: x3 max/mean {e3[0]:.2e} {e3[1]:.2e} | fp32 mfma {e32[0]:.2e} {e32[1]:.2e} | torch cpu {et[0]:.2e} {et[1]:.2e}")
+    assert e3[1] <= 2.0 * max(e32[1], et[1]) and e3[0] <= 3.0 * max(e32[0], et[0]), (e3, e32, et)
+    assert e3[0] < 5e-5
+
+
+def test_x3_layernorm_round_trip_is_the_fp32_layernorm():
+    """The planes are an exact image: LayerNorm -> X3 -> (hi + mid) + lo equals the fp32 LayerNorm kernel's output bit for bit."""
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    for rows, d in ((1500, 512), (77, 384), (300, 1280), (64, 768)):
+        x = (rng.standard_normal((rows, d)) * 3.0).astype(np.float32)
+        x[:, 7] += 100.0
+        g = (1 + 0.2 * rng.standard_normal(d)).astype(np.float32)
+        b = (0.3 * rng.standard_normal(d)).astype(np.float32)
+        y = np.empty((rows, d), np.float32)
+        y3 = np.empty((rows, d), np.float32)
+        assert lib.wlk_diag_layernorm(vp(x), vp(g), vp(b), rows, d, vp(y)) == 0
+        assert lib.wlk_diag_layernorm_x3(vp(x), vp(g), vp(b), rows, d, vp(y3)) == 0, lib.wlk_diag_last_error()
+        assert np.array_equal(y.view(np.uint32), y3.view(np.uint32)), (rows, d, np.abs(y - y3).max())

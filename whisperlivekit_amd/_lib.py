@@ -182,6 +182,9 @@ def _declare(lib: C.CDLL) -> None:
         "wlk_diag_encoder_attention_time": (cint, [cint, cint, cint, cint, cint, C.POINTER(C.c_float)]),
         "wlk_diag_encoder_attention": (cint, [p, cint, cint, cint, p]),
         "wlk_diag_wave_ops": (cint, [p, p, p]),
+        "wlk_diag_linear_x3": (cint, [p, p, p, cint, cint, cint, cint, C.c_float, cint, p]),
+        "wlk_diag_linear_x3_time": (cint, [cint, cint, cint, cint, cint, C.POINTER(C.c_float)]),
+        "wlk_diag_layernorm_x3": (cint, [p, p, p, cint, cint, p]),
     }
     for name, (res, args) in sig.items():
         try:
@@ -218,6 +221,7 @@ EXPORTED_SYMBOLS = (
     "wlk_nllb_decode", "wlk_nllb_step", "wlk_nllb_kv_reorder", "wlk_nllb_topk", "wlk_nllb_export", "wlk_nllb_sync",
     "wlk_diag_last_error", "wlk_diag_linear", "wlk_diag_linear_time", "wlk_diag_linear_ln", "wlk_diag_layernorm",
     "wlk_diag_encoder_attention", "wlk_diag_encoder_attention_time", "wlk_diag_wave_ops",
+    "wlk_diag_linear_x3", "wlk_diag_linear_x3_time", "wlk_diag_layernorm_x3",
 )
 
 

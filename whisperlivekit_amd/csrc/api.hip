@@ -338,6 +338,32 @@ int wlk_model_finalize(wlk_model* m) {
                                   hipMemcpyDeviceToDevice);
             }
         }
+        {   // X3 images of the encoder's wide projection weights (gemm_x3.hip); shapes the wide kernel does not take keep
+            // their fp32 kernels.  Built here, from the arena, so that ranks that got the weights by broadcast build the same.
+            for (unsigned short* p : m->x3_owned) (void)hipFree(p);
+            m->x3_owned.clear();
+            m->xkv_all_w3 = nullptr;
+            const int da = m->D.n_audio_state, T = m->D.n_audio_ctx;
+            LaunchCtx c;
+            c.stream = nullptr;
+            hipStream_t st;
+            WLK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            c.stream = st;
+            auto pack = [&](const float* w, int n_rows) -> unsigned short* {
+                unsigned short* p3 = dev_alloc<unsigned short>((size_t)n_rows * 3 * da);
+                m->x3_owned.push_back(p3);
+                launch_x3_pack(c, w, da, p3, da, n_rows, da);
+                return p3;
+            };
+            for (auto& L : m->enc_layers) {
+                L.qkvw3 = gemm_x3_wide_applicable(T, 3 * da, da, da) ? pack(L.qkvw, 3 * da) : nullptr;
+                L.fc1w3 = gemm_x3_wide_applicable(T, 4 * da, da, da) ? pack(L.fc1w, 4 * da) : nullptr;
+            }
+            const int n_xkv = m->D.n_text_layer * 2 * m->D.n_text_state;
+            if (gemm_x3_wide_applicable(T, n_xkv, da, da)) m->xkv_all_w3 = pack(m->xkv_all_w, n_xkv);
+            WLK_HIP(hipStreamSynchronize(st));
+            (void)hipStreamDestroy(st);
+        }
         m->w_tok_emb = m->w("dec.tok_emb");
         m->w_dec_pos = m->w("dec.pos");
         m->w_ln_w = m->w("dec.ln.w");
@@ -354,6 +380,7 @@ int wlk_model_destroy(wlk_model* m) {
     if (m->owns_arena) (void)hipFree(m->arena);
     if (m->xkv_all_w) (void)hipFree(m->xkv_all_w);
     if (m->xkv_all_b) (void)hipFree(m->xkv_all_b);
+    for (unsigned short* p : m->x3_owned) (void)hipFree(p);
     (void)hipFree(m->twiddle);
     (void)hipFree(m->filt_lo);
     (void)hipFree(m->filt_hi);
@@ -398,6 +425,8 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         s->eatt = dev_alloc<float>(T * d);
         s->emlp = dev_alloc<float>(T * 4 * d);
         s->enc_out = dev_alloc<float>(T * d);
+        s->eh3 = dev_alloc<unsigned short>(T * 3 * d);
+        s->enc_out3 = dev_alloc<unsigned short>(T * 3 * d);
         s->cross_kv = dev_alloc<float>((size_t)D.n_text_layer * T * 2 * d);
 
         s->max_rows = beam * (int)ctx;
@@ -480,6 +509,8 @@ int wlk_session_destroy(wlk_session* s) {
         if (e) (void)hipGraphExecDestroy(e);
     if (s->topk_scratch) (void)hipFree(s->topk_scratch);
     if (s->pcm16_dev) (void)hipFree(s->pcm16_dev);
+    if (s->eh3) (void)hipFree(s->eh3);
+    if (s->enc_out3) (void)hipFree(s->enc_out3);
     if (s->wa_buf) (void)hipFree(s->wa_buf);
     if (s->esplit) (void)hipFree(s->esplit);
     if (s->pinned) (void)hipHostFree(s->pinned);
@@ -768,36 +799,73 @@ extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const
     const PtrTable z_eh_mlp = table([](wlk_session* s) { return (const float*)s->eh; }, [](wlk_session* s) { return s->emlp; }, none);
     const PtrTable z_mlp_ex = table([](wlk_session* s) { return (const float*)s->emlp; }, [](wlk_session* s) { return s->ex; },
                                     [](wlk_session* s) { return (const float*)s->ex; });
+    // Wide projections (qkv, fc1, cross-attention K|V) on the bf16 matrix cores at fp32 accuracy (gemm_x3.hip): their
+    // LayerNorm writes the operand in the X3 format, the weights were packed by wlk_model_finalize.  Every session of a
+    // group takes the same path (the choice depends on the model only).
+    const PtrTable z_ex_eh3 = table([](wlk_session* s) { return (const float*)s->ex; },
+                                    [](wlk_session* s) { return reinterpret_cast<float*>(s->eh3); }, none);
+    const PtrTable z_eh3_qkv = table([](wlk_session* s) { return reinterpret_cast<const float*>(s->eh3); },
+                                     [](wlk_session* s) { return s->eqkv; }, none);
+    const PtrTable z_eh3_mlp = table([](wlk_session* s) { return reinterpret_cast<const float*>(s->eh3); },
+                                     [](wlk_session* s) { return s->emlp; }, none);
+    auto gemm_x3 = [&](const GemmArgs& g, const unsigned short* w3, const PtrTable& z, const char* tag) {
+        X3GemmArgs x;
+        x.lda = g.lda; x.W3 = w3; x.bias = g.bias; x.ldc = g.ldc; x.ldr = g.ldr; x.M = g.M; x.N = g.N; x.K = g.K;
+        x.flags = g.flags; x.scale = g.scale; x.scale_cols = g.scale_cols; x.scale_period = g.scale_period;
+        x.batch = B;
+        x.z = z;
+        launch_gemm_x3(c, x, tag);
+    };
     for (int i = 0; i < D.n_audio_layer; ++i) {
         const LayerW& L = m->enc_layers[i];
-        launch_layernorm_batched(c, z_ex_eh, B, d, L.ln1w, L.ln1b, d, T, d, "enc_ln1");
         GemmArgs g;
         g.lda = d; g.W = L.qkvw; g.bias = L.qkvb; g.ldc = 3 * d; g.M = T; g.N = 3 * d;
         g.K = d; g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = 2 * d;
-        gemm(g, z_eh_qkv, "enc_qkv");
+        if (L.qkvw3) {
+            launch_layernorm_x3_batched(c, z_ex_eh3, B, d, L.ln1w, L.ln1b, d, T, d, "enc_ln1");
+            gemm_x3(g, L.qkvw3, z_eh3_qkv, "enc_qkv");
+        } else {
+            launch_layernorm_batched(c, z_ex_eh, B, d, L.ln1w, L.ln1b, d, T, d, "enc_ln1");
+            gemm(g, z_eh_qkv, "enc_qkv");
+        }
         launch_encoder_attention_batched(c, z_qkv_att, B, T, d, D.n_audio_head);
         GemmArgs o;
         o.lda = d; o.W = L.outw; o.bias = L.outb; o.ldc = d; o.M = T; o.N = d; o.K = d;
         o.flags = kGemmResidual; o.ldr = d;
         gemm(o, z_att_ex, "enc_out");
-        launch_layernorm_batched(c, z_ex_eh, B, d, L.ln2w, L.ln2b, d, T, d, "enc_ln2");
         GemmArgs f1;
         f1.lda = d; f1.W = L.fc1w; f1.bias = L.fc1b; f1.ldc = 4 * d; f1.M = T; f1.N = 4 * d; f1.K = d; f1.flags = kGemmGelu;
-        gemm(f1, z_eh_mlp, "enc_fc1");
+        if (L.fc1w3) {
+            launch_layernorm_x3_batched(c, z_ex_eh3, B, d, L.ln2w, L.ln2b, d, T, d, "enc_ln2");
+            gemm_x3(f1, L.fc1w3, z_eh3_mlp, "enc_fc1");
+        } else {
+            launch_layernorm_batched(c, z_ex_eh, B, d, L.ln2w, L.ln2b, d, T, d, "enc_ln2");
+            gemm(f1, z_eh_mlp, "enc_fc1");
+        }
         GemmArgs f2;
         f2.lda = 4 * d; f2.W = L.fc2w; f2.bias = L.fc2b; f2.ldc = d; f2.M = T; f2.N = d; f2.K = 4 * d;
         f2.flags = kGemmResidual; f2.ldr = d;
         gemm(f2, z_mlp_ex, "enc_fc2");
     }
-    launch_layernorm_batched(c, table([](wlk_session* s) { return (const float*)s->ex; }, [](wlk_session* s) { return s->enc_out; }, none),
-                             B, d, m->w("enc.ln_post.w"), m->w("enc.ln_post.b"), d, T, d, "enc_ln_post");
-    {   // cross-attention K (scaled) and V of every decoder layer in ONE GEMM: cross_kv is [T][L][k | v]
+    {   // final LayerNorm + cross-attention K (scaled) and V of every decoder layer in ONE GEMM: cross_kv is [T][L][k | v]
         GemmArgs g;
         g.lda = d; g.W = m->xkv_all_w; g.bias = m->xkv_all_b;
         g.ldc = (long)D.n_text_layer * 2 * d; g.M = T; g.N = D.n_text_layer * 2 * d; g.K = d;
         g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = d; g.scale_period = 2 * d;
-        gemm(g, table([](wlk_session* s) { return (const float*)s->enc_out; }, [](wlk_session* s) { return s->cross_kv; }, none),
-             "dec_cross_kv");
+        if (m->xkv_all_w3) {
+            launch_layernorm_x3_batched(c, table([](wlk_session* s) { return (const float*)s->ex; },
+                                                 [](wlk_session* s) { return reinterpret_cast<float*>(s->enc_out3); }, none),
+                                        B, d, m->w("enc.ln_post.w"), m->w("enc.ln_post.b"), d, T, d, "enc_ln_post");
+            gemm_x3(g, m->xkv_all_w3,
+                    table([](wlk_session* s) { return reinterpret_cast<const float*>(s->enc_out3); }, [](wlk_session* s) { return s->cross_kv; }, none),
+                    "dec_cross_kv");
+        } else {
+            launch_layernorm_batched(c, table([](wlk_session* s) { return (const float*)s->ex; }, [](wlk_session* s) { return s->enc_out; }, none),
+                                     B, d, m->w("enc.ln_post.w"), m->w("enc.ln_post.b"), d, T, d, "enc_ln_post");
+            gemm(g, table([](wlk_session* s) { return (const float*)s->enc_out; }, [](wlk_session* s) { return s->cross_kv; }, none),
+                 "dec_cross_kv");
+        }
+        for (int i = 0; i < B; ++i) group[i]->enc_out_is_x3 = m->xkv_all_w3 != nullptr;
     }
     for (int i = 0; i < B; ++i) {
         wlk_session* s = group[i];
@@ -1524,7 +1592,12 @@ int wlk_export(wlk_session* s, const char* what, float* host, uint64_t capacity,
                 for (int mm = 0; mm < D.n_mels; ++mm) host[(size_t)mm * kMelFrames + t] = tm[(size_t)t * D.n_mels + mm];
             return WLK_OK;
         }
-        if (w == "enc") return copy_out(s, s->enc_out, T * d, host, capacity, n_written);
+        if (w == "enc") {
+            if (s->enc_out_is_x3) {      // the encoder output exists as three bf16 planes: hi + mid + lo is the fp32 value, exactly
+                launch_x3_unpack(s->ctx(), s->enc_out3, d, s->enc_out, d, (int)T, (int)d);
+            }
+            return copy_out(s, s->enc_out, T * d, host, capacity, n_written);
+        }
         if (w == "logits_last") return copy_out(s, s->logits_last, (uint64_t)s->beam * D.n_vocab, host, capacity, n_written);
         if (w == "logits_sot") return copy_out(s, s->logits_sot, (uint64_t)s->beam * D.n_vocab, host, capacity, n_written);
         if (w == "attn_last") return copy_out(s, s->attn_last, (uint64_t)s->beam * T, host, capacity, n_written);

@@ -225,12 +225,43 @@ inline void launch_linear(const LaunchCtx& ctx, const GemmArgs& g, const char* t
     else launch_gemm(ctx, g, tag);
 }
 
+// ---- gemm_x3.hip / x3.h: fp32-accurate GEMM on the bf16 matrix cores (operands as three bf16 planes) ---------------
+struct X3GemmArgs {
+    const unsigned short* A3 = nullptr;   // activations in X3: row m at A3 + m * 3 * lda (bf16 units)
+    long lda = 0;                         // in fp32-element units (a row holds 3 * lda bf16)
+    const unsigned short* W3 = nullptr;   // weights [N][K] in X3 (row n at W3 + n * 3 * K)
+    const float* bias = nullptr;
+    float* C = nullptr;                   // fp32 result
+    long ldc = 0;
+    const float* R = nullptr;
+    long ldr = 0;
+    int M = 0, N = 0, K = 0;
+    int flags = 0;                        // kGemmGelu | kGemmResidual | kGemmScaleCols
+    float scale = 1.f;
+    int scale_cols = 0;
+    int scale_period = 0;
+    int batch = 0;                        // > 0: grid.y = batch; A3 = z.in[i] (X3), C = z.out[i], R = z.res[i]
+    PtrTable z;
+};
+bool gemm_x3_wide_applicable(int M, int N, int K, long lda);
+void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag);
+// fp32 [rows][ld_src] (cols used) -> X3 [rows][3 * ld_dst]
+void launch_x3_pack(const LaunchCtx& ctx, const float* src, long ld_src, unsigned short* dst, long ld_dst, int rows, int cols);
+// X3 [rows][3 * ld_src] -> fp32 [rows][ld_dst]: (hi + mid) + lo, the exact fp32 value the planes were split from
+void launch_x3_unpack(const LaunchCtx& ctx, const unsigned short* src, long ld_src, float* dst, long ld_dst, int rows, int cols);
+
 // ---- layernorm.hip --------------------------------------------------------------------------
 void launch_layernorm(const LaunchCtx& ctx, const float* x, long ldx, const float* gamma, const float* beta,
                       float* y, long ldy, int rows, int d, const char* tag);
 // the same for `batch` sessions at once: x = z.in[i], y = z.out[i]
 void launch_layernorm_batched(const LaunchCtx& ctx, const PtrTable& z, int batch, long ldx, const float* gamma,
                               const float* beta, long ldy, int rows, int d, const char* tag);
+// the same with the result in the X3 format (three bf16 planes; the operand of launch_gemm_x3): y3 row stride 3 * ldy3
+// bf16; batched form: x = z.in[i], y3 = z.out[i] reinterpreted
+void launch_layernorm_x3(const LaunchCtx& ctx, const float* x, long ldx, const float* gamma, const float* beta,
+                         unsigned short* y3, long ldy3, int rows, int d, const char* tag);
+void launch_layernorm_x3_batched(const LaunchCtx& ctx, const PtrTable& z, int batch, long ldx, const float* gamma,
+                                 const float* beta, long ldy3, int rows, int d, const char* tag);
 
 // ---- mel.hip --------------------------------------------------------------------------------
 struct MelArgs {

@@ -312,4 +312,83 @@ int wlk_diag_wave_ops(const float* in64, float* out640, float* ref640) {
     });
 }
 
+/* C[m, n] = epilogue(A[m, k] . W[n, k]^T + bias) through the X3 path (gemm_x3.hip): both operands are packed into three
+ * bf16 planes on the device, the wide bf16-MFMA kernel runs, the fp32 result comes back */
+int wlk_diag_linear_x3(const float* a, const float* w, const float* bias, int m, int n, int k, int flags, float scale,
+                       int scale_cols, float* c) {
+    return run([&]() {
+        DevBuf A((size_t)m * k, a), W((size_t)n * k, w), B(n, bias), Cc((size_t)m * n);
+        unsigned short *a3 = nullptr, *w3 = nullptr;
+        WLK_HIP(hipMalloc(reinterpret_cast<void**>(&a3), (size_t)m * 3 * k * sizeof(unsigned short)));
+        WLK_HIP(hipMalloc(reinterpret_cast<void**>(&w3), (size_t)n * 3 * k * sizeof(unsigned short)));
+        LaunchCtx ctx;
+        launch_x3_pack(ctx, A.p, k, a3, k, m, k);
+        launch_x3_pack(ctx, W.p, k, w3, k, n, k);
+        X3GemmArgs g;
+        g.A3 = a3; g.lda = k; g.W3 = w3; g.bias = bias ? B.p : nullptr; g.C = Cc.p; g.ldc = n; g.M = m; g.N = n; g.K = k;
+        g.flags = flags; g.scale = scale; g.scale_cols = scale_cols;
+        launch_gemm_x3(ctx, g, "diag_x3");
+        WLK_HIP(hipDeviceSynchronize());
+        WLK_HIP(hipMemcpy(c, Cc.p, (size_t)m * n * sizeof(float), hipMemcpyDeviceToHost));
+        (void)hipFree(a3);
+        (void)hipFree(w3);
+    });
+}
+
+/* kernel-tuning probe: average microseconds per launch of the X3 wide GEMM (device-resident pseudo-random operands) */
+int wlk_diag_linear_x3_time(int m, int n, int k, int flags, int reps, float* us_per_launch) {
+    return run([&]() {
+        std::vector<float> ha((size_t)m * k), hw((size_t)n * k);
+        unsigned seed = 12345u;
+        auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xffff) / 65536.0f - 0.5f; };
+        for (auto& v : ha) v = rnd();
+        for (auto& v : hw) v = rnd() * 0.05f;
+        DevBuf A((size_t)m * k, ha.data()), W((size_t)n * k, hw.data()), B(n), Cc((size_t)m * n);
+        WLK_HIP(hipMemset(B.p, 0, n * sizeof(float)));
+        unsigned short *a3 = nullptr, *w3 = nullptr;
+        WLK_HIP(hipMalloc(reinterpret_cast<void**>(&a3), (size_t)m * 3 * k * sizeof(unsigned short)));
+        WLK_HIP(hipMalloc(reinterpret_cast<void**>(&w3), (size_t)n * 3 * k * sizeof(unsigned short)));
+        hipStream_t st;
+        WLK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        LaunchCtx ctx{st, nullptr};
+        launch_x3_pack(ctx, A.p, k, a3, k, m, k);
+        launch_x3_pack(ctx, W.p, k, w3, k, n, k);
+        X3GemmArgs g;
+        g.A3 = a3; g.lda = k; g.W3 = w3; g.bias = B.p; g.C = Cc.p; g.ldc = n; g.M = m; g.N = n; g.K = k; g.flags = flags;
+        g.scale = 0.5f; g.scale_cols = n / 2;
+        launch_gemm_x3(ctx, g, "diag");
+        WLK_HIP(hipStreamSynchronize(st));
+        hipEvent_t e0, e1;
+        WLK_HIP(hipEventCreate(&e0));
+        WLK_HIP(hipEventCreate(&e1));
+        WLK_HIP(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) launch_gemm_x3(ctx, g, "diag");
+        WLK_HIP(hipEventRecord(e1, st));
+        WLK_HIP(hipStreamSynchronize(st));
+        float ms = 0.f;
+        WLK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *us_per_launch = 1e3f * ms / (float)reps;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipStreamDestroy(st);
+        (void)hipFree(a3);
+        (void)hipFree(w3);
+    });
+}
+
+/* LayerNorm with the result in the X3 format, unpacked again: y must equal wlk_diag_layernorm's y bit for bit */
+int wlk_diag_layernorm_x3(const float* x, const float* gamma, const float* beta, int rows, int d, float* y) {
+    return run([&]() {
+        DevBuf X((size_t)rows * d, x), G(d, gamma), Bt(d, beta), Y((size_t)rows * d);
+        unsigned short* y3 = nullptr;
+        WLK_HIP(hipMalloc(reinterpret_cast<void**>(&y3), (size_t)rows * 3 * d * sizeof(unsigned short)));
+        LaunchCtx ctx;
+        launch_layernorm_x3(ctx, X.p, d, G.p, Bt.p, y3, d, rows, d, "diag_ln_x3");
+        launch_x3_unpack(ctx, y3, d, Y.p, d, rows, d);
+        WLK_HIP(hipDeviceSynchronize());
+        WLK_HIP(hipMemcpy(y, Y.p, (size_t)rows * d * sizeof(float), hipMemcpyDeviceToHost));
+        (void)hipFree(y3);
+    });
+}
+
 }  // extern "C"

@@ -76,6 +76,9 @@ struct LayerW {
     const float *ln1w, *ln1b, *qkvw, *qkvb, *outw, *outb, *ln2w, *ln2b, *fc1w, *fc1b, *fc2w, *fc2b;
     const float *lnxw = nullptr, *lnxb = nullptr, *xqw = nullptr, *xqb = nullptr, *xkvw = nullptr, *xkvb = nullptr,
                 *xoutw = nullptr, *xoutb = nullptr;
+    // encoder layers: the wide projections' weights in the X3 format (x3.h), packed by wlk_model_finalize; nullptr = the
+    // shape stays on the fp32-MFMA kernels
+    const unsigned short *qkvw3 = nullptr, *fc1w3 = nullptr;
 };
 
 template <typename T>
@@ -133,6 +136,8 @@ struct wlk_model {
     // arena's per-layer tensors made by wlk_model_finalize): one GEMM per encode instead of L
     float* xkv_all_w = nullptr;
     float* xkv_all_b = nullptr;
+    unsigned short* xkv_all_w3 = nullptr;      // the same weights in the X3 format (nullptr: fp32 kernels)
+    std::vector<unsigned short*> x3_owned;     // every X3 weight buffer of this model (freed with it)
     int* filt_lo = nullptr;           // [n_mels]
     int* filt_hi = nullptr;
     int* head_rank = nullptr;         // [L][H] alignment rank or -1
@@ -189,6 +194,10 @@ struct wlk_session {
     int frame_cap = 0;
     float *x1p = nullptr, *ex = nullptr, *eh = nullptr, *eqkv = nullptr, *eatt = nullptr, *emlp = nullptr,
           *enc_out = nullptr, *cross_kv = nullptr;
+    // X3 images (three bf16 planes) of the LayerNorm outputs that feed the bf16-MFMA projections (gemm_x3.hip); enc_out3
+    // replaces enc_out when the cross-attention K|V projection takes that path (wlk_export("enc") unpacks it)
+    unsigned short *eh3 = nullptr, *enc_out3 = nullptr;
+    bool enc_out_is_x3 = false;
     bool encoded = false;
     int content_len = 0;
 
