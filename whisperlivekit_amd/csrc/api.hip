@@ -823,7 +823,7 @@ extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const
         g.K = d; g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = 2 * d;
         if (L.qkvw3) {
             launch_layernorm_x3_batched(c, z_ex_eh3, B, d, L.ln1w, L.ln1b, d, T, d, "enc_ln1");
-            gemm_x3(g, L.qkvw3, z_eh3_qkv, "enc_qkv");
+            gemm_x3(g, L.qkvw3, z_eh3_qkv, "enc_qkv_x3");
         } else {
             launch_layernorm_batched(c, z_ex_eh, B, d, L.ln1w, L.ln1b, d, T, d, "enc_ln1");
             gemm(g, z_eh_qkv, "enc_qkv");
@@ -837,7 +837,7 @@ extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const
         f1.lda = d; f1.W = L.fc1w; f1.bias = L.fc1b; f1.ldc = 4 * d; f1.M = T; f1.N = 4 * d; f1.K = d; f1.flags = kGemmGelu;
         if (L.fc1w3) {
             launch_layernorm_x3_batched(c, z_ex_eh3, B, d, L.ln2w, L.ln2b, d, T, d, "enc_ln2");
-            gemm_x3(f1, L.fc1w3, z_eh3_mlp, "enc_fc1");
+            gemm_x3(f1, L.fc1w3, z_eh3_mlp, "enc_fc1_x3");
         } else {
             launch_layernorm_batched(c, z_ex_eh, B, d, L.ln2w, L.ln2b, d, T, d, "enc_ln2");
             gemm(f1, z_eh_mlp, "enc_fc1");
@@ -858,7 +858,7 @@ extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const
                                         B, d, m->w("enc.ln_post.w"), m->w("enc.ln_post.b"), d, T, d, "enc_ln_post");
             gemm_x3(g, m->xkv_all_w3,
                     table([](wlk_session* s) { return reinterpret_cast<const float*>(s->enc_out3); }, [](wlk_session* s) { return s->cross_kv; }, none),
-                    "dec_cross_kv");
+                    "dec_cross_kv_x3");
         } else {
             launch_layernorm_batched(c, table([](wlk_session* s) { return (const float*)s->ex; }, [](wlk_session* s) { return s->enc_out; }, none),
                                      B, d, m->w("enc.ln_post.w"), m->w("enc.ln_post.b"), d, T, d, "enc_ln_post");

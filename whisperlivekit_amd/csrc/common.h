@@ -241,6 +241,7 @@ struct X3GemmArgs {
     int scale_cols = 0;
     int scale_period = 0;
     int batch = 0;                        // > 0: grid.y = batch; A3 = z.in[i] (X3), C = z.out[i], R = z.res[i]
+    int map_mode = 0;                     // probe only (WLK_X3_MAP): 1 = plain tile order, 2 = 2 x 4 bands
     PtrTable z;
 };
 bool gemm_x3_wide_applicable(int M, int N, int K, long lda);

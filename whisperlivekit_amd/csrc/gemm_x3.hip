@@ -23,6 +23,11 @@ namespace wlk {
 typedef float xf32x16 __attribute__((ext_vector_type(16)));
 typedef float xf32x4 __attribute__((ext_vector_type(4)));
 
+// exact-erf GELU as a CALL: inlined 48 times per lane (3 row blocks x 16 accumulator registers) the erf polynomial was
+// ~50 KB of straight-line code that every workgroup pulled through the instruction cache once - 6 us of the 28 us the
+// 1500 x 2048 x 512 fc1 launch took (profiles/r04e_x3_ablation.txt: fixed cost 13.5 us with GELU, 7.6 us without)
+__device__ __attribute__((noinline)) float x3_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
 template <int N, int I = 0, typename F>
 __device__ __forceinline__ void x3_static_for(F&& f) {
     if constexpr (I < N) {
@@ -116,6 +121,9 @@ __device__ __forceinline__ void xw_read_frags(xf32x4 (&f)[XW_NF], const unsigned
 // wave beside each compute wave on every SIMD the two instruction streams overlap.
 // One workgroup barrier per slab: the loaders arrive when their pieces of slab t + 1 have landed, the compute waves when
 // they have read the last fragments of slab t; behind it slab t + 1 is readable and the slot of slab t - 1 is free.
+// ABL (timing probe only, WLK_X3_ABL): 1 = the loaders run, the compute waves skip their MFMAs and fragment reads;
+// 2 = the compute waves run, the loaders issue nothing; 3 = MFMAs only (no fragment reads, no DMA)
+template <int ABL>
 __global__ __launch_bounds__(512) void gemm_x3_wide_kernel(X3GemmArgs g) {
     asm volatile("" ::"s"(g.A3), "s"(g.lda), "s"(g.W3), "s"(g.bias), "s"(g.C), "s"(g.ldc), "s"(g.R), "s"(g.ldr), "s"(g.M),
                  "s"(g.N), "s"(g.K), "s"(g.flags), "s"(g.scale), "s"(g.scale_cols), "s"(g.scale_period), "s"(g.batch));
@@ -130,7 +138,13 @@ __global__ __launch_bounds__(512) void gemm_x3_wide_kernel(X3GemmArgs g) {
     // XCD-aware tile mapping, as in gemm_nt_f32_kernel: 4 row bands x 2 column bands, one per XCD
     const int tiles_m = (g.M + XW_BM - 1) / XW_BM, tiles_n = (g.N + XW_BN - 1) / XW_BN;
     int tile_m, tile_n;
-    if (tiles_m >= 8) {
+    if (tiles_m >= 8 && g.map_mode == 2) {          // probe: 2 row bands x 4 column bands
+        const int band_m = (tiles_m + 1) / 2, band_n = (tiles_n + 3) / 4;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        tile_m = (xcd >> 2) * band_m + slot / band_n;
+        tile_n = (xcd & 3) * band_n + slot % band_n;
+        if (slot >= band_m * band_n || tile_m >= tiles_m || tile_n >= tiles_n) return;
+    } else if (tiles_m >= 8 && g.map_mode == 0) {
         const int band_m = (tiles_m + 3) / 4, band_n = (tiles_n + 1) / 2;
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         tile_m = (xcd >> 1) * band_m + slot / band_n;
@@ -163,6 +177,7 @@ __global__ __launch_bounds__(512) void gemm_x3_wide_kernel(X3GemmArgs g) {
                 src[i] = reinterpret_cast<const char*>(g.W3) + ((long)min(n0 + row - XW_BM, g.N - 1) * 3 * g.K) * 2 + unit * 16;
         }
         auto issue_slab = [&](int slab) {     // slab (clamped: the tail re-fetches the last one into a free slot)
+            if constexpr (ABL >= 2) return;
             const int slot = slab % XW_NB;
             const long adv = (long)min(slab, nslab - 1) * XW_ROW_BYTES;
             x3_static_for<XW_NPW>([&](auto I) {
@@ -224,15 +239,15 @@ __global__ __launch_bounds__(512) void gemm_x3_wide_kernel(X3GemmArgs g) {
     read_frags(g0, 0, f_addr[0]);
     xw_wait_frags(g0);
     for (int tt = 0; tt < nslab; ++tt) {
-        read_frags(g1, tt, f_addr[1]);
+        if constexpr (ABL != 1 && ABL != 3) read_frags(g1, tt, f_addr[1]);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_step(g0);
+        if constexpr (ABL != 1) mfma_step(g0);
         __builtin_amdgcn_sched_barrier(0);
         xw_wait_frags(g1);
         __builtin_amdgcn_s_barrier();          // slab tt + 1 readable; everybody is done with slab tt's fragments
-        read_frags(g0, tt + 1, f_addr[0]);
+        if constexpr (ABL != 1 && ABL != 3) read_frags(g0, tt + 1, f_addr[0]);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_step(g1);
+        if constexpr (ABL != 1) mfma_step(g1);
         __builtin_amdgcn_sched_barrier(0);
         xw_wait_frags(g0);
     }
@@ -255,7 +270,7 @@ __global__ __launch_bounds__(512) void gemm_x3_wide_kernel(X3GemmArgs g) {
                 const int row = row_base + (q & 3) + 8 * (q >> 2);
                 float v = acc[i][q] + bias;
                 if (do_scale) v *= g.scale;
-                if (gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                if (gelu) v = x3_gelu_erf(v);
                 v += res[q];
                 if (row < g.M) gC[(long)row * g.ldc + col] = v;
             }
@@ -279,18 +294,35 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
     int dev = 0;
     WLK_HIP(hipGetDevice(&dev));
     if (!(configured.load(std::memory_order_acquire) >> (dev & 63) & 1)) {
-        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)XW_LDS_BYTES));
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
         configured.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const int tiles_m = (g.M + XW_BM - 1) / XW_BM, tiles_n = (g.N + XW_BN - 1) / XW_BN;
+    static const int map_mode = [] {
+        const char* e = getenv("WLK_X3_MAP");
+        return e ? atoi(e) : 0;
+    }();
+    X3GemmArgs gg = g;
+    gg.map_mode = map_mode;
     int blocks = tiles_m * tiles_n;
-    if (tiles_m >= 8) blocks = 8 * ((tiles_m + 3) / 4) * ((tiles_n + 1) / 2);
+    if (tiles_m >= 8 && map_mode == 0) blocks = 8 * ((tiles_m + 3) / 4) * ((tiles_n + 1) / 2);
+    if (tiles_m >= 8 && map_mode == 2) blocks = 8 * ((tiles_m + 1) / 2) * ((tiles_n + 3) / 4);
     const int batch = g.batch > 0 ? g.batch : 1;
     // algorithmic work (what the roofline fraction is computed from): 2 M N K flop, operands and result once
     KernelScope ks(ctx, tag, 2.0 * batch * (double)g.M * g.N * g.K,
                    batch * (6.0 * ((double)g.M * g.K) + 4.0 * (double)g.M * g.N) + 6.0 * (double)g.N * g.K);
-    hipLaunchKernelGGL(gemm_x3_wide_kernel, dim3(blocks, batch), dim3(512), XW_LDS_BYTES, ctx.stream, g);
+    static const int abl = [] {
+        const char* e = getenv("WLK_X3_ABL");
+        return e ? atoi(e) : 0;
+    }();
+    const dim3 grid(blocks, batch);
+    if (abl == 1) hipLaunchKernelGGL(gemm_x3_wide_kernel<1>, grid, dim3(512), XW_LDS_BYTES, ctx.stream, gg);
+    else if (abl == 2) hipLaunchKernelGGL(gemm_x3_wide_kernel<2>, grid, dim3(512), XW_LDS_BYTES, ctx.stream, gg);
+    else if (abl == 3) hipLaunchKernelGGL(gemm_x3_wide_kernel<3>, grid, dim3(512), XW_LDS_BYTES, ctx.stream, gg);
+    else hipLaunchKernelGGL(gemm_x3_wide_kernel<0>, grid, dim3(512), XW_LDS_BYTES, ctx.stream, gg);
     WLK_HIP(hipGetLastError());
 }
 
