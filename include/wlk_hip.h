@@ -397,6 +397,10 @@ int wlk_diag_linear_x3(const float* a, const float* w, const float* bias, int m,
                        int scale_cols, float* c);
 int wlk_diag_linear_x3_time(int m, int n, int k, int flags, int reps, float* us_per_launch);
 int wlk_diag_layernorm_x3(const float* x, const float* gamma, const float* beta, int rows, int d, float* y);
+/* encoder self-attention through the X3 path (csrc/attention_x3.hip; same contract as wlk_diag_encoder_attention) and
+ * its timing probe */
+int wlk_diag_encoder_attention_x3(const float* qkv, int t, int d, int n_head, float* out);
+int wlk_diag_encoder_attention_x3_time(int t, int d, int n_head, int reps, float* us_per_launch);
 
 #ifdef __cplusplus
 }

@@ -63,3 +63,29 @@ def test_x3_layernorm_round_trip_is_the_fp32_layernorm():
         assert lib.wlk_diag_layernorm(vp(x), vp(g), vp(b), rows, d, vp(y)) == 0
         assert lib.wlk_diag_layernorm_x3(vp(x), vp(g), vp(b), rows, d, vp(y3)) == 0, lib.wlk_diag_last_error()
         assert np.array_equal(y.view(np.uint32), y3.view(np.uint32)), (rows, d, np.abs(y - y3).max())
+
+
+@pytest.mark.parametrize("T,d,H", [(1500, 512, 8), (1500, 384, 6), (200, 128, 2), (1500, 1280, 20)])
+def test_x3_encoder_attention_matches_float64_like_the_fp32_kernel(T, d, H):
+    """softmax(Q K^T) V per 64-wide head through the bf16 matrix cores (three planes per operand, fp32 softmax): against a
+    float64 reference the output must be as close as the fp32-MFMA attention kernel's."""
+    lib = _lib.load()
+    rng = np.random.default_rng(T + d)
+    qkv = rng.standard_normal((T, 3 * d)).astype(np.float32)
+    qkv[:, :2 * d] *= 0.6                                   # pre-scaled q and k: scores of a few units, as in the model
+    qkv[:, 2 * d + 3] += 5.0
+    q = qkv[:, :d].astype(np.float64).reshape(T, H, 64).transpose(1, 0, 2)
+    k = qkv[:, d:2 * d].astype(np.float64).reshape(T, H, 64).transpose(1, 0, 2)
+    v = qkv[:, 2 * d:].astype(np.float64).reshape(T, H, 64).transpose(1, 0, 2)
+    s = q @ k.transpose(0, 2, 1)
+    s -= s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    ref = (p @ v).transpose(1, 0, 2).reshape(T, d)
+    o3 = np.empty((T, d), np.float32)
+    o32 = np.empty((T, d), np.float32)
+    assert lib.wlk_diag_encoder_attention_x3(vp(qkv), T, d, H, vp(o3)) == 0, lib.wlk_diag_last_error()
+    assert lib.wlk_diag_encoder_attention(vp(qkv), T, d, H, vp(o32)) == 0, lib.wlk_diag_last_error()
+    e3, e32 = _err(o3, ref), _err(o32, ref)
+    print(f"T{T} d{d}: x3 max/mean {e3[0]:.2e} {e3[1]:.2e} | fp32 mfma {e32[0]:.2e} {e32[1]:.2e}")
+    assert e3[1] <= 2.0 * e32[1] + 1e-7 and e3[0] <= 3.0 * e32[0] + 1e-6, (e3, e32)

@@ -185,6 +185,8 @@ def _declare(lib: C.CDLL) -> None:
         "wlk_diag_linear_x3": (cint, [p, p, p, cint, cint, cint, cint, C.c_float, cint, p]),
         "wlk_diag_linear_x3_time": (cint, [cint, cint, cint, cint, cint, C.POINTER(C.c_float)]),
         "wlk_diag_layernorm_x3": (cint, [p, p, p, cint, cint, p]),
+        "wlk_diag_encoder_attention_x3": (cint, [p, cint, cint, cint, p]),
+        "wlk_diag_encoder_attention_x3_time": (cint, [cint, cint, cint, cint, C.POINTER(C.c_float)]),
     }
     for name, (res, args) in sig.items():
         try:
@@ -222,6 +224,7 @@ EXPORTED_SYMBOLS = (
     "wlk_diag_last_error", "wlk_diag_linear", "wlk_diag_linear_time", "wlk_diag_linear_ln", "wlk_diag_layernorm",
     "wlk_diag_encoder_attention", "wlk_diag_encoder_attention_time", "wlk_diag_wave_ops",
     "wlk_diag_linear_x3", "wlk_diag_linear_x3_time", "wlk_diag_layernorm_x3",
+    "wlk_diag_encoder_attention_x3", "wlk_diag_encoder_attention_x3_time",
 )
 
 

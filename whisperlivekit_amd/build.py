@@ -10,7 +10,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwlk_hip.so")
-SOURCES = ["api.hip", "gemm_f32.hip", "gemm_x3.hip", "layernorm.hip", "mel.hip", "attention.hip", "decoder.hip", "select.hip", "diag.hip", "melspec.hip",
+SOURCES = ["api.hip", "gemm_f32.hip", "gemm_x3.hip", "layernorm.hip", "mel.hip", "attention.hip", "attention_x3.hip", "decoder.hip", "select.hip", "diag.hip", "melspec.hip",
            "sortformer.hip", "sortformer_api.hip", "vad.hip", "loop.hip", "engine.hip", "dtw.hip", "word_align.hip", "nllb.hip"]
 # -amdgpu-kernarg-preload-count: leading scalar kernel arguments arrive in SGPRs at wave start (gfx950 firmware preloads
 # them; the compiler keeps a fallback prologue) instead of behind an s_load round trip - the decode-step kernels are

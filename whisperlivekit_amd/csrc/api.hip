@@ -426,6 +426,7 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         s->emlp = dev_alloc<float>(T * 4 * d);
         s->enc_out = dev_alloc<float>(T * d);
         s->eh3 = dev_alloc<unsigned short>(T * 3 * d);
+        s->eqkv3 = dev_alloc_zero<unsigned short>(x3_attn_image_elems((int)T, (int)d), st);
         s->enc_out3 = dev_alloc<unsigned short>(T * 3 * d);
         s->cross_kv = dev_alloc<float>((size_t)D.n_text_layer * T * 2 * d);
 
@@ -510,6 +511,7 @@ int wlk_session_destroy(wlk_session* s) {
     if (s->topk_scratch) (void)hipFree(s->topk_scratch);
     if (s->pcm16_dev) (void)hipFree(s->pcm16_dev);
     if (s->eh3) (void)hipFree(s->eh3);
+    if (s->eqkv3) (void)hipFree(s->eqkv3);
     if (s->enc_out3) (void)hipFree(s->enc_out3);
     if (s->wa_buf) (void)hipFree(s->wa_buf);
     if (s->esplit) (void)hipFree(s->esplit);
@@ -808,6 +810,11 @@ extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const
                                      [](wlk_session* s) { return s->eqkv; }, none);
     const PtrTable z_eh3_mlp = table([](wlk_session* s) { return reinterpret_cast<const float*>(s->eh3); },
                                      [](wlk_session* s) { return s->emlp; }, none);
+    const PtrTable z_eh3_qkv3 = table([](wlk_session* s) { return reinterpret_cast<const float*>(s->eh3); },
+                                      [](wlk_session* s) { return reinterpret_cast<float*>(s->eqkv3); }, none);
+    const PtrTable z_qkv3_att = table([](wlk_session* s) { return reinterpret_cast<const float*>(s->eqkv3); },
+                                      [](wlk_session* s) { return s->eatt; }, none);
+    const bool attn_x3 = enc_attention_x3_enabled() && d == D.n_audio_head * 64 && T >= 64 && (2 * d) % 128 == 0;
     auto gemm_x3 = [&](const GemmArgs& g, const unsigned short* w3, const PtrTable& z, const char* tag) {
         X3GemmArgs x;
         x.lda = g.lda; x.W3 = w3; x.bias = g.bias; x.ldc = g.ldc; x.ldr = g.ldr; x.M = g.M; x.N = g.N; x.K = g.K;
@@ -821,14 +828,27 @@ extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const
         GemmArgs g;
         g.lda = d; g.W = L.qkvw; g.bias = L.qkvb; g.ldc = 3 * d; g.M = T; g.N = 3 * d;
         g.K = d; g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = 2 * d;
-        if (L.qkvw3) {
+        if (L.qkvw3 && attn_x3) {
+            // q | k | v leave the projection as the X3 operand image of the bf16-MFMA attention (V transposed, keys in the
+            // order a lane of that kernel holds its probabilities): no fp32 qkv is written at all
             launch_layernorm_x3_batched(c, z_ex_eh3, B, d, L.ln1w, L.ln1b, d, T, d, "enc_ln1");
-            gemm_x3(g, L.qkvw3, z_eh3_qkv, "enc_qkv_x3");
+            X3GemmArgs x;
+            x.lda = d; x.W3 = L.qkvw3; x.bias = g.bias; x.M = T; x.N = 3 * d; x.K = d; x.flags = g.flags; x.scale = g.scale;
+            x.scale_cols = g.scale_cols; x.batch = B; x.z = z_eh3_qkv3;
+            x.x3_out = true; x.ldc3 = 2 * d; x.vt_col0 = 2 * d; x.vt_off = x3_attn_vt_off(T, d); x.vt_ld = x3_attn_vt_ld(T);
+            launch_gemm_x3(c, x, "enc_qkv_x3");
+            launch_encoder_attention_x3(c, nullptr, 2L * d, x3_attn_vt_off(T, d), x3_attn_vt_ld(T), nullptr, d, T, d, D.n_audio_head,
+                                        &z_qkv3_att, B);
         } else {
-            launch_layernorm_batched(c, z_ex_eh, B, d, L.ln1w, L.ln1b, d, T, d, "enc_ln1");
-            gemm(g, z_eh_qkv, "enc_qkv");
+            if (L.qkvw3) {
+                launch_layernorm_x3_batched(c, z_ex_eh3, B, d, L.ln1w, L.ln1b, d, T, d, "enc_ln1");
+                gemm_x3(g, L.qkvw3, z_eh3_qkv, "enc_qkv_x3");
+            } else {
+                launch_layernorm_batched(c, z_ex_eh, B, d, L.ln1w, L.ln1b, d, T, d, "enc_ln1");
+                gemm(g, z_eh_qkv, "enc_qkv");
+            }
+            launch_encoder_attention_batched(c, z_qkv_att, B, T, d, D.n_audio_head);
         }
-        launch_encoder_attention_batched(c, z_qkv_att, B, T, d, D.n_audio_head);
         GemmArgs o;
         o.lda = d; o.W = L.outw; o.bias = L.outb; o.ldc = d; o.M = T; o.N = d; o.K = d;
         o.flags = kGemmResidual; o.ldr = d;

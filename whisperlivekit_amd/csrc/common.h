@@ -242,6 +242,17 @@ struct X3GemmArgs {
     int scale_period = 0;
     int batch = 0;                        // > 0: grid.y = batch; A3 = z.in[i] (X3), C = z.out[i], R = z.res[i]
     int map_mode = 0;                     // probe only (WLK_X3_MAP): 1 = plain tile order, 2 = 2 x 4 bands
+    // Result in the X3 format instead of fp32 (the operands of enc_attention_x3_kernel): columns [0, vt_col0) as X3 rows
+    // (row m at C3 + m * 3 * ldc3), columns [vt_col0, N) TRANSPOSED - column n is row n - vt_col0 of a [N - vt_col0][vt_ld]
+    // X3 matrix at C3 + vt_off whose chunks run along m, with the keys of every 16-row group stored in the order
+    // 0-3, 8-11, 4-7, 12-15 (the order in which a lane of the attention kernel holds its probabilities).  Batched:
+    // C3 = z.out[i] reinterpreted; the fp32 C is not written in this mode.
+    unsigned short* C3 = nullptr;
+    long ldc3 = 0;
+    int vt_col0 = 0;
+    long vt_off = 0;                      // in bf16 units, from C3
+    long vt_ld = 0;                       // fp32-element units (multiple of 16, >= M)
+    bool x3_out = false;
     PtrTable z;
 };
 bool gemm_x3_wide_applicable(int M, int N, int K, long lda);
@@ -250,6 +261,16 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag);
 void launch_x3_pack(const LaunchCtx& ctx, const float* src, long ld_src, unsigned short* dst, long ld_dst, int rows, int cols);
 // X3 [rows][3 * ld_src] -> fp32 [rows][ld_dst]: (hi + mid) + lo, the exact fp32 value the planes were split from
 void launch_x3_unpack(const LaunchCtx& ctx, const unsigned short* src, long ld_src, float* dst, long ld_dst, int rows, int cols);
+
+// ---- attention_x3.hip: encoder self-attention on the bf16 matrix cores at fp32 accuracy ---------------------------
+// operand image of T rows of a d-wide model: [T][2 d] X3 rows (q | k) followed by V^T as [d][vt_ld] X3 rows
+inline long x3_attn_vt_ld(int T) { return ((long)T + 31) / 32 * 32; }
+inline long x3_attn_vt_off(int T, int d) { return (long)T * 3 * 2 * d; }                       // bf16 units
+inline size_t x3_attn_image_elems(int T, int d) { return (size_t)x3_attn_vt_off(T, d) + (size_t)d * 3 * x3_attn_vt_ld(T); }
+bool enc_attention_x3_enabled();
+void launch_encoder_attention_x3(const LaunchCtx& ctx, const unsigned short* qk3, long ldqk, long vt_off, long vt_ld, float* out,
+                                 long ldo, int T, int d, int n_head, const PtrTable* z, int batch);
+void launch_x3_pack_qkv(const LaunchCtx& ctx, const float* qkv, unsigned short* out, int T, int d, long vt_off, long vt_ld);
 
 // ---- layernorm.hip --------------------------------------------------------------------------
 void launch_layernorm(const LaunchCtx& ctx, const float* x, long ldx, const float* gamma, const float* beta,

@@ -391,4 +391,54 @@ int wlk_diag_layernorm_x3(const float* x, const float* gamma, const float* beta,
     });
 }
 
+/* encoder self-attention through the X3 path (attention_x3.hip): qkv [t, 3d] (q and k pre-scaled) is packed into the
+ * operand image on the device, out [t, d] comes back; compare with wlk_diag_encoder_attention */
+int wlk_diag_encoder_attention_x3(const float* qkv, int t, int d, int n_head, float* out) {
+    return run([&]() {
+        DevBuf Q((size_t)t * 3 * d, qkv), O((size_t)t * d);
+        unsigned short* img = nullptr;
+        const size_t n = x3_attn_image_elems(t, d);
+        WLK_HIP(hipMalloc(reinterpret_cast<void**>(&img), n * sizeof(unsigned short)));
+        LaunchCtx ctx;
+        launch_x3_pack_qkv(ctx, Q.p, img, t, d, x3_attn_vt_off(t, d), x3_attn_vt_ld(t));
+        launch_encoder_attention_x3(ctx, img, 2L * d, x3_attn_vt_off(t, d), x3_attn_vt_ld(t), O.p, d, t, d, n_head, nullptr, 0);
+        WLK_HIP(hipDeviceSynchronize());
+        WLK_HIP(hipMemcpy(out, O.p, (size_t)t * d * sizeof(float), hipMemcpyDeviceToHost));
+        (void)hipFree(img);
+    });
+}
+
+/* timing probe of the same: average microseconds per launch */
+int wlk_diag_encoder_attention_x3_time(int t, int d, int n_head, int reps, float* us_per_launch) {
+    return run([&]() {
+        std::vector<float> h((size_t)t * 3 * d);
+        unsigned seed = 777u;
+        for (auto& v : h) { seed = seed * 1664525u + 1013904223u; v = (((seed >> 8) & 0xffff) / 65536.0f - 0.5f) * 1.5f; }
+        DevBuf Q((size_t)t * 3 * d, h.data()), O((size_t)t * d);
+        unsigned short* img = nullptr;
+        WLK_HIP(hipMalloc(reinterpret_cast<void**>(&img), x3_attn_image_elems(t, d) * sizeof(unsigned short)));
+        hipStream_t st;
+        WLK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        LaunchCtx ctx{st, nullptr};
+        launch_x3_pack_qkv(ctx, Q.p, img, t, d, x3_attn_vt_off(t, d), x3_attn_vt_ld(t));
+        auto go = [&]() { launch_encoder_attention_x3(ctx, img, 2L * d, x3_attn_vt_off(t, d), x3_attn_vt_ld(t), O.p, d, t, d, n_head, nullptr, 0); };
+        go();
+        WLK_HIP(hipStreamSynchronize(st));
+        hipEvent_t e0, e1;
+        WLK_HIP(hipEventCreate(&e0));
+        WLK_HIP(hipEventCreate(&e1));
+        WLK_HIP(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) go();
+        WLK_HIP(hipEventRecord(e1, st));
+        WLK_HIP(hipStreamSynchronize(st));
+        float ms = 0.f;
+        WLK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *us_per_launch = 1e3f * ms / (float)reps;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipStreamDestroy(st);
+        (void)hipFree(img);
+    });
+}
+
 }  // extern "C"

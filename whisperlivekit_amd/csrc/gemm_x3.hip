@@ -197,6 +197,7 @@ __global__ __launch_bounds__(512) void gemm_x3_wide_kernel(X3GemmArgs g) {
             __builtin_amdgcn_s_barrier();
         }
         xw_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();          // nothing of this loader is in flight any more: the ring may be reused (epilogue staging)
         return;
     }
 
@@ -252,6 +253,54 @@ __global__ __launch_bounds__(512) void gemm_x3_wide_kernel(X3GemmArgs g) {
         xw_wait_frags(g0);
     }
 
+    __builtin_amdgcn_s_barrier();              // the loaders' tail fetches have landed
+    if (g.x3_out) {
+        // ---- result in the X3 format: the tile goes through LDS (the ring is free) so that 8 consecutive columns - or, for
+        // the transposed part, 8 rows in the attention kernel's key order - meet in one thread, which splits them into the
+        // three planes and writes the chunk's 48 contiguous bytes
+        constexpr int PITCH = XW_BN + 4;
+        float* stage = reinterpret_cast<float*>(lds);
+        const bool do_scale = (g.flags & kGemmScaleCols) && (g.scale_period ? col % g.scale_period : col) < g.scale_cols;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float v = acc[i][q] + bias;
+                if (do_scale) v *= g.scale;
+                stage[(32 * i + (q & 3) + 8 * (q >> 2) + 4 * hi) * PITCH + 32 * wave + (lane & 31)] = v;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        unsigned short* const c3 = batched ? reinterpret_cast<unsigned short*>(table_at(g.z.out, blockIdx.y)) : g.C3;
+        const int tid = threadIdx.x;           // 0 .. 255: the compute waves
+        if (n0 < g.vt_col0) {                  // (tiles do not straddle vt_col0: it is a multiple of the tile width)
+            for (int item = tid; item < XW_BM * (XW_BN / 8); item += 256) {
+                const int row = item >> 4, c = item & 15;
+                if (m0 + row < g.M && n0 + 8 * c < g.N) {
+                    const float4 a = *reinterpret_cast<const float4*>(stage + row * PITCH + 8 * c);
+                    const float4 b = *reinterpret_cast<const float4*>(stage + row * PITCH + 8 * c + 4);
+                    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                    x3_store_chunk(c3 + (long)(m0 + row) * 3 * g.ldc3 + (long)((n0 >> 3) + c) * 24, v);
+                }
+            }
+        } else {
+            unsigned short* const vt = c3 + g.vt_off;
+            for (int item = tid; item < XW_BN * (XW_BM / 8); item += 256) {
+                const int dcol = item / (XW_BM / 8), u = item - dcol * (XW_BM / 8);
+                const int r0 = 16 * (u >> 1) + 4 * (u & 1);     // rows r0 .. r0 + 3 and r0 + 8 .. r0 + 11
+                if (n0 + dcol < g.N && m0 + r0 < g.vt_ld) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int row = r0 + (e & 3) + 8 * (e >> 2);
+                        v[e] = m0 + row < g.M ? stage[row * PITCH + dcol] : 0.f;
+                    }
+                    x3_store_chunk(vt + (long)(n0 + dcol - g.vt_col0) * 3 * g.vt_ld + (long)((m0 >> 3) + u) * 24, v);
+                }
+            }
+        }
+        return;
+    }
     // epilogue: acc[i][q] is C[row = 32 i + (q & 3) + 8 (q >> 2) + 4 (lane >> 5)][col] of the tile
     if (col < g.N) {
         const bool do_scale = (g.flags & kGemmScaleCols) && (g.scale_period ? col % g.scale_period : col) < g.scale_cols;
@@ -290,6 +339,9 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
     if (g.M <= 0 || g.N <= 0) return;
     if (g.K % 32 != 0 || g.lda % 8 != 0 || g.K < 64) throw std::invalid_argument("x3 gemm: K must be a multiple of 32 (>= 64), lda of 8");
     if (g.flags & ~(kGemmGelu | kGemmResidual | kGemmScaleCols)) throw std::invalid_argument("x3 gemm: unsupported epilogue flag");
+    if (g.x3_out && ((g.flags & (kGemmGelu | kGemmResidual)) || g.vt_col0 % XW_BN != 0 || g.ldc3 % 8 != 0 || g.vt_ld % 16 != 0 ||
+                     g.vt_ld < g.M))
+        throw std::invalid_argument("x3 gemm: unsupported X3 result layout");
     static std::atomic<uint64_t> configured{0};
     int dev = 0;
     WLK_HIP(hipGetDevice(&dev));

@@ -198,6 +198,9 @@ struct wlk_session {
     // replaces enc_out when the cross-attention K|V projection takes that path (wlk_export("enc") unpacks it)
     unsigned short *eh3 = nullptr, *enc_out3 = nullptr;
     bool enc_out_is_x3 = false;
+    // operand image of the X3 encoder attention (attention_x3.hip): q | k as X3 rows, V^T behind them; written by the qkv
+    // projection's epilogue.  Zero-initialised once: the padding keys of V^T are never written and must stay finite.
+    unsigned short* eqkv3 = nullptr;
     bool encoded = false;
     int content_len = 0;
 
