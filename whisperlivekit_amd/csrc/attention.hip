@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "wave_ops.h"
 
 namespace wlk {
 
@@ -66,16 +67,6 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
     const int half = lane >> 5;
     const int lq = lane & 31;
 
-    // Q tile -> LDS once ([32][K_LD], same padded layout as the K tiles); the B fragments are
-    // re-read per key tile (one ds_read_b128 per 4 MFMAs - the 64-cycle fp32 MFMA leaves the LDS idle)
-    float* Qs = lds + kAttnLdsFloats;
-    for (int i = tid; i < QT * 16; i += 256) {
-        const int qr = i >> 4, c4 = i & 15;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q0 + qr < a.Tq) v = *reinterpret_cast<const float4*>(aq + (long)(q0 + qr) * a.ldq + head * 64 + c4 * 4);
-        *reinterpret_cast<float4*>(&Qs[qr * K_LD + c4 * 4]) = v;
-    }
-    const float* Qw = Qs + lq * K_LD + half * 4;
 
     f32x16 o0, o1;
 #pragma unroll
@@ -84,17 +75,12 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
 
     // staging map: per iteration 128 keys x 64 floats for K and for V = 2048 float4 each, 8 per thread
     // stacked prefills: this query tile's session supplies the keys / values and the alignment window
-    const float* const tk = a.tile_rows ? a.tile_rows[qt_idx].cross_kv + a.tile_kv_off : ak;
-    const float* kbase = tk + head * 64;
-    const float* vbase = (a.tile_rows ? tk + a.tile_v_off : av) + head * 64;
-    // alignment-head score dump (decoder prefill only)
-    const int rank = a.head_rank ? a.head_rank[head] : -1;
-    float* dump = nullptr;
-    if (rank >= 0 && q0 + lq < a.Tq) {
-        const int row = q0 + lq;
-        if (a.tile_rows) dump = a.tile_rows[qt_idx].ring + ((long)rank * a.ring_rows + a.ring_row[row]) * (long)T;
-        else dump = a.ring + (((long)rank * a.n_beam + a.beam_of_row[row]) * a.ring_rows + a.ring_row[row]) * (long)T;
-    }
+    // (round 4: global address space kept explicit - a pointer loaded from the tile table made these flat loads; no
+    // select on the loaded VALUES - hipcc turned `ok ? k4 : 0` into one predicated branch per load with waits in between:
+    // rows past T are fetched from row 0 instead, their scores are set to -inf below and their probabilities are 0)
+    const gcf_ptr tk = to_global(a.tile_rows ? a.tile_rows[qt_idx].cross_kv + a.tile_kv_off : ak);
+    const gcf_ptr kbase = tk + head * 64;
+    const gcf_ptr vbase = (a.tile_rows ? tk + a.tile_v_off : to_global(av)) + head * 64;
     float4 rk[8], rv[8];
     auto fetch = [&](int it) {
 #pragma unroll
@@ -102,14 +88,52 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
             const int idx = tid + 256 * i;
             const int key = it * (NWAVE * KT) + (idx >> 4);
             const int c4 = idx & 15;
-            const bool ok = key < T;
-            const long off = (long)(ok ? key : 0) * ld + c4 * 4;   // branch-free: keeps rk/rv in registers
-            const float4 k4 = *reinterpret_cast<const float4*>(kbase + off);
-            const float4 v4 = *reinterpret_cast<const float4*>(vbase + off);
-            rk[i] = ok ? k4 : make_float4(0.f, 0.f, 0.f, 0.f);
-            rv[i] = ok ? v4 : make_float4(0.f, 0.f, 0.f, 0.f);
+            const long off = (long)(key < T ? key : 0) * ld + c4 * 4;
+            rk[i] = ldg4(kbase + off);
+            rv[i] = ldg4(vbase + off);
         }
     };
+    // key range of this workgroup: iterations [it_lo, it_hi) of 128 keys each
+    const int n_iter_all = (T + NWAVE * KT - 1) / (NWAVE * KT);
+    const int it_per = (n_iter_all + a.k_splits - 1) / a.k_splits;
+    const int it_lo = ks * it_per;
+    const int n_iter = min(n_iter_all, it_lo + it_per);
+    fetch(it_lo);     // in flight while the Q tile is staged and the alignment-head bookkeeping below resolves
+    // alignment-window bookkeeping of this lane's query row: requested together with the tiles (each used to be its own
+    // memory round trip in front of the first key tile)
+    // (unconditional loads from pointers that are always readable - an absent table points at the queries - and pinned
+    // behind the Q staging: a load inside a branch, or one hipcc can sink into one, costs its own wait)
+    const int bk_row = min(q0 + lq, a.Tq - 1);
+    const int* const any_ints = reinterpret_cast<const int*>(aq);
+    int rank_raw = (a.head_rank ? a.head_rank + head : any_ints)[0];
+    int ring_row_v = (a.ring_row ? a.ring_row + bk_row : any_ints)[0];
+    int beam_v = (a.beam_of_row ? a.beam_of_row + bk_row : any_ints)[0];
+    // Q tile -> LDS once ([32][K_LD], same padded layout as the K tiles); the B fragments are
+    // re-read per key tile (one ds_read_b128 per 4 MFMAs - the 64-cycle fp32 MFMA leaves the LDS idle)
+    float* Qs = lds + kAttnLdsFloats;
+    static_assert(QT * 16 == 2 * 256, "two float4 of the Q tile per thread");
+    {
+        float4 qv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + 256 * j, qr = i >> 4, c4 = i & 15;
+            qv[j] = *reinterpret_cast<const float4*>(aq + (long)min(q0 + qr, a.Tq - 1) * a.ldq + head * 64 + c4 * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + 256 * j, qr = i >> 4, c4 = i & 15;
+            *reinterpret_cast<float4*>(&Qs[qr * K_LD + c4 * 4]) = q0 + qr < a.Tq ? qv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float* Qw = Qs + lq * K_LD + half * 4;
+    asm volatile("" : "+v"(rank_raw), "+v"(ring_row_v), "+v"(beam_v));
+    const int rank = a.head_rank ? rank_raw : -1;
+    // alignment-head score dump (decoder prefill only): pointer resolved from the values requested above
+    float* dump = nullptr;
+    if (rank >= 0 && q0 + lq < a.Tq) {
+        if (a.tile_rows) dump = a.tile_rows[qt_idx].ring + ((long)rank * a.ring_rows + ring_row_v) * (long)T;
+        else dump = a.ring + (((long)rank * a.n_beam + beam_v) * a.ring_rows + ring_row_v) * (long)T;
+    }
     auto stash = [&]() {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -121,12 +145,6 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(FlashArgs a) {
         }
     };
 
-    // key range of this workgroup: iterations [it_lo, it_hi) of 128 keys each
-    const int n_iter_all = (T + NWAVE * KT - 1) / (NWAVE * KT);
-    const int it_per = (n_iter_all + a.k_splits - 1) / a.k_splits;
-    const int it_lo = ks * it_per;
-    const int n_iter = min(n_iter_all, it_lo + it_per);
-    fetch(it_lo);
     const float* Kw = Ks + wave * (KT * K_LD) + lq * K_LD + half * 4;
     const float* Vw = Vs + wave * (KT * 64) + lq;
 

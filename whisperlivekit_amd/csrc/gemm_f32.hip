@@ -370,6 +370,144 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kwave_kernel(GemmArgs g) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// The decoder prefill (M ~ 60 prompt rows) on 16 x 16 tiles: the k-wave kernel above, with v_mfma_f32_16x16x4_f32.
+// A 32 x 32 tile per workgroup leaves a 60 x 512 projection on 32 of 256 compute units, each streaming 32 weight rows
+// and running 16 dependent 64-cycle MFMAs per wave and slab (11 us per launch, 32 launches per prefill); 16 x 16 tiles
+// are 128 workgroups that each stream 16 weight rows and run 8 MFMAs of 32 cycles per wave and slab.
+// Every wave feeds the k values of its quarter in the order the 32 x 32 x 2 sequence accumulates them (k-group s: 8s,
+// 8s+4, 8s+1, 8s+5 | 8s+2, 8s+6, 8s+3, 8s+7), and the four partials are folded in wave order as above.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_nt_f32_kwave16_kernel(GemmArgs g) {
+    WLK_PIN_GEMM_ARGS(g);
+    constexpr int KW = 4, SLAB = BK * KW, SUB = 16 * LDS_LD;
+    __shared__ __attribute__((aligned(16))) float As[2][KW * SUB];
+    __shared__ __attribute__((aligned(16))) float Ws[2][KW * SUB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (g.N + 15) / 16;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * 16, n0 = tile_n * 16;
+
+    constexpr unsigned kOob = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.A), 0, (int)((((long)g.M - 1) * g.lda + g.K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.W), 0, (int)((long)g.N * g.K * 4), 0x00020000);
+    // a slab row is 32 float4 (512 contiguous bytes); thread t moves float4 (t & 31) of rows (t >> 5) + 8 i, i = 0, 1
+    unsigned a_byte[2], w_byte[2];
+    int lds_at[2];
+    const int c4 = tid & 31, kcol = c4 * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 5) + 8 * i;
+        a_byte[i] = (m0 + row) < g.M ? (unsigned)(((long)(m0 + row) * g.lda + kcol) * 4) : kOob;
+        w_byte[i] = (n0 + row) < g.N ? (unsigned)(((long)(n0 + row) * g.K + kcol) * 4) : kOob;
+        lds_at[i] = (c4 >> 3) * SUB + row * LDS_LD + (c4 & 7) * 4;
+    }
+    struct Slab {
+        float4 a[2], w[2];
+    };
+    auto fetch = [&](Slab& st, int ks) {
+        const int k0 = ks * SLAB;
+        const bool in = (k0 + kcol) < g.K;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)(in ? a_byte[i] + (unsigned)k0 * 4u : kOob), 0, 0);
+            st.a[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)(in ? w_byte[i] + (unsigned)k0 * 4u : kOob), 0, 0);
+            st.w[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+    };
+    auto stash = [&](const Slab& st, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&As[buf][lds_at[i]]) = st.a[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&Ws[buf][lds_at[i]]) = st.w[i];
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // lane (row / column = lane & 15, k-slot g4 = lane >> 4): of k-group s it supplies k = 8s + 4 (g4 & 1) + (g4 >> 1) to the
+    // first MFMA and that + 2 to the second - elements (g4 >> 1) and (g4 >> 1) + 2 of the float4 at 8s + 4 (g4 & 1)
+    const int g4 = lane >> 4;
+    const int frag = wave * SUB + (lane & 15) * LDS_LD + (g4 & 1) * 4;
+    const bool odd = (g4 >> 1) != 0;
+    auto mma = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][frag + s * 8]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&Ws[buf][frag + s * 8]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(odd ? a4.y : a4.x, odd ? b4.y : b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(odd ? a4.w : a4.z, odd ? b4.w : b4.z, acc, 0, 0, 0);
+        }
+    };
+    const int ns = (g.K + SLAB - 1) / SLAB, ns2 = (ns + 1) & ~1;
+    Slab s0, s1;
+    fetch(s0, 0);
+    fetch(s1, 1);
+    stash(s0, 0);
+    __syncthreads();
+    for (int ks = 0; ks < ns2; ks += 2) {
+        fetch(s0, ks + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0);
+        stash(s1, 1);
+        __syncthreads();
+        fetch(s1, ks + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1);
+        stash(s0, 0);
+        __syncthreads();
+    }
+    // fold the four k-partials in wave order
+    float* red = &As[0][0];
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave - 1) * 4 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < KW - 1; ++w)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += red[(w * 4 + r) * 64 + lane];
+
+    // acc[r] is C[row = 4 (lane >> 4) + r][col = lane & 15] of the tile
+    const int col = n0 + (lane & 15);
+    if (col >= g.N) return;
+    const float b = g.bias ? g.bias[col] : 0.f;
+    const bool do_scale = (g.flags & kGemmScaleCols) && (g.scale_period ? col % g.scale_period : col) < g.scale_cols;
+    const int row_base = m0 + 4 * g4;
+    float* kv_dst = nullptr;
+    int kv_col = 0, kv_off = 0;
+    if (g.kcache && col >= g.kv_d) {
+        kv_dst = col < 2 * g.kv_d ? g.kcache : g.vcache;
+        kv_col = col < 2 * g.kv_d ? col - g.kv_d : col - 2 * g.kv_d;
+        kv_off = *g.kv_pos;
+    }
+    float res[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) res[r] = (g.flags & kGemmResidual) ? g.R[(long)min(row_base + r, g.M - 1) * g.ldr + col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = row_base + r;
+        float v = acc[r] + b;
+        if (do_scale) v *= g.scale;
+        if (g.flags & kGemmGelu) v = gelu_erf(v);
+        if (g.flags & kGemmRelu) v = fmaxf(v, 0.f);
+        if (g.flags & kGemmSwish) v = v / (1.0f + expf(-v));
+        v += res[r];
+        if (row < g.M) {
+            g.C[(long)row * g.ldc + col] = v;
+            if (kv_dst) {
+                const int bm = row / g.kv_ntok, t = row - bm * g.kv_ntok;
+                kv_dst[((long)bm * g.kv_ctx + kv_off + t) * g.kv_d + kv_col] = v;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Encoder-sized problems (M ~ 1500 rows, N = d .. 12d): the "one tile per compute unit" kernel.
 //
 // What the 64x64 kernel above loses on these shapes is not arithmetic but quantisation and fixed cost: 1500 x 512
@@ -1033,7 +1171,17 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (g.kcache && !(gemm_takes_kwave(g.M, g.N, g.K) || want_kwave))
         throw std::invalid_argument("gemm: fused KV-cache append is only available on the k-wave path");
     if ((gemm_takes_kwave(g.M, g.N, g.K) && g.force_kernel != 3) || (want_kwave && g.K >= 256)) {
-        hipLaunchKernelGGL(gemm_nt_f32_kwave_kernel, dim3((unsigned)tiles32), dim3(256), 0, ctx.stream, g);
+        // prompt-sized row counts (decoder prefill): 16 x 16 tiles - four times the workgroups, a quarter of the chain each
+        static const bool kwave16 = [] {
+            const char* e = getenv("WLK_KWAVE16");
+            return !(e && e[0] == '0');
+        }();
+        if (kwave16 && g.M <= 128 && g.force_kernel != 2) {
+            const long tiles16 = (long)((g.N + 15) / 16) * ((g.M + 15) / 16);
+            hipLaunchKernelGGL(gemm_nt_f32_kwave16_kernel, dim3((unsigned)tiles16), dim3(256), 0, ctx.stream, g);
+        } else {
+            hipLaunchKernelGGL(gemm_nt_f32_kwave_kernel, dim3((unsigned)tiles32), dim3(256), 0, ctx.stream, g);
+        }
     } else if (tiles64 >= 64) {
         const int tiles_m = (g.M + 63) / 64;
         const int blocks = tiles_m >= 8 ? 8 * ((tiles_m + 3) / 4) * ((tiles_n + 1) / 2) : tiles_m * tiles_n;
