@@ -520,22 +520,47 @@ __global__ __launch_bounds__(256) void cross_split_kernel(const float* __restric
     if constexpr (UB != 0) {
         // q_h = scale * (Wq[64 head + i, :] . LN(x_row) + b), i = 0..63: wave w derives i = 16 w .. 16 w + 15.  Statement for
         // statement gemv1_f32_kernel's arithmetic (fused LayerNorm statistics over lane-strided scalars, lane-strided
-        // float4 fmaf chains, xor-shuffle folds), which is also what every row of the multi-row GEMV computes.
+        // float4 fmaf chains, butterfly folds), which is also what every row of the multi-row GEMV computes.
+        // Round 4: the residual row, the LayerNorm affine, the biases and the first 32 / UB weight rows are requested
+        // together with the keys and values above - ONE memory round trip in front of the scores instead of the separate
+        // dec_lnx_xq launch (4 us) in front of this one.
         const int K = d, K4 = K >> 2;
         const float* xrow = a.xq_x + (long)row * K;
-        float4 x[UB];
+        constexpr int NPASS = 32 / UB;      // outputs whose weight rows are in flight together (32 float4 per lane)
+        float4 x[UB], ga[UB], be[UB];
+        float v[UB * 4];
+        float4 w[NPASS][UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int c = lane + 64 * u;
-            x[u] = *reinterpret_cast<const float4*>(xrow + (c < K4 ? c : 0) * 4);
+            const int cc = (c < K4 ? c : 0) * 4;
+            x[u] = *reinterpret_cast<const float4*>(xrow + cc);
+            ga[u] = *reinterpret_cast<const float4*>(a.xq_gamma + cc);
+            be[u] = *reinterpret_cast<const float4*>(a.xq_beta + cc);
         }
+#pragma unroll
+        for (int i = 0; i < UB * 4; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = xrow[c < K ? c : 0];
+        }
+        const float bias_l = (a.xq_b ? a.xq_b + head * 64 + wave * 16 + (lane & 15) : xrow)[0];   // output (lane & 15)'s bias
+        auto load_rows = [&](int i0) {
+#pragma unroll
+            for (int r = 0; r < NPASS; ++r) {
+                const int n = head * 64 + wave * 16 + i0 + r;
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int c = lane + 64 * u;
+                    w[r][u] = *reinterpret_cast<const float4*>(a.xq_w + (long)n * K + (c < K4 ? c : 0) * 4);
+                }
+            }
+        };
+        load_rows(0);
         {
-            float v[UB * 4];
             float sum = 0.f;
 #pragma unroll
             for (int i = 0; i < UB * 4; ++i) {
-                const int c = lane + 64 * i;
-                v[i] = c < K ? xrow[c] : 0.f;
+                v[i] = (lane + 64 * i) < K ? v[i] : 0.f;
                 sum += v[i];
             }
             sum = wave_sum(sum);
@@ -550,29 +575,15 @@ __global__ __launch_bounds__(256) void cross_split_kernel(const float* __restric
             const float rstd = 1.0f / sqrtf(sq / (float)K + 1e-5f);
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
-                const int c = lane + 64 * u;
-                const int cc = (c < K4 ? c : 0) * 4;
-                const float4 ga = *reinterpret_cast<const float4*>(a.xq_gamma + cc);
-                const float4 be = *reinterpret_cast<const float4*>(a.xq_beta + cc);
-                x[u].x = (x[u].x - mean) * rstd * ga.x + be.x;
-                x[u].y = (x[u].y - mean) * rstd * ga.y + be.y;
-                x[u].z = (x[u].z - mean) * rstd * ga.z + be.z;
-                x[u].w = (x[u].w - mean) * rstd * ga.w + be.w;
+                x[u].x = (x[u].x - mean) * rstd * ga[u].x + be[u].x;
+                x[u].y = (x[u].y - mean) * rstd * ga[u].y + be[u].y;
+                x[u].z = (x[u].z - mean) * rstd * ga[u].z + be[u].z;
+                x[u].w = (x[u].w - mean) * rstd * ga[u].w + be[u].w;
             }
         }
-        constexpr int NPASS = UB <= 2 ? 4 : (UB <= 4 ? 2 : 1);      // outputs whose weight rows are in flight together
 #pragma unroll
         for (int i0 = 0; i0 < 16; i0 += NPASS) {
-            float4 w[NPASS][UB];
-#pragma unroll
-            for (int r = 0; r < NPASS; ++r) {
-                const int n = head * 64 + wave * 16 + i0 + r;
-#pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    const int c = lane + 64 * u;
-                    w[r][u] = *reinterpret_cast<const float4*>(a.xq_w + (long)n * K + (c < K4 ? c : 0) * 4);
-                }
-            }
+            if (i0 > 0) load_rows(i0);
 #pragma unroll
             for (int r = 0; r < NPASS; ++r) {
                 float acc = 0.f;
@@ -586,12 +597,12 @@ __global__ __launch_bounds__(256) void cross_split_kernel(const float* __restric
                     }
                 }
                 acc = wave_sum(acc);
+                const float bias_r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bias_l), i0 + r));
                 if (lane == 0) {
-                    const int n = head * 64 + wave * 16 + i0 + r;
-                    float v = acc;
-                    if (a.xq_b) v += a.xq_b[n];
-                    v *= a.xq_scale;
-                    qs[wave * 16 + i0 + r] = v;
+                    float o = acc;
+                    if (a.xq_b) o += bias_r;
+                    o *= a.xq_scale;
+                    qs[wave * 16 + i0 + r] = o;
                 }
             }
         }
@@ -710,14 +721,16 @@ void launch_decoder_cross_attention_split(const LaunchCtx& ctx, const CrossAttnA
         WLK_HIP(hipGetLastError());
     }
 }
-// Opt-in (WLK_XQ_FOLD=1).  Measured on MI355X, base.en, alternating runs on one box (profiles/r03_ab_xq_fold.txt): with the
-// fold a stream runs 141.2 / 142.0 audio-s/s, without it 144.7 / 146.4 - the launch it saves (46 instead of 52 per
-// step) is cheaper than 64 workgroups each pulling their head's 128 KB of Wq through L2 in front of their keys.  All
-// golden streams are bit-identical either way (the fold reproduces the GEMV's arithmetic).
+// Round 3 measured this fold SLOWER than the separate dec_lnx_xq launch (141-142 vs 145-146 audio-s/s,
+// profiles/r03_ab_xq_fold.txt): the folded prologue was a chain of memory round trips (residual row -> LayerNorm
+// statistics -> affine -> four batches of weight rows) in front of the keys.  Round 4 requests all of it together with the
+// keys and values (one round trip), and a dependent launch now costs ~3.9 us of a 200 us step: default ON, WLK_XQ_FOLD=0
+// restores the separate launch (profiles/r04h_ab_xq_fold.txt).  All golden streams are bit-identical either way (the fold
+// reproduces the GEMV's arithmetic).
 bool cross_split_folds_query(int d) {
     static const bool on = [] {
         const char* e = getenv("WLK_XQ_FOLD");
-        return e && e[0] == '1';
+        return !(e && e[0] == '0');
     }();
     return on && d % 256 == 0 && d >= 256 && d <= 2048;
 }
