@@ -5,14 +5,15 @@
 //
 // Operands come straight from the qkv projection's epilogue (gemm_x3.hip, X3GemmArgs::x3_out):
 //   Q | K : X3 rows [T][2 d] (chunks run along the feature axis) - a lane's A / B fragment is one 16-byte unit;
-//   V^T   : X3 rows [d][T padded to 16] - chunks run along the KEY axis, keys of every 16-group stored 0-3, 8-11, 4-7,
-//           12-15: exactly the keys whose probabilities a lane holds after S^T = K Q^T, so the accumulator registers of
-//           step 1 are (after the split into planes) the B operand of step 2 without any data movement between lanes.
-// Workgroup = (head, 64 queries); eight waves: compute wave (qb, ks) owns queries 32 qb .. 32 qb + 31 and the key tiles
-// t = ks (mod 2) (flash-style online softmax per wave, the two key streams of a query block merged at the end), four
-// loader waves feed a ring of three slots of two 32-key tiles each (K tile 12 KiB + V^T tile 12 KiB per stream) by
-// LDS-DMA - the wide GEMM's schedule: one workgroup barrier per pair of tiles.  Per tile and wave: 24 MFMAs for S^T,
-// 24 for O^T += V^T P^T, a 16-value softmax per lane in between.
+//   V^T   : X3 rows [d][T padded to 32] - chunks run along the KEY axis; stored chunk u of every 32-key group holds keys
+//           4 u .. 4 u + 3 and 16 + 4 u .. 16 + 4 u + 3: exactly the keys whose probabilities a lane of group u holds
+//           after S^T = K Q^T, so the accumulator registers of step 1 are (after the split into planes) the B operand of
+//           step 2 without any data movement between lanes.
+// Workgroup = (head, 64 queries), eight waves, all of them computing: wave (qs, ks) owns queries 16 qs .. 16 qs + 15 and
+// the key tiles t = ks (mod 2) (flash-style online softmax per wave, the two key streams of a query block merged at the
+// end); every wave also issues a sixth of the LDS-DMA that feeds a ring of three slots of two 32-key tiles (K tile
+// 12 KiB + V^T tile 12 KiB per stream); one workgroup barrier per pair of tiles.  Per tile and wave: 24
+// v_mfma_f32_16x16x32_bf16 for S^T, 24 for O^T += V^T P^T, an 8-value softmax per lane in between.
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
@@ -24,7 +25,6 @@
 namespace wlk {
 
 namespace {
-typedef float af32x16 __attribute__((ext_vector_type(16)));
 typedef float af32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int AX_QT = 64, AX_KT = 32;
@@ -35,7 +35,7 @@ constexpr int AX_V_BYTES = 64 * AX_V_ROW;                  // 12 288
 constexpr int AX_TILE_BYTES = AX_K_BYTES + AX_V_BYTES;     // one stream's tile
 constexpr int AX_SLOT_BYTES = 2 * AX_TILE_BYTES;           // both streams: 49 152
 constexpr int AX_NB = 3, AX_DT = AX_NB - 1;
-constexpr int AX_NPW = AX_SLOT_BYTES / 1024 / 4;           // 12 DMA pieces per loader wave and slot
+constexpr int AX_NPW = AX_SLOT_BYTES / 1024 / 8;           // 6 DMA pieces per wave and slot
 constexpr size_t AX_LDS_BYTES = (size_t)AX_NB * AX_SLOT_BYTES;
 constexpr int AX_PA[6] = {2, 0, 1, 1, 0, 0}, AX_PB[6] = {0, 2, 1, 0, 1, 0};   // plane products, small terms first
 
@@ -64,6 +64,9 @@ __device__ __forceinline__ void ax_split8(const float (&v)[8], bf16x8 (&out)[3])
         out[2][e] = t.l;
     }
 }
+// key row (relative to the start of its 32-key group) of element e of stored chunk u of V^T: a lane of group u = lane >> 4
+// holds, after S^T = K Q^T with 16 x 16 MFMAs, the probabilities of keys 4 u .. 4 u + 3 and 16 + 4 u .. 16 + 4 u + 3
+__host__ __device__ inline int ax_vt_key(int u, int e) { return 4 * u + (e & 3) + 16 * (e >> 2); }
 }  // namespace
 
 struct AttnX3Args {
@@ -78,6 +81,14 @@ struct AttnX3Args {
     PtrTable z;                  // batched encodes: qk3 = z.in[i], out = z.out[i]
 };
 
+// Round 4, second version.  The first one had four compute waves (32 queries each, 32 x 32 MFMAs) beside four loader
+// waves: per key tile a compute wave ran its S MFMAs, ~220 VALU instructions of softmax / plane split and its P V MFMAs
+// strictly one after the other, so the matrix pipe of its SIMD idled through every softmax (47 us per launch against
+// 18 us of MFMA time).  Here ALL EIGHT waves compute: wave (qs, ks) owns 16 queries (v_mfma_f32_16x16x32_bf16: same flop
+// rate, half the accumulator and softmax work per wave) of key stream ks, the two waves of a SIMD belong to different
+// streams and cover each other's softmax and DMA issue (6 pieces per wave and step) with their MFMAs.
+// ABL (timing probe, WLK_X3_ATTN_ABL): 1 = DMA and barriers only, 2 = no DMA, 3 = MFMAs only (no softmax, no DMA)
+template <int ABL>
 __global__ __launch_bounds__(512) void enc_attention_x3_kernel(AttnX3Args a) {
     asm volatile("" ::"s"(a.qk3), "s"(a.ldqk), "s"(a.vt_off), "s"(a.vt_ld), "s"(a.out), "s"(a.ldo), "s"(a.T), "s"(a.d), "s"(a.n_head),
                  "s"(a.batch));
@@ -94,211 +105,207 @@ __global__ __launch_bounds__(512) void enc_attention_x3_kernel(AttnX3Args a) {
     const int n_tiles = (T + AX_KT - 1) / AX_KT;
     const int n_steps = (n_tiles + 1) / 2;            // pairs of key tiles: stream 0 takes tile 2 j, stream 1 tile 2 j + 1
     const long row_qk = 3 * a.ldqk * 2, row_vt = 3 * a.vt_ld * 2;    // bytes
+    const int qs = wave & 3, ks = wave >> 2;
+    const int c = lane & 15, g = lane >> 4;
 
-    if (wave >= 4) {
-        // ---- loader: piece j of a slot covers its bytes [1024 j, 1024 j + 1024): [stream 0: K | V^T][stream 1: K | V^T] ----
-        const int lw = wave - 4;
-        const char* src[AX_NPW];
-        long adv[AX_NPW];         // bytes per pair step
-        int clamp_keys[AX_NPW];   // K pieces: the key row this lane fetches relative to the tile's first key (-1: V^T piece)
-        int stream_of[AX_NPW];
-#pragma unroll
-        for (int i = 0; i < AX_NPW; ++i) {
-            const int j = lw + 4 * i;
-            const int byte = 1024 * j + 16 * lane;
-            const int stream = byte / AX_TILE_BYTES, in_tile = byte - stream * AX_TILE_BYTES;
-            stream_of[i] = stream;
-            if (in_tile < AX_K_BYTES) {
-                const int row = in_tile / AX_K_ROW;
-                const int unit = ((in_tile - row * AX_K_ROW) >> 4) ^ ((row >> 1) & 7);
-                clamp_keys[i] = row;
-                src[i] = reinterpret_cast<const char*>(qk3) + (long)(a.d / 8 + head * 8) * 48 + unit * 16;    // + key * row_qk
-                adv[i] = 0;
-            } else {
-                const int off = in_tile - AX_K_BYTES;
-                const int row = off / AX_V_ROW;
-                const int unit = ((off - row * AX_V_ROW) >> 4) ^ ((row >> 2) & 3);
-                clamp_keys[i] = -1;
-                src[i] = reinterpret_cast<const char*>(qk3 + a.vt_off) + (long)(head * 64 + row) * row_vt + unit * 16 +
-                         (long)stream * (AX_KT / 8) * 48;
-                adv[i] = 2L * (AX_KT / 8) * 48;          // two tiles of 32 keys = 8 stored chunks further
-            }
-        }
-        auto issue_step = [&](int step) {
-            const int sc = min(step, n_steps - 1);         // the tail re-fetches the last pair into a free slot
-            const int slot = step % AX_NB;
-            ax_static_for<AX_NPW>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                const char* p;
-                if (clamp_keys[i] >= 0) {
-                    const int key = min((2 * sc + stream_of[i]) * AX_KT + clamp_keys[i], T - 1);   // rows past T: clamped, masked below
-                    p = src[i] + (long)key * row_qk;
-                } else {
-                    // a second stream without a tile (odd tile count) reads the padding columns of V^T: inside the row
-                    p = src[i] + (long)min(sc, (n_tiles - 1 - stream_of[i]) / 2) * adv[i];
-                }
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                                 (__attribute__((address_space(3))) void*)(lds + slot * AX_SLOT_BYTES + (lw + 4 * i) * 1024),
-                                                 16, 0, 0);
-            });
-        };
-        issue_step(0);
-        issue_step(1);
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        for (int st = 0; st < n_steps; ++st) {
-            issue_step(st + AX_DT);
-            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        return;
-    }
-
-    // ---- compute waves ------------------------------------------------------------------------------------------------
-    const int qb = wave & 1, ks = wave >> 1;
-    const int r = lane & 31, hi = lane >> 5;
-    // Q fragments (B operand of S^T = K Q^T): query q0 + 32 qb + r, feature chunk 2 s + hi, plane p
-    bf16x8 qf[12];
+    // Q fragments (B operand of S^T = K Q^T): query q0 + 16 qs + c, feature chunk 4 kstep + g, plane p - first in the queue
+    bf16x8 qf[6];
     {
-        const int q = min(q0 + 32 * qb + r, T - 1);
+        const int q = min(q0 + 16 * qs + c, T - 1);
         const char* qp = reinterpret_cast<const char*>(qk3) + (long)q * row_qk + (long)(head * 8) * 48;
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int kstep = 0; kstep < 2; ++kstep)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                qf[s * 3 + p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const x3_u32x4*>(qp + ((2 * s + hi) * 3 + p) * 16));
+                qf[kstep * 3 + p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const x3_u32x4*>(qp + ((4 * kstep + g) * 3 + p) * 16));
     }
+    // ---- DMA sources: piece j of a slot covers its bytes [1024 j, 1024 j + 1024): [stream 0: K | V^T][stream 1: K | V^T];
+    // the bank swizzle lives in the source address (K: chunk ^ (row & 7), V^T: chunk ^ ((row >> 1) & 3), planes in place) --
+    const char* src[AX_NPW];
+    long adv[AX_NPW];
+    int key_row[AX_NPW];      // K pieces: the key this lane fetches relative to the tile's first key (-1: V^T piece)
+    int stream_of[AX_NPW];
+#pragma unroll
+    for (int i = 0; i < AX_NPW; ++i) {
+        const int j = wave + 8 * i;
+        const int byte = 1024 * j + 16 * lane;
+        const int stream = byte / AX_TILE_BYTES, in_tile = byte - stream * AX_TILE_BYTES;
+        stream_of[i] = stream;
+        if (in_tile < AX_K_BYTES) {
+            const int row = in_tile / AX_K_ROW;
+            const int up = (in_tile - row * AX_K_ROW) >> 4;
+            const int unit = ((up / 3) ^ (row & 7)) * 3 + up % 3;
+            key_row[i] = row;
+            src[i] = reinterpret_cast<const char*>(qk3) + (long)(a.d / 8 + head * 8) * 48 + unit * 16;    // + key * row_qk
+            adv[i] = 0;
+        } else {
+            const int off = in_tile - AX_K_BYTES;
+            const int row = off / AX_V_ROW;
+            const int up = (off - row * AX_V_ROW) >> 4;
+            const int unit = ((up / 3) ^ ((row >> 1) & 3)) * 3 + up % 3;
+            key_row[i] = -1;
+            src[i] = reinterpret_cast<const char*>(qk3 + a.vt_off) + (long)(head * 64 + row) * row_vt + unit * 16 +
+                     (long)stream * (AX_KT / 8) * 48;
+            adv[i] = 2L * (AX_KT / 8) * 48;          // two tiles of 32 keys = 8 stored chunks further
+        }
+    }
+    auto issue_step = [&](int step) {
+        if constexpr (ABL >= 2) return;
+        const int sc = min(step, n_steps - 1);         // the tail re-fetches the last pair into a free slot
+        const int slot = step % AX_NB;
+        ax_static_for<AX_NPW>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const char* p;
+            if (key_row[i] >= 0) {
+                const int key = min((2 * sc + stream_of[i]) * AX_KT + key_row[i], T - 1);   // rows past T: clamped, masked below
+                p = src[i] + (long)key * row_qk;
+            } else {
+                // a second stream without a tile (odd tile count) re-reads its last real tile
+                p = src[i] + (long)min(sc, (n_tiles - 1 - stream_of[i]) / 2) * adv[i];
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                             (__attribute__((address_space(3))) void*)(lds + slot * AX_SLOT_BYTES + (wave + 8 * i) * 1024),
+                                             16, 0, 0);
+        });
+    };
+    issue_step(0);
+    issue_step(1);
+
+    // ---- fragment addresses of this wave's stream --------------------------------------------------------------------
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const unsigned tile_base = lds_base + (unsigned)ks * AX_TILE_BYTES;
-    unsigned k_addr[12], v_addr[2][6];
-    {
-        const unsigned kswz = (unsigned)((r >> 1) & 7), vswz = (unsigned)((r >> 2) & 3);
+    unsigned k_addr[12], v_addr[12];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                k_addr[s * 3 + p] = tile_base + (unsigned)(r * AX_K_ROW) + ((unsigned)((2 * s + hi) * 3 + p) ^ kswz) * 16u;
+        for (int kstep = 0; kstep < 2; ++kstep)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+            for (int p = 0; p < 3; ++p) {       // key 16 kb + c, feature chunk 4 kstep + g
+                const int row = 16 * kb + c;
+                k_addr[kb * 6 + kstep * 3 + p] = tile_base + (unsigned)(row * AX_K_ROW) + (unsigned)((((4 * kstep + g) ^ (row & 7)) * 3 + p) * 16);
+            }
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+    for (int db = 0; db < 4; ++db)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)      // d = 32 b + r (swizzle of row 32 b + r == that of row r), stored chunk 2 t + hi
-                    v_addr[b][t * 3 + p] = tile_base + AX_K_BYTES + (unsigned)((32 * b + r) * AX_V_ROW) + ((unsigned)((2 * t + hi) * 3 + p) ^ vswz) * 16u;
-    }
-    af32x16 o[2];
+        for (int p = 0; p < 3; ++p) {           // feature 16 db + c, stored key chunk g
+            const int row = 16 * db + c;
+            v_addr[db * 3 + p] = tile_base + AX_K_BYTES + (unsigned)(row * AX_V_ROW) + (unsigned)(((g ^ ((row >> 1) & 3)) * 3 + p) * 16);
+        }
+    af32x4 o[4];
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[b][i] = 0.f;
+    for (int db = 0; db < 4; ++db) o[db] = af32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
-    __builtin_amdgcn_s_barrier();              // pair 0 has landed
-    for (int st = 0; st < n_steps; ++st) {
-        const unsigned off = (unsigned)(st % AX_NB) * (unsigned)AX_SLOT_BYTES;
-        const int tile = 2 * st + ks;
-        const bool have = tile < n_tiles;      // wave-uniform
-        if (have) {
-            const int key0 = tile * AX_KT;
-            af32x4 kf[12], vf[12];
-            ax_read12(kf, k_addr, off);
-            {
-                unsigned va[12];
+    // (Measured and dropped, profiles/r04j_x3_attention_ablation.txt, r04k_x3_attention_skewed_ablation.txt: running stream 1 half a step out of phase - it finishes
+    // tile st - 1 while stream 0 computes S(st) - so that one wave of a SIMD is in its softmax while the other is in its
+    // MFMAs: 60.8 us instead of 48.9.  What the two waves of a SIMD share is issue bandwidth, not just the matrix pipe.)
+    af32x4 vf[12];
+    float s[8];
+    auto phase_s = [&](int tile, unsigned off) {          // fragments of `tile` -> registers, s = K Q^T
+        af32x4 kf[12];
+        ax_read12(kf, k_addr, off);
+        ax_read12(vf, v_addr, off);
+        ax_wait12(kf);
+        // key blocks 0 / 1 are two independent accumulator chains
+        af32x4 s2[2] = {af32x4{0.f, 0.f, 0.f, 0.f}, af32x4{0.f, 0.f, 0.f, 0.f}};
+        ax_static_for<24>([&](auto X) {
+            constexpr int x = decltype(X)::value;
+            constexpr int t = x / 4, kstep = (x / 2) % 2, kb = x % 2;      // product t of feature step kstep, key block kb
+            s2[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[kb * 6 + kstep * 3 + AX_PA[t]]),
+                                                             qf[kstep * 3 + AX_PB[t]], s2[kb], 0, 0, 0);
+        });
+        // s[4 kb + i] = score of key key0 + 16 kb + 4 g + i against this lane's query
 #pragma unroll
-                for (int i = 0; i < 6; ++i) { va[i] = v_addr[0][i]; va[6 + i] = v_addr[1][i]; }
-                ax_read12(vf, va, off);
-            }
-            ax_wait12(kf);
-            // ---- S^T = K Q^T: two accumulator chains (even / odd k-steps), added afterwards
-            af32x16 sa, sb;
+        for (int i = 0; i < 4; ++i) { s[i] = s2[0][i]; s[4 + i] = s2[1][i]; }
+        const int key0 = tile * AX_KT;
+        if (__builtin_amdgcn_readfirstlane(key0 + AX_KT > T)) {      // only the last tile has keys past the end
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
-            ax_static_for<24>([&](auto X) {
-                constexpr int x = decltype(X)::value;
-                constexpr int t = x / 4, s = x % 4;      // product t of k-step s
-                if constexpr (s % 2 == 0)
-                    sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[s * 3 + AX_PA[t]]), qf[s * 3 + AX_PB[t]], sa, 0, 0, 0);
-                else
-                    sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[s * 3 + AX_PA[t]]), qf[s * 3 + AX_PB[t]], sb, 0, 0, 0);
-            });
-            float s[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s[i] = sa[i] + sb[i];
-            // ---- online softmax over this lane's query column (its 16 keys here, the other 16 in lane ^ 32)
-            if (key0 + AX_KT > T) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (key0 + (i & 3) + 8 * (i >> 2) + 4 * hi >= T) s[i] = -INFINITY;
-            }
-            float mt = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) mt = fmaxf(mt, s[i]);
+            for (int i = 0; i < 8; ++i)
+                if (key0 + 16 * (i >> 2) + 4 * g + (i & 3) >= T) s[i] = -INFINITY;
+        }
+        ax_wait12(vf);
+    };
+    auto phase_pv = [&]() {                                 // online softmax of s, O^T += V^T P^T
+        bf16x8 pf[3];
+        if constexpr (ABL != 3) {
+            // this lane's query column: its 8 keys here, the others in lanes ^ 16, ^ 32
+            float mt = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+            mt = fmaxf(mt, wave_xor<16>(mt));
             mt = fmaxf(mt, wave_xor<32>(mt));
             const float m_new = fmaxf(m_run, mt);
             const float alpha = __expf(m_run - m_new);
             float rs = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 s[i] = __expf(s[i] - m_new);
                 rs += s[i];
             }
+            rs += wave_xor<16>(rs);
             rs += wave_xor<32>(rs);
             l_run = l_run * alpha + rs;
             m_run = m_new;
             if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+                for (int db = 0; db < 4; ++db) o[db] *= alpha;
             }
-            // ---- O^T += V^T P^T: the probabilities of k-step t are registers 8 t .. 8 t + 7, split into their planes
-            bf16x8 pf[2][3];
+            // the lane's 8 probabilities are, split into planes, its B fragment
+            ax_split8(s, pf);
+        } else {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float v8[8] = {s[8 * t], s[8 * t + 1], s[8 * t + 2], s[8 * t + 3], s[8 * t + 4], s[8 * t + 5], s[8 * t + 6], s[8 * t + 7]};
-                ax_split8(v8, pf[t]);
-            }
-            ax_wait12(vf);
-            ax_static_for<24>([&](auto X) {
-                constexpr int x = decltype(X)::value;
-                constexpr int pr = x / 4, t = (x / 2) % 2, b = x % 2;      // product pr of k-step t, feature block b
-                o[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[b * 6 + t * 3 + AX_PA[pr]]), pf[t][AX_PB[pr]], o[b], 0, 0, 0);
-            });
+            for (int p = 0; p < 3; ++p) pf[p] = __builtin_bit_cast(bf16x8, vf[p]);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // pair st + 1 readable; everybody is done with pair st
-    }
-    __builtin_amdgcn_s_barrier();              // the loaders' tail fetches have landed: the ring can be reused
+        ax_static_for<24>([&](auto X) {
+            constexpr int x = decltype(X)::value;
+            constexpr int t = x / 4, db = x % 4;      // product t of feature block db: four independent chains
+            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf[db * 3 + AX_PA[t]]), pf[AX_PB[t]], o[db], 0, 0, 0);
+        });
+    };
 
-    // ---- merge the two key streams of each query block through LDS and write the normalised rows ----------------------
-    // o[b][i] is O^T[feature 32 b + (i & 3) + 8 (i >> 2) + 4 hi][query r]
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // the Q fragments and this wave's pieces of pair 0
+    __builtin_amdgcn_s_barrier();
+    for (int st = 0; st < n_steps; ++st) {
+        issue_step(st + AX_DT);
+        const unsigned off = (unsigned)(st % AX_NB) * (unsigned)AX_SLOT_BYTES;
+        const int tile = 2 * st + ks;
+        if (ABL != 1 && tile < n_tiles) {      // wave-uniform
+            phase_s(tile, off);
+            phase_pv();
+        }
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // this wave's pieces of pair st + 1 have landed
+        __builtin_amdgcn_s_barrier();          // pair st + 1 readable; everybody is done with pair st's LDS image
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // the tail fetches have landed: the ring can be reused
+
+    // ---- merge the two key streams of each 16-query block through LDS and write the normalised rows -------------------
+    // o[db][i] is O^T[feature 16 db + 4 g + i][query c]
     constexpr int O_LD = 68;
-    float* Os = reinterpret_cast<float*>(lds);                 // [wave][32 queries][O_LD]
-    float* Ms = Os + 4 * 32 * O_LD;                            // [wave][32]
-    float* Ls = Ms + 4 * 32;
+    float* Os = reinterpret_cast<float*>(lds);                 // [wave][16 queries][O_LD]
+    float* Ms = Os + 8 * 16 * O_LD;                            // [wave][16]
+    float* Ls = Ms + 8 * 16;
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int db = 0; db < 4; ++db)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) Os[(wave * 32 + r) * O_LD + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * hi] = o[b][i];
-    if (hi == 0) {
-        Ms[wave * 32 + r] = m_run;
-        Ls[wave * 32 + r] = l_run;
+        for (int i = 0; i < 4; ++i) Os[(wave * 16 + c) * O_LD + 16 * db + 4 * g + i] = o[db][i];
+    if (g == 0) {
+        Ms[wave * 16 + c] = m_run;
+        Ls[wave * 16 + c] = l_run;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     {
-        const int tid = threadIdx.x;       // 0 .. 255
+        const int tid = threadIdx.x;       // 0 .. 511
         const int dd = tid & 63, qg = tid >> 6;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int q = qg * 16 + i;     // 0 .. 63: query block q >> 5, row q & 31
+        for (int i = 0; i < 8; ++i) {
+            const int q = qg * 8 + i;      // 0 .. 63: 16-query block q >> 4, row q & 15
             const int qrow = q0 + q;
-            const int w0 = q >> 5, w1 = w0 + 2;      // the block's two streams (wave = qb + 2 ks)
-            const float m0 = Ms[w0 * 32 + (q & 31)], m1 = Ms[w1 * 32 + (q & 31)];
+            const int w0 = q >> 4, w1 = w0 + 4;      // the block's two streams (wave = qs + 4 ks)
+            const float m0 = Ms[w0 * 16 + (q & 15)], m1 = Ms[w1 * 16 + (q & 15)];
             const float M = fmaxf(m0, m1);
             const float e0 = m0 == -INFINITY ? 0.f : expf(m0 - M), e1 = m1 == -INFINITY ? 0.f : expf(m1 - M);
-            const float L = e0 * Ls[w0 * 32 + (q & 31)] + e1 * Ls[w1 * 32 + (q & 31)];
-            const float acc = e0 * Os[(w0 * 32 + (q & 31)) * O_LD + dd] + e1 * Os[(w1 * 32 + (q & 31)) * O_LD + dd];
+            const float L = e0 * Ls[w0 * 16 + (q & 15)] + e1 * Ls[w1 * 16 + (q & 15)];
+            const float acc = e0 * Os[(w0 * 16 + (q & 15)) * O_LD + dd] + e1 * Os[(w1 * 16 + (q & 15)) * O_LD + dd];
             if (qrow < T) aout[(long)qrow * a.ldo + head * 64 + dd] = acc / L;
         }
     }
@@ -320,10 +327,9 @@ __global__ __launch_bounds__(256) void x3_pack_qkv_kernel(const float* __restric
     } else if (idx < n_qk + n_vt) {
         const long j = idx - n_qk;
         const int dcol = (int)(j / (vt_ld / 8)), u = (int)(j - (long)dcol * (vt_ld / 8));
-        const int r0 = 16 * (u >> 1) + 4 * (u & 1);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int t = r0 + (e & 3) + 8 * (e >> 2);
+            const int t = 32 * (u >> 2) + ax_vt_key(u & 3, e);
             v[e] = t < T ? qkv[(long)t * 3 * d + 2 * d + dcol] : 0.f;
         }
         x3_store_chunk(out + vt_off + (long)dcol * 3 * vt_ld + (long)u * 24, v);
@@ -347,14 +353,16 @@ bool enc_attention_x3_enabled() {
 
 void launch_encoder_attention_x3(const LaunchCtx& ctx, const unsigned short* qk3, long ldqk, long vt_off, long vt_ld, float* out,
                                  long ldo, int T, int d, int n_head, const PtrTable* z, int batch) {
-    if (d != n_head * 64 || ldqk % 8 != 0 || vt_ld % 16 != 0 || vt_ld < ((T + 31) / 32) * 32 || T < 64)
+    if (d != n_head * 64 || ldqk % 8 != 0 || vt_ld % 32 != 0 || vt_ld < ((T + 31) / 32) * 32 || T < 64)
         throw std::invalid_argument("x3 attention: unsupported shape");
     static std::atomic<uint64_t> configured{0};
     int dev = 0;
     WLK_HIP(hipGetDevice(&dev));
     if (!(configured.load(std::memory_order_acquire) >> (dev & 63) & 1)) {
-        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attention_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)AX_LDS_BYTES));
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attention_x3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AX_LDS_BYTES));
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attention_x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AX_LDS_BYTES));
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attention_x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AX_LDS_BYTES));
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attention_x3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AX_LDS_BYTES));
         configured.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     AttnX3Args a{};
@@ -363,7 +371,15 @@ void launch_encoder_attention_x3(const LaunchCtx& ctx, const unsigned short* qk3
     if (batch > 0) a.z = *z;
     const int q_tiles = (T + AX_QT - 1) / AX_QT;
     KernelScope ks(ctx, "enc_attention_x3", (batch > 0 ? batch : 1) * 4.0 * (double)T * T * 64 * n_head, 0.0);
-    hipLaunchKernelGGL(enc_attention_x3_kernel, dim3(q_tiles * n_head, batch > 0 ? batch : 1), dim3(512), AX_LDS_BYTES, ctx.stream, a);
+    static const int abl = [] {
+        const char* e = getenv("WLK_X3_ATTN_ABL");
+        return e ? atoi(e) : 0;
+    }();
+    const dim3 grid(q_tiles * n_head, batch > 0 ? batch : 1);
+    if (abl == 1) hipLaunchKernelGGL(enc_attention_x3_kernel<1>, grid, dim3(512), AX_LDS_BYTES, ctx.stream, a);
+    else if (abl == 2) hipLaunchKernelGGL(enc_attention_x3_kernel<2>, grid, dim3(512), AX_LDS_BYTES, ctx.stream, a);
+    else if (abl == 3) hipLaunchKernelGGL(enc_attention_x3_kernel<3>, grid, dim3(512), AX_LDS_BYTES, ctx.stream, a);
+    else hipLaunchKernelGGL(enc_attention_x3_kernel<0>, grid, dim3(512), AX_LDS_BYTES, ctx.stream, a);
     WLK_HIP(hipGetLastError());
 }
 

@@ -244,14 +244,14 @@ struct X3GemmArgs {
     int map_mode = 0;                     // probe only (WLK_X3_MAP): 1 = plain tile order, 2 = 2 x 4 bands
     // Result in the X3 format instead of fp32 (the operands of enc_attention_x3_kernel): columns [0, vt_col0) as X3 rows
     // (row m at C3 + m * 3 * ldc3), columns [vt_col0, N) TRANSPOSED - column n is row n - vt_col0 of a [N - vt_col0][vt_ld]
-    // X3 matrix at C3 + vt_off whose chunks run along m, with the keys of every 16-row group stored in the order
-    // 0-3, 8-11, 4-7, 12-15 (the order in which a lane of the attention kernel holds its probabilities).  Batched:
+    // X3 matrix at C3 + vt_off whose chunks run along m; stored chunk u of every 32-row group holds rows 4 u .. 4 u + 3 and
+    // 16 + 4 u .. 16 + 4 u + 3 (the keys whose probabilities a lane of the attention kernel holds).  Batched:
     // C3 = z.out[i] reinterpreted; the fp32 C is not written in this mode.
     unsigned short* C3 = nullptr;
     long ldc3 = 0;
     int vt_col0 = 0;
     long vt_off = 0;                      // in bf16 units, from C3
-    long vt_ld = 0;                       // fp32-element units (multiple of 16, >= M)
+    long vt_ld = 0;                       // fp32-element units (multiple of 32, >= M)
     bool x3_out = false;
     PtrTable z;
 };

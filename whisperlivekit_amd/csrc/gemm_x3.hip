@@ -287,12 +287,13 @@ __global__ __launch_bounds__(512) void gemm_x3_wide_kernel(X3GemmArgs g) {
             unsigned short* const vt = c3 + g.vt_off;
             for (int item = tid; item < XW_BN * (XW_BM / 8); item += 256) {
                 const int dcol = item / (XW_BM / 8), u = item - dcol * (XW_BM / 8);
-                const int r0 = 16 * (u >> 1) + 4 * (u & 1);     // rows r0 .. r0 + 3 and r0 + 8 .. r0 + 11
-                if (n0 + dcol < g.N && m0 + r0 < g.vt_ld) {
+                // stored chunk u of the tile's 96 rows = 32-row group u >> 2, chunk u & 3: rows 4 (u & 3) .. + 3 and 16 more
+                const int r0 = 32 * (u >> 2) + 4 * (u & 3);
+                if (n0 + dcol < g.N && m0 + 32 * (u >> 2) < g.vt_ld) {
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const int row = r0 + (e & 3) + 8 * (e >> 2);
+                        const int row = r0 + (e & 3) + 16 * (e >> 2);
                         v[e] = m0 + row < g.M ? stage[row * PITCH + dcol] : 0.f;
                     }
                     x3_store_chunk(vt + (long)(n0 + dcol - g.vt_col0) * 3 * g.vt_ld + (long)((m0 >> 3) + u) * 24, v);
@@ -339,7 +340,7 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
     if (g.M <= 0 || g.N <= 0) return;
     if (g.K % 32 != 0 || g.lda % 8 != 0 || g.K < 64) throw std::invalid_argument("x3 gemm: K must be a multiple of 32 (>= 64), lda of 8");
     if (g.flags & ~(kGemmGelu | kGemmResidual | kGemmScaleCols)) throw std::invalid_argument("x3 gemm: unsupported epilogue flag");
-    if (g.x3_out && ((g.flags & (kGemmGelu | kGemmResidual)) || g.vt_col0 % XW_BN != 0 || g.ldc3 % 8 != 0 || g.vt_ld % 16 != 0 ||
+    if (g.x3_out && ((g.flags & (kGemmGelu | kGemmResidual)) || g.vt_col0 % XW_BN != 0 || g.ldc3 % 8 != 0 || g.vt_ld % 32 != 0 ||
                      g.vt_ld < g.M))
         throw std::invalid_argument("x3 gemm: unsupported X3 result layout");
     static std::atomic<uint64_t> configured{0};
