@@ -17,11 +17,13 @@ for name, m, n, k, flags in shapes:
     assert lib.wlk_diag_linear_x3_time(m, n, k, flags, 50, C.byref(us3)) == 0, lib.wlk_diag_last_error()
     assert lib.wlk_diag_linear_time(m, n, k, flags, 0, 50, C.byref(us32)) == 0
     gf = 2.0 * m * n * k / 1e9
-    print(f"{name:20s} M{m} N{n} K{k}: x3 {us3.value:7.2f} us = {gf / us3.value * 1e3 / 1e3:6.1f} TF f32-equivalent ({6 * gf / us3.value:7.1f} TF bf16 issued) | "
-          f"fp32 mfma {us32.value:7.2f} us = {gf / us32.value:6.1f} TF | x{us32.value / us3.value:.2f}")
+    # gf GFLOP in us microseconds = gf / us * 1e-3 TFLOP/s... (1e9 / 1e-6 = 1e15): TFLOP/s = gf / us * 1e3
+    print(f"{name:20s} M{m} N{n} K{k}: x3 {us3.value:7.2f} us = {gf / us3.value * 1e3:6.1f} TF f32-equivalent ({6 * gf / us3.value * 1e3:7.1f} TF bf16 issued) | "
+          f"fp32 mfma {us32.value:7.2f} us = {gf / us32.value * 1e3:6.1f} TF | x{us32.value / us3.value:.2f}")
 for name, t, d, h in [("base attention", 1500, 512, 8), ("small attention", 1500, 768, 12), ("large-v3 attention", 1500, 1280, 20)]:
     us3, us32 = C.c_float(), C.c_float()
     assert lib.wlk_diag_encoder_attention_x3_time(t, d, h, 50, C.byref(us3)) == 0, lib.wlk_diag_last_error()
     assert lib.wlk_diag_encoder_attention_time(t, d, h, 1, 50, C.byref(us32)) == 0
     gf = 4.0 * t * t * 64 * h / 1e9
-    print(f"{name:20s} T{t} d{d}: x3 {us3.value:7.2f} us = {gf / us3.value * 1e3 / 1e3:6.1f} GF/us f32-equivalent | fp32 mfma {us32.value:7.2f} us | x{us32.value / us3.value:.2f}")
+    print(f"{name:20s} T{t} d{d}: x3 {us3.value:7.2f} us = {gf / us3.value * 1e3:6.1f} TF f32-equivalent | fp32 mfma {us32.value:7.2f} us = "
+          f"{gf / us32.value * 1e3:6.1f} TF | x{us32.value / us3.value:.2f}")

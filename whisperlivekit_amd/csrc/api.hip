@@ -981,7 +981,7 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
         q.flags = kGemmScaleCols; q.scale = scale; q.scale_cols = d;
         // decode steps: the split cross-attention kernel derives its head's query values itself (same arithmetic) - one
         // launch less per layer
-        const bool fold_xq = fused && R <= 8 && !s->debug && cross_split_folds_query(d);
+        const bool fold_xq = fused && R == 1 && !s->debug && cross_split_folds_query(d);   // one row: saves a launch; several rows would each re-stream Wq
         if (fold_xq) {
         } else if (fused) {
             q.A = s->dx; q.ln_gamma = L.lnxw; q.ln_beta = L.lnxb;

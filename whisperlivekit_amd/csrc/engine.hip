@@ -147,7 +147,10 @@ void wlk_engine::enqueue_decoder(int R, bool from_block) {
         GemmArgs qq;
         qq.A = x; qq.lda = d; qq.W = L.xqw; qq.bias = L.xqb; qq.C = q; qq.ldc = d; qq.M = R; qq.N = d; qq.K = d;
         qq.flags = kGemmScaleCols; qq.scale = scale; qq.scale_cols = d; qq.ln_gamma = L.lnxw; qq.ln_beta = L.lnxb;
-        const bool fold_xq = cross_split_folds_query(d);      // the split kernel derives the query values itself
+        // batched steps keep the query projection as ONE multi-row GEMV (weights streamed once for all rows): folded into the
+        // split cross-attention every row's 64 workgroups would stream Wq again (19 us per launch at 8 streams,
+        // profiles/r04_trace8_busy.txt) - the fold only pays for a single row, where it saves a launch
+        const bool fold_xq = R == 1 && cross_split_folds_query(d);
         if (!fold_xq) launch_gemv(c, qq, "dec_lnx_xq");
         CrossAttnArgs ca{};
         ca.q = q; ca.k = nullptr; ca.v = nullptr; ca.ldkv = (long)D.n_text_layer * 2 * d; ca.out = att;
