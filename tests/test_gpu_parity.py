@@ -481,7 +481,8 @@ vp = lambda a: a.ctypes.data_as(C.c_void_p)
 rng = np.random.default_rng(5)
 out = []
 for (N, K, flags, ln) in [(512, 512, 2, 0), (2048, 512, 1, 1), (512, 2048, 2, 0), (1536, 512, 4, 1), (384, 384, 0, 1),
-                          (1280, 1280, 2, 0), (130, 768, 0, 1)]:
+                          (1280, 1280, 2, 0), (130, 768, 0, 1), (3840, 1280, 0, 1), (5120, 1280, 1, 1), (768, 3072, 2, 0),
+                          (1024, 4096, 2, 0), (1280, 5120, 2, 0), (1100, 1536, 0, 0), (2304, 768, 0, 1)]:
     a = rng.standard_normal((1, K)).astype(np.float32)
     w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
     b = rng.standard_normal(N).astype(np.float32)

@@ -704,7 +704,7 @@ void launch_decoder_cross_attention_split(const LaunchCtx& ctx, const CrossAttnA
     hipLaunchKernelGGL(cross_split_kernel<UBv>, grid, dim3(256), 0, ctx.stream, a.k, a.v, a.q, a.ldkv, a.T, a.d, a.n_head, \
                        a.step_rows, scores, pm, pl, po, rest)
         if (a.xq_w) {
-            if (!cross_split_folds_query(a.d)) throw std::invalid_argument("cross-attention: cannot fold the query projection");
+            if (a.d % 256 != 0 || a.d < 256 || a.d > 2048) throw std::invalid_argument("cross-attention: cannot fold the query projection");
             const int ub = a.d / 256;
             if (ub <= 2) WLK_CROSS_SPLIT(2);
             else if (ub <= 4) WLK_CROSS_SPLIT(4);
@@ -727,12 +727,17 @@ void launch_decoder_cross_attention_split(const LaunchCtx& ctx, const CrossAttnA
 // keys and values (one round trip), and a dependent launch now costs ~3.9 us of a 200 us step: default ON, WLK_XQ_FOLD=0
 // restores the separate launch (profiles/r04h_ab_xq_fold.txt).  All golden streams are bit-identical either way (the fold
 // reproduces the GEMV's arithmetic).
+// Where it pays: every (head, split) workgroup streams its head's 64 rows of Wq itself, n_head * 8 * 64 * d * 4 bytes per
+// layer out of the L2s - 8 MB on base.en (neutral to +1 %), 52 MB on large-v3, where the split kernel went from 8.4 to
+// 19 us per layer and a step from 2.32 to 2.52 ms (profiles/r04m_large_v3_folds.txt).  Default: d <= 512.
+// WLK_XQ_FOLD=1 folds wherever the kernel can, =0 never.
 bool cross_split_folds_query(int d) {
-    static const bool on = [] {
+    static const int mode = [] {
         const char* e = getenv("WLK_XQ_FOLD");
-        return !(e && e[0] == '0');
+        return !e ? -1 : (e[0] == '0' ? 0 : 1);
     }();
-    return on && d % 256 == 0 && d >= 256 && d <= 2048;
+    if (mode == 0 || d % 256 != 0 || d < 256 || d > 2048) return false;
+    return mode == 1 || d <= 512;
 }
 size_t cross_split_scratch_floats(int rows, int n_head, int T) {
     return (size_t)rows * n_head * ((size_t)T + kCrossSplit * (2 + 64));

@@ -1403,7 +1403,7 @@ struct Gemv1Merge {            // A row = cross-attention output still in split 
     int T, ring_rows, n_beam, side_blocks;
 };
 
-template <int UB, int RPW, bool LN, bool MG>
+template <int UB, int RPW, bool LN, bool MG, bool FULL>
 __global__ __launch_bounds__(256) void gemv1_f32_kernel(const float* __restrict__ W, const float* __restrict__ A, int K, int N,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ bias, const float* R, Gemv1Tail t,
@@ -1458,7 +1458,7 @@ __global__ __launch_bounds__(256) void gemv1_f32_kernel(const float* __restrict_
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
         const int c = lane + 64 * u;
-        const int cc = c < K4 ? c : 0;
+        const int cc = (FULL || c < K4) ? c : 0;
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
             w[u][r] = *reinterpret_cast<const float4*>(W + (long)min(n_base + r, N - 1) * K + cc * 4);
@@ -1483,8 +1483,8 @@ __global__ __launch_bounds__(256) void gemv1_f32_kernel(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < UB * 4; ++i) {
             const int c = lane + 64 * i;
-            const float f = A[c < K ? c : 0];
-            v[i] = c < K ? f : 0.f;
+            const float f = A[(FULL || c < K) ? c : 0];
+            v[i] = (FULL || c < K) ? f : 0.f;
         }
     }
     const int n_out = min(n_base + (lane < RPW ? lane : 0), N - 1);
@@ -1493,6 +1493,9 @@ __global__ __launch_bounds__(256) void gemv1_f32_kernel(const float* __restrict_
     const int kv_pos = *t.kv_pos;
     WLK_PIN_S(t.C); WLK_PIN_S(t.kcache); WLK_PIN_S(t.vcache); WLK_PIN_S(t.flags); WLK_PIN_S(t.scale);
     WLK_PIN_S(t.scale_cols); WLK_PIN_S(t.kv_d); WLK_PIN_S(kv_pos);
+    // nothing below may move above this line and no load below it: hipcc otherwise rolls the long variants into a window
+    // of twelve loads with counted waits (UB 20: 3.3 memory round trips per wave instead of one)
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- arithmetic (statement for statement the round-3 kernel's) ---------------------------------------------------
     if constexpr (MG) {
@@ -1526,7 +1529,7 @@ __global__ __launch_bounds__(256) void gemv1_f32_kernel(const float* __restrict_
         float sq = 0.f;
 #pragma unroll
         for (int i = 0; i < UB * 4; ++i) {
-            const float d = (lane + 64 * i) < K ? v[i] - mean : 0.f;
+            const float d = (FULL || (lane + 64 * i) < K) ? v[i] - mean : 0.f;
             sq += d * d;
         }
         sq = wave_sum(sq);
@@ -1544,7 +1547,7 @@ __global__ __launch_bounds__(256) void gemv1_f32_kernel(const float* __restrict_
     for (int r = 0; r < RPW; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-        if (lane + 64 * u < K4) {
+        if (FULL || lane + 64 * u < K4) {
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 acc[r] = fmaf(w[u][r].x, x[u].x, acc[r]);
@@ -1556,6 +1559,8 @@ __global__ __launch_bounds__(256) void gemv1_f32_kernel(const float* __restrict_
     }
 #pragma unroll
     for (int r = 0; r < RPW; ++r) acc[r] = wave_sum(acc[r]);
+    // a use outside the epilogue's branch: hipcc otherwise sinks these two loads into it (one more memory round trip)
+    asm volatile("" ::"v"(bias_v), "v"(res_v));
     if (lane < RPW) {
         const int n = n_base + lane;
         if (n < N) {
@@ -1584,7 +1589,20 @@ static bool gemv1_enabled() {
     return on;
 }
 
-bool gemv1_folds_merge(int K) { return gemv1_enabled() && K <= 2048 && K % 64 == 0 && getenv("WLK_NO_MERGE_FOLD") == nullptr; }
+// Where the merged operand pays: every WAVE re-derives its slice of the attention output from the split partials, 8 x the
+// bytes of the activation row it replaces, and holds them in registers (UB 8: 442 VGPRs).  On base.en that is 8 MB per
+// launch out of the L2s and a launch saved; on large-v3 (K = 1280) 52 MB and one wave per SIMD: dec_xout 20 us against
+// 6.9 + 6.9 for merge kernel + plain GEMV (profiles/r04m_large_v3_folds.txt).  Default: K <= 512; WLK_MERGE_FOLD=1 folds
+// wherever the kernel can, WLK_NO_MERGE_FOLD=1 never.
+bool gemv1_folds_merge(int K) {
+    static const bool never = getenv("WLK_NO_MERGE_FOLD") != nullptr;
+    static const bool always = [] {
+        const char* e = getenv("WLK_MERGE_FOLD");
+        return e && e[0] == '1';
+    }();
+    if (never || !gemv1_enabled() || K > 2048 || K % 64 != 0) return false;
+    return always || K <= 512;
+}
 
 void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (g.M <= 0 || g.N <= 0) return;
@@ -1600,7 +1618,10 @@ void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     KernelScope ks(ctx, tag, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
     if (g.mg_pm && !(g.M == 1 && g.K <= 2048 && rpw <= 2 && gemv1_enabled() && !g.ln_gamma))
         throw std::invalid_argument("gemv: the merged cross-attention operand needs the single-row kernel");
-    if (g.M == 1 && g.K <= 2048 && rpw <= 2 && gemv1_enabled() && !g.kv_rows) {
+    // the whole K of a row in flight per wave: up to 2048 for every variant, up to 5120 (the MLP's second projection of
+    // the large models, 20 float4 per lane) for the plain one-feature-per-wave variant
+    const bool plain1 = rpw == 1 && !g.ln_gamma && !g.mg_pm;
+    if (g.M == 1 && (g.K <= 2048 || (plain1 && g.K <= 5120)) && rpw <= 2 && gemv1_enabled() && !g.kv_rows) {
         const int ub = (g.K / 4 + 63) / 64;
         blocks += g.mg_pm ? g.mg_side_blocks : 0;
         // absent operands point at the weights: the kernel requests every operand up front, unconditionally
@@ -1612,26 +1633,52 @@ void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
                       g.mg_beam_of_row, g.mg_T, g.mg_ring_rows, g.mg_n_beam, g.mg_side_blocks};
         if (g.mg_pm && g.mg_side_blocks > 0 && !g.mg_side_heads)
             throw std::invalid_argument("gemv: the merged operand's side blocks need the layer's alignment head list");
-#define WLK_GEMV1_I(UBv, RPWv, LNv, MGv)                                                                                 \
-    hipLaunchKernelGGL((gemv1_f32_kernel<UBv, RPWv, LNv, MGv>), dim3(blocks), dim3(256), 0, ctx.stream, g.W, g.A, g.K, \
-                       g.N, g.ln_gamma, g.ln_beta, bias, res, t, mg)
+#define WLK_GEMV1_F(UBv, RPWv, LNv, MGv, FULLv)                                                                         \
+    hipLaunchKernelGGL((gemv1_f32_kernel<UBv, RPWv, LNv, MGv, FULLv>), dim3(blocks), dim3(256), 0, ctx.stream, g.W, g.A, \
+                       g.K, g.N, g.ln_gamma, g.ln_beta, bias, res, t, mg)
+    // FULL: K fills every lane of every chunk (all Whisper widths but tiny's 384) - no predicates, one basic block, every
+    // load above the barrier
+#define WLK_GEMV1_I(UBv, RPWv, LNv, MGv)                             \
+    do {                                                             \
+        if (g.K == 256 * UBv) WLK_GEMV1_F(UBv, RPWv, LNv, MGv, true); \
+        else WLK_GEMV1_F(UBv, RPWv, LNv, MGv, false);                \
+    } while (0)
 #define WLK_GEMV1_R(UBv, LNv, MGv)                 \
     do {                                           \
         if (rpw == 2) WLK_GEMV1_I(UBv, 2, LNv, MGv); \
         else WLK_GEMV1_I(UBv, 1, LNv, MGv);        \
     } while (0)
+#define WLK_GEMV1_NOMG(UBv)                                    \
+    do {                                                       \
+        if (g.ln_gamma) WLK_GEMV1_R(UBv, true, false);         \
+        else WLK_GEMV1_R(UBv, false, false);                   \
+    } while (0)
 #define WLK_GEMV1(UBv)                                         \
     do {                                                       \
         if (g.mg_pm) WLK_GEMV1_R(UBv, false, true);            \
-        else if (g.ln_gamma) WLK_GEMV1_R(UBv, true, false);    \
-        else WLK_GEMV1_R(UBv, false, false);                   \
+        else WLK_GEMV1_NOMG(UBv);                              \
     } while (0)
-        if (ub <= 2) WLK_GEMV1(2);
-        else if (ub <= 4) WLK_GEMV1(4);
-        else WLK_GEMV1(8);
+        // UB = float4 chunks per lane = registers held and loads in flight: exact for every Whisper width (K = d or 4 d,
+        // d in 384 .. 1280), so that a wave of the large models does not carry dead registers into its occupancy
+        // (K = 1280 as UB 8: 188 VGPRs, 512 of fc1's 640 workgroups resident -> two rounds)
+        switch (ub) {
+            case 1: case 2: WLK_GEMV1(2); break;
+            case 3: if (g.mg_pm) WLK_GEMV1(4); else WLK_GEMV1_NOMG(3); break;
+            case 4: WLK_GEMV1(4); break;
+            case 5: if (g.mg_pm) WLK_GEMV1(8); else WLK_GEMV1_NOMG(5); break;
+            case 6: if (g.mg_pm) WLK_GEMV1(8); else WLK_GEMV1_NOMG(6); break;
+            case 7: case 8: WLK_GEMV1(8); break;
+            default:
+                if (ub <= 12) WLK_GEMV1_I(12, 1, false, false);
+                else if (ub <= 16) WLK_GEMV1_I(16, 1, false, false);
+                else WLK_GEMV1_I(20, 1, false, false);
+                break;
+        }
 #undef WLK_GEMV1
+#undef WLK_GEMV1_NOMG
 #undef WLK_GEMV1_R
 #undef WLK_GEMV1_I
+#undef WLK_GEMV1_F
         WLK_HIP(hipGetLastError());
         return;
     }
