@@ -454,7 +454,7 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         s->ring_rows = (int)ctx + kAlignWindow;
         if (m->n_align > 0) s->ring = dev_alloc<float>((size_t)m->n_align * beam * s->ring_rows * T);
         s->xsplit = dev_alloc<float>(cross_split_scratch_floats(8, D.n_text_head, (int)T));
-        s->fsplit = dev_alloc<float>(flash_split_scratch_floats(s->max_rows, D.n_text_head, wlk_session::kFlashSplits));
+        s->fsplit = dev_alloc<float>(flash_split_scratch_floats(s->max_rows, D.n_text_head, wlk_session::kFlashSplitsMax));
         // partial softmax states of the encoder attention's key splits (<= 8 per (query, head))
         s->esplit = dev_alloc<float>(flash_split_scratch_floats(D.n_audio_ctx, D.n_audio_head, 8));
         s->z = dev_alloc<float>((size_t)beam * std::max(m->n_align, 1) * T);
@@ -919,6 +919,18 @@ int wlk_encode(wlk_session* s, int32_t* content_mel_len) {
     });
 }
 
+// Key ranges of the decoder prefill's cross-attention (one workgroup per 32 prompt rows x head x range, partial softmax
+// states folded by flash_merge_kernel in range order).  The count is part of the arithmetic (it groups the key sums): the
+// same for a session alone and stacked with others.
+int wlk_session::flash_splits() {
+    static const int n = [] {
+        const char* e = getenv("WLK_FLASH_SPLITS");
+        const int v = e ? atoi(e) : 6;
+        return v < 1 ? 1 : (v > kFlashSplitsMax ? kFlashSplitsMax : v);
+    }();
+    return n;
+}
+
 // ---- decode ---------------------------------------------------------------------------------
 // Enqueue one decoder forward on the session stream.  Everything that changes from call to call
 // (tokens, alignment-window row map, cache offset) is read from the pinned staging block through
@@ -1003,7 +1015,7 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
             fa.head_rank = ranks_l; fa.ring = s->ring; fa.ring_row = s->ring_row;
             fa.beam_of_row = s->beam_of_row; fa.ring_rows = s->ring_rows; fa.n_beam = s->beam;
             if (((R + 31) / 32) * H < 256) {   // few query tiles: spread the 1500 keys over more workgroups
-                fa.k_splits = wlk_session::kFlashSplits;
+                fa.k_splits = wlk_session::flash_splits();
                 fa.part_o = s->fsplit;
                 fa.part_m = fa.part_o + (size_t)s->max_rows * H * fa.k_splits * 64;
                 fa.part_l = fa.part_m + (size_t)s->max_rows * H * fa.k_splits;
@@ -1103,7 +1115,7 @@ extern "C++" void wlk_prefill_ws_alloc(const wlk_model* m, wlk_prefill_ws& ws, i
     ws.dmlp = dev_alloc<float>(R * 4 * d);
     ws.hsel = dev_alloc<float>((size_t)2 * max_sessions * d);
     ws.logits = dev_alloc<float>((size_t)8 * V);
-    ws.part = dev_alloc<float>(flash_split_scratch_floats((int)R, (int)H, wlk_session::kFlashSplits));
+    ws.part = dev_alloc<float>(flash_split_scratch_floats((int)R, (int)H, wlk_session::kFlashSplitsMax));
     ws.rows_dev = reinterpret_cast<StepRow*>(dev_alloc<char>(R * sizeof(StepRow)));
     ws.tiles_dev = reinterpret_cast<StepRow*>(dev_alloc<char>(R / 32 * sizeof(StepRow)));
     ws.ring_row_dev = dev_alloc<int>(R);
@@ -1213,7 +1225,7 @@ extern "C++" void wlk_prefill_group(const std::vector<wlk_prefill_item*>& items,
         fa.head_rank = m->n_align > 0 ? m->head_rank + (size_t)i * H : nullptr;
         fa.ring = nullptr; fa.ring_row = ws.ring_row_dev; fa.beam_of_row = ws.zeros_dev;
         fa.ring_rows = items[0]->s->ring_rows; fa.n_beam = 1;
-        fa.k_splits = wlk_session::kFlashSplits;
+        fa.k_splits = wlk_session::flash_splits();
         fa.part_o = ws.part;
         fa.part_m = fa.part_o + (size_t)R * H * fa.k_splits * 64;
         fa.part_l = fa.part_m + (size_t)R * H * fa.k_splits;

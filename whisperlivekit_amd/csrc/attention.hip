@@ -1029,11 +1029,19 @@ static void launch_flash(const LaunchCtx& ctx, const FlashArgs& a, const char* t
     KernelScope ks(ctx, tag, nb * 4.0 * a.Tq * (double)a.Tk * 64.0 * a.n_head,
                    nb * 4.0 * 64.0 * a.n_head * (2.0 * a.Tq + 2.0 * a.Tk));
     if (a.batch > 0 && (a.k_splits > 1 || a.head_rank)) throw std::invalid_argument("flash attention: plain form only when batched");
-    hipLaunchKernelGGL(flash_attention_kernel, dim3(q_tiles * a.n_head * a.k_splits, std::max(a.batch, 1)), dim3(256), lds,
-                       ctx.stream, a);
+    // no empty key range: a range is whole 128-key iterations, so 1500 keys are at most 12 ranges (a range without keys
+    // would hand the merge a (-inf, 0) state to fold)
+    FlashArgs b = a;
+    if (b.k_splits > 1) {
+        const int n_iter_all = (b.Tk + NWAVE * KT - 1) / (NWAVE * KT);
+        const int it_per = (n_iter_all + b.k_splits - 1) / b.k_splits;
+        b.k_splits = (n_iter_all + it_per - 1) / it_per;
+    }
+    hipLaunchKernelGGL(flash_attention_kernel, dim3(q_tiles * b.n_head * b.k_splits, std::max(b.batch, 1)), dim3(256), lds,
+                       ctx.stream, b);
     WLK_HIP(hipGetLastError());
-    if (a.k_splits > 1) {
-        hipLaunchKernelGGL(flash_merge_kernel, dim3(a.Tq, a.n_head), dim3(64), 0, ctx.stream, a);
+    if (b.k_splits > 1) {
+        hipLaunchKernelGGL(flash_merge_kernel, dim3(b.Tq, b.n_head), dim3(64), 0, ctx.stream, b);
         WLK_HIP(hipGetLastError());
     }
 }

@@ -445,6 +445,21 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kwave16_kernel(GemmArgs g) {
     Slab s0, s1;
     fetch(s0, 0);
     fetch(s1, 1);
+    // the epilogue's operands (bias, residual, cache position) travel with the first two slabs instead of behind the
+    // last fold: acc[r] is C[row = 4 (lane >> 4) + r][col = lane & 15] of the tile; absent operands read the weights
+    const int col = n0 + (lane & 15);
+    const int colc = min(col, g.N - 1);
+    const int row_base = m0 + 4 * g4;
+    const bool has_res = (g.flags & kGemmResidual) != 0;
+    float b = (g.bias ? g.bias + colc : g.W)[0];
+    float res[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) res[r] = (has_res ? g.R + (long)min(row_base + r, g.M - 1) * g.ldr + colc : g.W)[0];
+    int kv_off = (g.kcache ? g.kv_pos : reinterpret_cast<const int*>(g.W))[0];
+    pin_loaded(b);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pin_loaded(res[r]);
+    asm volatile("" : "+v"(kv_off));
     stash(s0, 0);
     __syncthreads();
     for (int ks = 0; ks < ns2; ks += 2) {
@@ -472,22 +487,18 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kwave16_kernel(GemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] += red[(w * 4 + r) * 64 + lane];
 
-    // acc[r] is C[row = 4 (lane >> 4) + r][col = lane & 15] of the tile
-    const int col = n0 + (lane & 15);
     if (col >= g.N) return;
-    const float b = g.bias ? g.bias[col] : 0.f;
+    if (!g.bias) b = 0.f;
     const bool do_scale = (g.flags & kGemmScaleCols) && (g.scale_period ? col % g.scale_period : col) < g.scale_cols;
-    const int row_base = m0 + 4 * g4;
     float* kv_dst = nullptr;
-    int kv_col = 0, kv_off = 0;
+    int kv_col = 0;
     if (g.kcache && col >= g.kv_d) {
         kv_dst = col < 2 * g.kv_d ? g.kcache : g.vcache;
         kv_col = col < 2 * g.kv_d ? col - g.kv_d : col - 2 * g.kv_d;
-        kv_off = *g.kv_pos;
     }
-    float res[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) res[r] = (g.flags & kGemmResidual) ? g.R[(long)min(row_base + r, g.M - 1) * g.ldr + col] : 0.f;
+    for (int r = 0; r < 4; ++r)
+        if (!has_res) res[r] = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = row_base + r;

@@ -225,7 +225,8 @@ struct wlk_session {
     float* qk_debug = nullptr;  // [L][max_rows][H][T]
     float* xsplit = nullptr;    // scratch of the split cross-attention (decode steps)
     float* fsplit = nullptr;    // scratch of the key-split flash attention (decoder prefill)
-    static constexpr int kFlashSplits = 6;
+    static constexpr int kFlashSplitsMax = 16;   // scratch is sized for this many key ranges
+    static int flash_splits();                   // key ranges of the prefill cross-attention (WLK_FLASH_SPLITS, default 6)
 
     // select scratch (device) + pinned host staging
     int *adj_row = nullptr, *src_rows = nullptr;   // adj_row: packed [rows | ids | deltas] of the current call

@@ -36,6 +36,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         g[i] = gamma[cc];
         b[i] = beta[cc];
     }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { pin_loaded(g[i]); pin_loaded(b[i]); }   // see layernorm_x3_kernel
+    __builtin_amdgcn_sched_barrier(0);
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
@@ -98,6 +101,15 @@ __global__ __launch_bounds__(256) void layernorm_x3_kernel(const float* __restri
         bc[j][0] = *reinterpret_cast<const float4*>(beta + at);
         bc[j][1] = *reinterpret_cast<const float4*>(beta + at + 4);
     }
+    // the ISA without this: v[0], v[1] -> wait -> the other loads -> statistics -> gamma / beta chunks inside the store's
+    // branch: three dependent memory round trips for one
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        pin_loaded(xc[j][0]); pin_loaded(xc[j][1]);
+        pin_loaded(gc[j][0]); pin_loaded(gc[j][1]);
+        pin_loaded(bc[j][0]); pin_loaded(bc[j][1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
@@ -118,13 +130,14 @@ __global__ __launch_bounds__(256) void layernorm_x3_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int q = lane + 64 * j;
-        if (q < n_chunks) {
-            const float o[8] = {(xc[j][0].x - mean) * rstd * gc[j][0].x + bc[j][0].x, (xc[j][0].y - mean) * rstd * gc[j][0].y + bc[j][0].y,
-                                (xc[j][0].z - mean) * rstd * gc[j][0].z + bc[j][0].z, (xc[j][0].w - mean) * rstd * gc[j][0].w + bc[j][0].w,
-                                (xc[j][1].x - mean) * rstd * gc[j][1].x + bc[j][1].x, (xc[j][1].y - mean) * rstd * gc[j][1].y + bc[j][1].y,
-                                (xc[j][1].z - mean) * rstd * gc[j][1].z + bc[j][1].z, (xc[j][1].w - mean) * rstd * gc[j][1].w + bc[j][1].w};
-            x3_store_chunk(yr + (long)q * 24, o);
-        }
+        // computed by every lane (a lane past the row holds chunk 0's values), only the store is conditional: operands that
+        // are used inside a branch only get their LOADS sunk into it by hipcc - a second memory round trip behind the
+        // statistics
+        const float o[8] = {(xc[j][0].x - mean) * rstd * gc[j][0].x + bc[j][0].x, (xc[j][0].y - mean) * rstd * gc[j][0].y + bc[j][0].y,
+                            (xc[j][0].z - mean) * rstd * gc[j][0].z + bc[j][0].z, (xc[j][0].w - mean) * rstd * gc[j][0].w + bc[j][0].w,
+                            (xc[j][1].x - mean) * rstd * gc[j][1].x + bc[j][1].x, (xc[j][1].y - mean) * rstd * gc[j][1].y + bc[j][1].y,
+                            (xc[j][1].z - mean) * rstd * gc[j][1].z + bc[j][1].z, (xc[j][1].w - mean) * rstd * gc[j][1].w + bc[j][1].w};
+        if (q < n_chunks) x3_store_chunk(yr + (long)q * 24, o);
     }
 }
 

@@ -30,6 +30,13 @@ __device__ __forceinline__ float4 ldg4(gcf_ptr p) {
     return make_float4(t.x, t.y, t.z, t.w);
 }
 
+// "This value exists here": an empty asm that reads and rewrites the registers.  hipcc sinks a load whose only uses sit
+// inside a branch INTO that branch (a dependent memory round trip behind whatever the kernel computes first) and hoists
+// single uses between the loads of a block (a wait in the middle of the issue stream); a pin after the last load of the
+// block, followed by __builtin_amdgcn_sched_barrier(0), keeps the whole block in front of the first wait.
+__device__ __forceinline__ void pin_loaded(float4& a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)); }
+__device__ __forceinline__ void pin_loaded(float& a) { asm volatile("" : "+v"(a)); }
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
