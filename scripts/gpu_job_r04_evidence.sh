@@ -6,6 +6,17 @@ O=gpurun_out/r04; mkdir -p $O; R=$PWD
 S=$(date +%s); timeout 1300 python -m pytest tests -q -m gpu 2>&1 | tail -6 > $O/pytest_gpu.log; echo "pytest gpu $(( $(date +%s) - S )) s: $(tail -1 $O/pytest_gpu.log)"
 cp gpurun_out/parity_report.json $O/ 2>/dev/null
 S=$(date +%s); timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.log; echo "default bench rc=$? $(( $(date +%s) - S )) s"
+# same-box calibration: boxes of this pool differ by up to 10 % (host, fabric, memory) - the round-3 library (kept beside the
+# tree, git-ignored) and the tree's library alternate on THIS box, short bench lines
+if [ -f whisperlivekit_amd/libwlk_hip_r3.so ]; then
+  BS="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-diarization --no-eight-streams"
+  : > $O/same_box_ab.txt
+  for i in 1 2; do
+    echo -n "tree   " >> $O/same_box_ab.txt; timeout 300 $BS 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'audio-s/s', d['ms_per_step'], 'ms per 30 s stream, parity_ok', d['parity_ok'])" >> $O/same_box_ab.txt
+    echo -n "round3 " >> $O/same_box_ab.txt; WLK_HIP_LIB=$PWD/whisperlivekit_amd/libwlk_hip_r3.so timeout 300 $BS 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'audio-s/s', d['ms_per_step'], 'ms per 30 s stream, parity_ok', d['parity_ok'])" >> $O/same_box_ab.txt
+  done
+  cat $O/same_box_ab.txt
+fi
 export TMPDIR=/tmp; cd /tmp
 B="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-diarization --no-eight-streams"
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/prof/stats -o st -- $B > $R/$O/prof_stats.log 2>&1

@@ -509,6 +509,29 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
     assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1])
 
 
+def test_prefill_gemm_fuses_the_layernorm():
+    """gemm_nt_f32_kwave16_kernel<NPL> (decoder prefill: ln1 -> qkv, lnx -> xq, ln2 -> fc1 in one launch) derives the row
+    statistics the way layernorm_kernel does and normalises with the same expression: LayerNorm launch + projection
+    launch, bit for bit, at every Whisper width and for ragged row counts."""
+    lib = _lib.load()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rng = np.random.default_rng(23)
+    for (M, N, K) in [(60, 1536, 512), (60, 512, 512), (61, 2048, 512), (9, 512, 512), (128, 1152, 384), (33, 768, 768),
+                      (17, 3072, 1024), (60, 1280, 1280)]:
+        a = (rng.standard_normal((M, K)) * 3 + 0.5).astype(np.float32)
+        w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32)
+        g = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+        be = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        fused = np.empty((M, N), np.float32)
+        assert lib.wlk_diag_linear_ln(vp(a), vp(w), vp(b), vp(g), vp(be), M, N, K, 0, vp(fused)) == 0, (lib.wlk_diag_last_error(), M, N, K)
+        y = np.empty((M, K), np.float32)
+        assert lib.wlk_diag_layernorm(vp(a), vp(g), vp(be), M, K, vp(y)) == 0
+        two = np.empty((M, N), np.float32)
+        assert lib.wlk_diag_linear(vp(y), K, M * K, vp(w), vp(b), None, N, M, N, K, 0, 1.0, 0, 0, vp(two)) == 0
+        assert np.array_equal(fused, two), (M, N, K, float(np.abs(fused - two).max()))
+
+
 def test_valu_wave_butterflies_equal_the_shuffle_loops():
     """csrc/wave_ops.h: sum / max / 16-lane sum / xor exchanges / arg-max through DPP and v_permlane{16,32}_swap against
     the __shfl_xor loops they replace in every latency-bound kernel - bit for bit, on values whose sums round."""
@@ -583,6 +606,24 @@ def test_merge_folded_into_out_projection_is_bit_identical(monkeypatch, case):
     separate = run()
     assert folded == separate
     assert sum(len(steps) for _, steps in folded[0]) > 20
+
+
+@pytest.mark.parametrize("case", ["micro_12s", "base_4s", "micro_prompt"])
+def test_prefill_layernorm_fused_into_the_projection_is_bit_identical(monkeypatch, case):
+    """WLK_PREFILL_LN_FUSE=1: the decoder prefill's three LayerNorm launches per layer run inside the 16 x 16 projection
+    kernel - same statistics, same expression, so whole streams keep every token, frame and log-prob sum."""
+    def run():
+        g, proc, got = replay_stream(case, make_hip_processor)
+        trace = [(r["content_mel_len"], [(s.get("token"), s.get("frame"), s.get("sum_logprob")) for s in r["steps"]])
+                 for r in proc.trace]
+        words = [[(t.start, t.end, t.text) for t in toks] for _, toks, _ in got]
+        proc.close()
+        return trace, words
+    separate = run()
+    monkeypatch.setenv("WLK_PREFILL_LN_FUSE", "1")
+    fused = run()
+    assert fused == separate
+    assert sum(len(steps) for _, steps in fused[0]) > 10
 
 
 def test_transcribe_wav_script_streams_a_file(tmp_path):

@@ -689,6 +689,9 @@ static void transformer_mlp(const LaunchCtx& c, const LayerW& L, float* x, float
     if (gemv_applicable(rows, d)) {
         g.A = x; g.ln_gamma = L.ln2w; g.ln_beta = L.ln2b;
         launch_gemv(c, g, "dec_ln2_fc1");
+    } else if (gemm_fuses_layernorm(rows, 4 * d, d)) {   // decoder prefill: see gemm_nt_f32_kwave16_kernel
+        g.A = x; g.ln_gamma = L.ln2w; g.ln_beta = L.ln2b;
+        launch_gemm(c, g, "dec_ln2_fc1");
     } else {
         launch_layernorm(c, x, d, L.ln2w, L.ln2b, h, d, rows, d, t_ln);
         g.A = h;
@@ -971,6 +974,10 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
             g.A = s->dx; g.ln_gamma = L.ln1w; g.ln_beta = L.ln1b;
             g.kcache = kc; g.vcache = vc; g.kv_pos = s->d_offset; g.kv_d = d; g.kv_ctx = ctx_len;
             launch_gemv(c, g, "dec_ln1_qkv_kv");
+        } else if (gemm_fuses_layernorm(R, 3 * d, d)) {   // prompt rows: the 16 x 16 kernel normalises its A rows itself
+            g.A = s->dx; g.ln_gamma = L.ln1w; g.ln_beta = L.ln1b;
+            g.kcache = kc; g.vcache = vc; g.kv_pos = s->d_offset; g.kv_d = d; g.kv_ctx = ctx_len; g.kv_ntok = n_tok;
+            launch_gemm(c, g, "dec_ln1_qkv");
         } else {
             launch_layernorm(c, s->dx, d, L.ln1w, L.ln1b, s->dh, d, R, d, "dec_ln1");
             g.A = s->dh;
@@ -998,6 +1005,9 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
         } else if (fused) {
             q.A = s->dx; q.ln_gamma = L.lnxw; q.ln_beta = L.lnxb;
             launch_gemv(c, q, "dec_lnx_xq");
+        } else if (gemm_fuses_layernorm(R, d, d)) {
+            q.A = s->dx; q.ln_gamma = L.lnxw; q.ln_beta = L.lnxb;
+            launch_gemm(c, q, "dec_lnx_xq");
         } else {
             launch_layernorm(c, s->dx, d, L.lnxw, L.lnxb, s->dh, d, R, d, "dec_lnx");
             q.A = s->dh;
@@ -1208,15 +1218,27 @@ extern "C++" void wlk_prefill_group(const std::vector<wlk_prefill_item*>& items,
         g.force_kwave = true;
         launch_gemm(c, g, tag);
     };
+    // LayerNorm + projection: one launch where the 16 x 16 kernel takes it (the same rule as a session's own prefill, so
+    // that a stacked row gets its solo arithmetic - which it would either way: the fused statistics are the kernel's)
+    auto ln_linear = [&](const float* gamma, const float* beta, const float* W, const float* bias, float* C, long ldc, int N,
+                         int flags, float sc, int sc_cols, const char* t_ln, const char* tag) {
+        if (gemm_fuses_layernorm(R, N, d)) {
+            GemmArgs g;
+            g.A = ws.dx; g.lda = d; g.W = W; g.bias = bias; g.C = C; g.ldc = ldc; g.M = R; g.N = N; g.K = d;
+            g.flags = flags; g.scale = sc; g.scale_cols = sc_cols; g.ln_gamma = gamma; g.ln_beta = beta;
+            launch_gemm(c, g, tag);
+        } else {
+            launch_layernorm(c, ws.dx, d, gamma, beta, ws.dh, d, R, d, t_ln);
+            linear(ws.dh, d, W, bias, C, ldc, N, d, flags, nullptr, sc, sc_cols, tag);
+        }
+    };
     for (int i = 0; i < L; ++i) {
         const LayerW& W = m->dec_layers[i];
-        launch_layernorm(c, ws.dx, d, W.ln1w, W.ln1b, ws.dh, d, R, d, "dec_ln1");
-        linear(ws.dh, d, W.qkvw, W.qkvb, ws.dqkv, 3 * d, 3 * d, d, kGemmScaleCols, nullptr, scale, 2 * d, "dec_qkv");
+        ln_linear(W.ln1w, W.ln1b, W.qkvw, W.qkvb, ws.dqkv, 3 * d, 3 * d, kGemmScaleCols, scale, 2 * d, "dec_ln1", "dec_qkv");
         launch_kv_append_rows(c, ws.dqkv, ws.rows_dev, (long)(i * cache_layer), R, d);
         launch_decoder_self_attention_rows(c, ws.dqkv, ws.rows_dev, (long)(i * cache_layer), ws.datt, R, d, H, D.n_text_ctx);
         linear(ws.datt, d, W.outw, W.outb, ws.dx, d, d, d, kGemmResidual, ws.dx, 1.f, 0, "dec_out");
-        launch_layernorm(c, ws.dx, d, W.lnxw, W.lnxb, ws.dh, d, R, d, "dec_lnx");
-        linear(ws.dh, d, W.xqw, W.xqb, ws.dq, d, d, d, kGemmScaleCols, nullptr, scale, d, "dec_xq");
+        ln_linear(W.lnxw, W.lnxb, W.xqw, W.xqb, ws.dq, d, d, kGemmScaleCols, scale, d, "dec_lnx", "dec_xq");
         FlashArgs fa;
         fa.q = ws.dq; fa.ldq = d;
         fa.k = nullptr; fa.v = nullptr; fa.ldkv = (long)L * 2 * d;
@@ -1231,8 +1253,7 @@ extern "C++" void wlk_prefill_group(const std::vector<wlk_prefill_item*>& items,
         fa.part_l = fa.part_m + (size_t)R * H * fa.k_splits;
         launch_prefill_cross_attention(c, fa);
         linear(ws.datt, d, W.xoutw, W.xoutb, ws.dx, d, d, d, kGemmResidual, ws.dx, 1.f, 0, "dec_xout");
-        launch_layernorm(c, ws.dx, d, W.ln2w, W.ln2b, ws.dh, d, R, d, "dec_ln2");
-        linear(ws.dh, d, W.fc1w, W.fc1b, ws.dmlp, 4 * d, 4 * d, d, kGemmGelu, nullptr, 1.f, 0, "dec_fc1");
+        ln_linear(W.ln2w, W.ln2b, W.fc1w, W.fc1b, ws.dmlp, 4 * d, 4 * d, kGemmGelu, 1.f, 0, "dec_ln2", "dec_fc1");
         linear(ws.dmlp, 4 * d, W.fc2w, W.fc2b, ws.dx, d, d, 4 * d, kGemmResidual, ws.dx, 1.f, 0, "dec_fc2");
     }
     // ---- per session: the alignment heads' raw scores softmaxed in place; final LayerNorm of the last and the sot row

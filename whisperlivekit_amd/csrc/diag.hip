@@ -180,8 +180,9 @@ int wlk_diag_linear_ln(const float* a, const float* w, const float* bias, const 
         g.A = A.p; g.lda = k; g.W = W.p; g.bias = B.p; g.C = Cc.p; g.ldc = n; g.M = m; g.N = n; g.K = k;
         g.ln_gamma = G.p; g.ln_beta = Bt.p;
         LaunchCtx ctx;
-        (void)force_gemv;   // only the weight-streaming path fuses the LayerNorm
-        launch_gemv(ctx, g, "diag_gemv_ln");
+        (void)force_gemv;
+        if (m <= 8) launch_gemv(ctx, g, "diag_gemv_ln");     // decode steps: the weight-streaming kernels
+        else launch_gemm(ctx, g, "diag_gemm_ln");            // prompt rows: the 16 x 16 kernel (throws where it does not apply)
         WLK_HIP(hipDeviceSynchronize());
         WLK_HIP(hipMemcpy(c, Cc.p, (size_t)m * n * sizeof(float), hipMemcpyDeviceToHost));
     });

@@ -377,8 +377,17 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kwave_kernel(GemmArgs g) {
 // Every wave feeds the k values of its quarter in the order the 32 x 32 x 2 sequence accumulates them (k-group s: 8s,
 // 8s+4, 8s+1, 8s+5 | 8s+2, 8s+6, 8s+3, 8s+7), and the four partials are folded in wave order as above.
 // -------------------------------------------------------------------------------------------------
+// NPL > 0: the LayerNorm in front of the projection (ln1 -> qkv, lnx -> xq, ln2 -> fc1) is part of the kernel.  K = 64 NPL is
+// the model width; each wave derives mean and rstd of four of the tile's sixteen rows exactly as layernorm_kernel does
+// (lane-strided elements summed in index order, butterfly fold, two passes) while the first two slabs are in flight, and
+// the A values are normalised - (x - mean) * rstd * gamma + beta, the same expression - on their way into LDS.  Bit for
+// bit the LayerNorm launch + this kernel (tests/test_gpu_parity.py::test_prefill_gemm_fuses_the_layernorm); 18 launches
+// less per prefill.
+template <int NPL>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kwave16_kernel(GemmArgs g) {
     WLK_PIN_GEMM_ARGS(g);
+    constexpr bool LN = NPL > 0;
+    __shared__ float ln_stat[LN ? 32 : 1];
     constexpr int KW = 4, SLAB = BK * KW, SUB = 16 * LDS_LD;
     __shared__ __attribute__((aligned(16))) float As[2][KW * SUB];
     __shared__ __attribute__((aligned(16))) float Ws[2][KW * SUB];
@@ -405,6 +414,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kwave16_kernel(GemmArgs g) {
     }
     struct Slab {
         float4 a[2], w[2];
+        float4 ga, be;      // LN: gamma / beta of this thread's four k columns of the slab
     };
     auto fetch = [&](Slab& st, int ks) {
         const int k0 = ks * SLAB;
@@ -419,10 +429,25 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kwave16_kernel(GemmArgs g) {
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)(in ? w_byte[i] + (unsigned)k0 * 4u : kOob), 0, 0);
             st.w[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
+        if constexpr (LN) {
+            const int kk = min(k0 + kcol, g.K - 4);
+            st.ga = *reinterpret_cast<const float4*>(g.ln_gamma + kk);
+            st.be = *reinterpret_cast<const float4*>(g.ln_beta + kk);
+        }
     };
+    [[maybe_unused]] float ln_mean[2] = {0.f, 0.f}, ln_rstd[2] = {1.f, 1.f};
     auto stash = [&](const Slab& st, int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&As[buf][lds_at[i]]) = st.a[i];
+        for (int i = 0; i < 2; ++i) {
+            float4 a4 = st.a[i];
+            if constexpr (LN) {
+                a4.x = (a4.x - ln_mean[i]) * ln_rstd[i] * st.ga.x + st.be.x;
+                a4.y = (a4.y - ln_mean[i]) * ln_rstd[i] * st.ga.y + st.be.y;
+                a4.z = (a4.z - ln_mean[i]) * ln_rstd[i] * st.ga.z + st.be.z;
+                a4.w = (a4.w - ln_mean[i]) * ln_rstd[i] * st.ga.w + st.be.w;
+            }
+            *reinterpret_cast<float4*>(&As[buf][lds_at[i]]) = a4;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&Ws[buf][lds_at[i]]) = st.w[i];
     };
@@ -456,10 +481,50 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kwave16_kernel(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) res[r] = (has_res ? g.R + (long)min(row_base + r, g.M - 1) * g.ldr + colc : g.W)[0];
     int kv_off = (g.kcache ? g.kv_pos : reinterpret_cast<const int*>(g.W))[0];
+    // LN: rows m0 + 4 wave + q - layernorm_kernel's statistics, all four rows' elements requested together (and before the
+    // pins below: a pin waits for what it names)
+    [[maybe_unused]] float v[4][LN ? NPL : 1];
+    if constexpr (LN) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float* xr = g.A + (long)min(m0 + 4 * wave + q, g.M - 1) * g.lda;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) v[q][i] = xr[lane + 64 * i];
+        }
+    }
     pin_loaded(b);
 #pragma unroll
     for (int r = 0; r < 4; ++r) pin_loaded(res[r]);
     asm volatile("" : "+v"(kv_off));
+    if constexpr (LN) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) sum += v[q][i];
+            sum = wave_sum(sum);
+            const float mean = sum / (float)g.K;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                const float t = v[q][i] - mean;
+                sq += t * t;
+            }
+            sq = wave_sum(sq);
+            const float rstd = 1.0f / sqrtf(sq / (float)g.K + 1e-5f);
+            if (lane == 0) {
+                ln_stat[2 * (4 * wave + q)] = mean;
+                ln_stat[2 * (4 * wave + q) + 1] = rstd;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (tid >> 5) + 8 * i;
+            ln_mean[i] = ln_stat[2 * row];
+            ln_rstd[i] = ln_stat[2 * row + 1];
+        }
+    }
     stash(s0, 0);
     __syncthreads();
     for (int ks = 0; ks < ns2; ks += 2) {
@@ -1146,6 +1211,30 @@ bool gemm_takes_kwave(int M, int N, int K) {
 
 bool gemm_takes_ksplit(int M, int N, int K) { return ksplit_tile(M, N, K).tm != 0; }
 
+// prompt-sized row counts (decoder prefill): 16 x 16 tiles - four times the workgroups, a quarter of the chain each
+static bool kwave16_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("WLK_KWAVE16");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+// Can launch_gemm take the LayerNorm in front of this projection (GemmArgs::ln_gamma / ln_beta, A = the un-normalised rows)?
+// Only the 16 x 16 prefill kernel does, for K = a Whisper width.
+static bool gemm_can_fuse_layernorm(int M, int N, int K) {
+    return kwave16_enabled() && M > 8 && M <= 128 && gemm_takes_kwave(M, N, K) && ksplit_tile(M, N, K).tm == 0 &&
+           (K == 384 || K == 512 || K == 768 || K == 1024 || K == 1280);
+}
+// ... and do the decoder's prefill chains ask for it?  Measured neutral (profiles/r04p_ab_prefill_ln_fuse.txt: 18 launches
+// less per prefill, but 128-512 workgroups each re-derive the statistics of their sixteen rows - 200.7-201.7 fused against
+// 200.5-203.5 audio-s/s, 8 streams 358-363 either way), so the separate launch stays the default; WLK_PREFILL_LN_FUSE=1
+// turns the fused form on (bit-identical: tests/test_gpu_parity.py::test_prefill_gemm_fuses_the_layernorm).
+bool gemm_fuses_layernorm(int M, int N, int K) {
+    const char* e = getenv("WLK_PREFILL_LN_FUSE");     // read per call: the parity test flips it inside one process
+    return e && e[0] == '1' && gemm_can_fuse_layernorm(M, N, K);
+}
+
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (g.M <= 0 || g.N <= 0) return;
     if (g.K % 4 != 0 || g.lda % 4 != 0) throw std::invalid_argument("gemm: K and lda must be multiples of 4");
@@ -1159,6 +1248,8 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     // encoder-sized problems: one tile per compute unit, K split over the waves (force_kernel 3 = the 64x64 kernel)
     const KSplitTile kt = (want_kwave || g.kcache || g.force_kernel == 3) ? KSplitTile{0, 0, 0} : ksplit_tile(g.M, g.N, g.K, g.force_kernel == 4);
     if (g.force_kernel == 4 && !kt.tm) throw std::invalid_argument("gemm: the k-split kernel does not take this shape");
+    if (g.ln_gamma && !(gemm_can_fuse_layernorm(g.M, g.N, g.K) && !kt.tm && g.force_kernel == 0 && g.batch == 0))
+        throw std::invalid_argument("gemm: only the 16 x 16 prefill kernel takes the LayerNorm (gemm_fuses_layernorm)");
     if (kt.tm) {
         // probe override (scripts/gemm_tile_probe.py): WLK_KSPLIT_FORCE="tm,tn,ks" (ks 64: compiler-scheduled k-split; 103 / 104: k-pipe)
         static const KSplitTile forced = [] {
@@ -1182,14 +1273,18 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (g.kcache && !(gemm_takes_kwave(g.M, g.N, g.K) || want_kwave))
         throw std::invalid_argument("gemm: fused KV-cache append is only available on the k-wave path");
     if ((gemm_takes_kwave(g.M, g.N, g.K) && g.force_kernel != 3) || (want_kwave && g.K >= 256)) {
-        // prompt-sized row counts (decoder prefill): 16 x 16 tiles - four times the workgroups, a quarter of the chain each
-        static const bool kwave16 = [] {
-            const char* e = getenv("WLK_KWAVE16");
-            return !(e && e[0] == '0');
-        }();
-        if (kwave16 && g.M <= 128 && g.force_kernel != 2) {
+        if (kwave16_enabled() && g.M <= 128 && g.force_kernel != 2) {
             const long tiles16 = (long)((g.N + 15) / 16) * ((g.M + 15) / 16);
-            hipLaunchKernelGGL(gemm_nt_f32_kwave16_kernel, dim3((unsigned)tiles16), dim3(256), 0, ctx.stream, g);
+            const dim3 grid((unsigned)tiles16);
+            switch (g.ln_gamma ? g.K / 64 : 0) {
+                case 0: hipLaunchKernelGGL(gemm_nt_f32_kwave16_kernel<0>, grid, dim3(256), 0, ctx.stream, g); break;
+                case 6: hipLaunchKernelGGL(gemm_nt_f32_kwave16_kernel<6>, grid, dim3(256), 0, ctx.stream, g); break;
+                case 8: hipLaunchKernelGGL(gemm_nt_f32_kwave16_kernel<8>, grid, dim3(256), 0, ctx.stream, g); break;
+                case 12: hipLaunchKernelGGL(gemm_nt_f32_kwave16_kernel<12>, grid, dim3(256), 0, ctx.stream, g); break;
+                case 16: hipLaunchKernelGGL(gemm_nt_f32_kwave16_kernel<16>, grid, dim3(256), 0, ctx.stream, g); break;
+                case 20: hipLaunchKernelGGL(gemm_nt_f32_kwave16_kernel<20>, grid, dim3(256), 0, ctx.stream, g); break;
+                default: throw std::invalid_argument("gemm: fused LayerNorm needs K = 384 / 512 / 768 / 1024 / 1280");
+            }
         } else {
             hipLaunchKernelGGL(gemm_nt_f32_kwave_kernel, dim3((unsigned)tiles32), dim3(256), 0, ctx.stream, g);
         }
@@ -1606,13 +1701,10 @@ static bool gemv1_enabled() {
 // 6.9 + 6.9 for merge kernel + plain GEMV (profiles/r04m_large_v3_folds.txt).  Default: K <= 512; WLK_MERGE_FOLD=1 folds
 // wherever the kernel can, WLK_NO_MERGE_FOLD=1 never.
 bool gemv1_folds_merge(int K) {
-    static const bool never = getenv("WLK_NO_MERGE_FOLD") != nullptr;
-    static const bool always = [] {
-        const char* e = getenv("WLK_MERGE_FOLD");
-        return e && e[0] == '1';
-    }();
-    if (never || !gemv1_enabled() || K > 2048 || K % 64 != 0) return false;
-    return always || K <= 512;
+    // read per call: test_merge_folded_into_out_projection_is_bit_identical flips the switch inside one process
+    if (getenv("WLK_NO_MERGE_FOLD") != nullptr || !gemv1_enabled() || K > 2048 || K % 64 != 0) return false;
+    const char* e = getenv("WLK_MERGE_FOLD");
+    return (e && e[0] == '1') || K <= 512;
 }
 
 void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
