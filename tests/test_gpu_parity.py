@@ -590,10 +590,14 @@ def test_hipgraph_replay_equals_eager_launches(monkeypatch):
     assert with_graph == eager
 
 
-@pytest.mark.parametrize("case", ["micro_12s", "tiny_6s", "base_4s", "micro_cif"])
+@pytest.mark.parametrize("case", ["micro_12s", "tiny_6s", "base_4s", "micro_cif", "large_v3_2s"])
 def test_merge_folded_into_out_projection_is_bit_identical(monkeypatch, case):
     """Beam-1 steps: the merge of the 8 key splits of the cross-attention is the A-operand load of the out-projection
-    GEMV (and spare workgroups write the alignment rows) instead of a kernel of its own - same arithmetic, same order."""
+    GEMV (and spare workgroups write the alignment rows) instead of a kernel of its own - same arithmetic, same order.
+    Up to d = 512 every wave merges its own slice (gemv1_f32_kernel<MG>), beyond it the workgroup merges once through LDS
+    (gemv1_mgl_f32_kernel: large-v3)."""
+    if not H.golden_exists(f"stream_{case}.json"):
+        pytest.skip(f"golden stream {case} not generated")
     def run():
         g, proc, got = replay_stream(case, make_hip_processor)
         trace = [(r["content_mel_len"], [(s.get("token"), s.get("frame"), s.get("sum_logprob")) for s in r["steps"]])
@@ -605,7 +609,7 @@ def test_merge_folded_into_out_projection_is_bit_identical(monkeypatch, case):
     monkeypatch.setenv("WLK_NO_MERGE_FOLD", "1")
     separate = run()
     assert folded == separate
-    assert sum(len(steps) for _, steps in folded[0]) > 20
+    assert sum(len(steps) for _, steps in folded[0]) > (5 if case == "large_v3_2s" else 20)
 
 
 @pytest.mark.parametrize("case", ["micro_12s", "base_4s", "micro_prompt"])

@@ -1690,6 +1690,126 @@ __global__ __launch_bounds__(256) void gemv1_f32_kernel(const float* __restrict_
     }
 }
 
+// The merged operand at the widths where one wave per output feature cannot afford to re-derive it (d > 512: small,
+// medium, large): the WORKGROUP merges the cross-attention's split partials once - thread t owns float4 chunks t and
+// t + 256 of the attention output - and hands the row to its four waves through LDS, while every wave's weight row is
+// already in flight.  41 KB of partials per workgroup instead of per wave, 100 VGPRs instead of 440.  Arithmetic: the
+// merge is cross_merge_kernel's / gemv1_f32_kernel<MG>'s statement for statement, the dot product gemv1_f32_kernel's -
+// bit-identical to the separate merge launch + plain GEMV it replaces (tests/test_gpu_parity.py::
+// test_merge_folded_into_out_projection_is_bit_identical runs small / large shapes through both).
+template <int UB>
+__global__ __launch_bounds__(256) void gemv1_mgl_f32_kernel(const float* __restrict__ W, int K, int N,
+                                                            const float* __restrict__ bias, const float* R, Gemv1Tail t,
+                                                            Gemv1Merge mg) {
+    __shared__ __attribute__((aligned(16))) float xs[2048];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int K4 = K >> 2;
+    if ((int)blockIdx.x >= (int)gridDim.x - mg.side_blocks) {
+        // side job (cross_merge_kernel's tail): softmax row of the k-th alignment head of this layer -> alignment window
+        const int head = mg.side_heads[(int)blockIdx.x - ((int)gridDim.x - mg.side_blocks)];
+        const int rank = mg.head_rank[head];
+        const int ring_row = mg.ring_row[0], beam = mg.beam_of_row[0];
+        const long base = (long)head * kCrossSplitWays;
+        float pmv[kCrossSplitWays], plv[kCrossSplitWays];
+#pragma unroll
+        for (int s = 0; s < kCrossSplitWays; ++s) { pmv[s] = mg.pm[base + s]; plv[s] = mg.pl[base + s]; }
+        const float* srow = mg.scores + (long)head * mg.T;
+        constexpr int kMaxPer = 8;
+        float sv[kMaxPer];
+#pragma unroll
+        for (int i = 0; i < kMaxPer; ++i) {
+            const int j = threadIdx.x + 256 * i;
+            sv[i] = srow[j < mg.T ? j : 0];
+        }
+        float M = pmv[0];
+#pragma unroll
+        for (int s = 1; s < kCrossSplitWays; ++s) M = fmaxf(M, pmv[s]);
+        float L = 0.f;
+#pragma unroll
+        for (int s = 0; s < kCrossSplitWays; ++s) L += plv[s] * expf(pmv[s] - M);
+        float* dst = mg.ring + (((long)rank * mg.n_beam + beam) * mg.ring_rows + ring_row) * (long)mg.T;
+#pragma unroll
+        for (int i = 0; i < kMaxPer; ++i) {
+            const int j = threadIdx.x + 256 * i;
+            if (j < mg.T) dst[j] = expf(sv[i] - M) / L;
+        }
+        for (int j = threadIdx.x + 256 * kMaxPer; j < mg.T; j += 256) dst[j] = expf(srow[j] - M) / L;
+        return;
+    }
+    const int n = min((int)blockIdx.x * 4 + wave, N - 1);      // (a wave past the last feature recomputes it and stores nothing)
+    // ---- every load of the kernel, before the first wait -------------------------------------------------------------
+    float4 w[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) w[u] = *reinterpret_cast<const float4*>(W + (long)n * K + (lane + 64 * u) * 4);   // K = 256 UB
+    constexpr int NCH = (UB + 3) / 4;                          // float4 chunks of the row per thread
+    float pmv[NCH][kCrossSplitWays], plv[NCH][kCrossSplitWays];
+    float4 pov[NCH][kCrossSplitWays];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = (int)threadIdx.x + 256 * j;
+        const int cc = c < K4 ? c : 0;
+        const int head = (4 * cc) >> 6, dd = (4 * cc) & 63;
+        const long base = (long)head * kCrossSplitWays;
+#pragma unroll
+        for (int s = 0; s < kCrossSplitWays; ++s) {
+            pmv[j][s] = mg.pm[base + s];
+            plv[j][s] = mg.pl[base + s];
+            pov[j][s] = *reinterpret_cast<const float4*>(mg.po + (base + s) * 64 + dd);
+        }
+    }
+    float bias_v = bias[n];
+    float res_v = R[n];
+    const int kv_pos = *t.kv_pos;
+    WLK_PIN_S(t.C); WLK_PIN_S(t.kcache); WLK_PIN_S(t.vcache); WLK_PIN_S(t.flags); WLK_PIN_S(t.scale);
+    WLK_PIN_S(t.scale_cols); WLK_PIN_S(t.kv_d); WLK_PIN_S(kv_pos);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- the merged row, once per workgroup ----------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        float M = pmv[j][0];
+#pragma unroll
+        for (int s = 1; s < kCrossSplitWays; ++s) M = fmaxf(M, pmv[j][s]);
+        float L = 0.f;
+        float f[kCrossSplitWays];
+#pragma unroll
+        for (int s = 0; s < kCrossSplitWays; ++s) {
+            f[s] = expf(pmv[j][s] - M);
+            L += plv[j][s] * f[s];
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int s = 0; s < kCrossSplitWays; ++s) {
+            const float4 o = pov[j][s];
+            acc.x += o.x * f[s]; acc.y += o.y * f[s]; acc.z += o.z * f[s]; acc.w += o.w * f[s];
+        }
+        const int c = (int)threadIdx.x + 256 * j;
+        if (c < K4) reinterpret_cast<float4*>(xs)[c] = make_float4(acc.x / L, acc.y / L, acc.z / L, acc.w / L);
+    }
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        const float4 x = reinterpret_cast<const float4*>(xs)[lane + 64 * u];
+        acc = fmaf(w[u].x, x.x, acc);
+        acc = fmaf(w[u].y, x.y, acc);
+        acc = fmaf(w[u].z, x.z, acc);
+        acc = fmaf(w[u].w, x.w, acc);
+    }
+    acc = wave_sum(acc);
+    asm volatile("" ::"v"(bias_v), "v"(res_v));
+    if (lane == 0 && (int)blockIdx.x * 4 + wave < N) {
+        float o = acc;
+        if (bias != W) o += bias_v;
+        if ((t.flags & kGemmScaleCols) && n < t.scale_cols) o *= t.scale;
+        if (t.flags & kGemmGelu) o = gelu_erf(o);
+        if (t.flags & kGemmRelu) o = fmaxf(o, 0.f);
+        if (t.flags & kGemmSwish) o = o / (1.0f + expf(-o));
+        if (t.flags & kGemmResidual) o += res_v;
+        t.C[n] = o;
+    }
+}
+
 static bool gemv1_enabled() {
     static const bool on = getenv("WLK_NO_GEMV1") == nullptr;
     return on;
@@ -1700,11 +1820,18 @@ static bool gemv1_enabled() {
 // launch out of the L2s and a launch saved; on large-v3 (K = 1280) 52 MB and one wave per SIMD: dec_xout 20 us against
 // 6.9 + 6.9 for merge kernel + plain GEMV (profiles/r04m_large_v3_folds.txt).  Default: K <= 512; WLK_MERGE_FOLD=1 folds
 // wherever the kernel can, WLK_NO_MERGE_FOLD=1 never.
+// From there to K = 2048 the workgroup-level form (gemv1_mgl_f32_kernel) takes over where K is a multiple of 256 (small,
+// medium, large); WLK_MERGE_FOLD_LDS=0 keeps merge kernel + plain GEMV at those widths.
+static bool gemv1_merge_through_lds(int K) {
+    const char* e = getenv("WLK_MERGE_FOLD_LDS");
+    const char* w = getenv("WLK_MERGE_FOLD");
+    return K > 512 && K <= 2048 && K % 256 == 0 && !(e && e[0] == '0') && !(w && w[0] == '1');
+}
 bool gemv1_folds_merge(int K) {
     // read per call: test_merge_folded_into_out_projection_is_bit_identical flips the switch inside one process
     if (getenv("WLK_NO_MERGE_FOLD") != nullptr || !gemv1_enabled() || K > 2048 || K % 64 != 0) return false;
     const char* e = getenv("WLK_MERGE_FOLD");
-    return (e && e[0] == '1') || K <= 512;
+    return (e && e[0] == '1') || K <= 512 || gemv1_merge_through_lds(K);
 }
 
 void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
@@ -1736,6 +1863,21 @@ void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
                       g.mg_beam_of_row, g.mg_T, g.mg_ring_rows, g.mg_n_beam, g.mg_side_blocks};
         if (g.mg_pm && g.mg_side_blocks > 0 && !g.mg_side_heads)
             throw std::invalid_argument("gemv: the merged operand's side blocks need the layer's alignment head list");
+        if (g.mg_pm && rpw == 1 && !g.kcache && gemv1_merge_through_lds(g.K)) {
+#define WLK_GEMV1_MGL(UBv)                                                                                             \
+    hipLaunchKernelGGL((gemv1_mgl_f32_kernel<UBv>), dim3(blocks), dim3(256), 0, ctx.stream, g.W, g.K, g.N, bias, res, t, mg)
+            switch (ub) {
+                case 3: WLK_GEMV1_MGL(3); break;
+                case 4: WLK_GEMV1_MGL(4); break;
+                case 5: WLK_GEMV1_MGL(5); break;
+                case 6: WLK_GEMV1_MGL(6); break;
+                case 8: WLK_GEMV1_MGL(8); break;
+                default: throw std::invalid_argument("gemv: no workgroup-merge instantiation for this width");
+            }
+#undef WLK_GEMV1_MGL
+            WLK_HIP(hipGetLastError());
+            return;
+        }
 #define WLK_GEMV1_F(UBv, RPWv, LNv, MGv, FULLv)                                                                         \
     hipLaunchKernelGGL((gemv1_f32_kernel<UBv, RPWv, LNv, MGv, FULLv>), dim3(blocks), dim3(256), 0, ctx.stream, g.W, g.A, \
                        g.K, g.N, g.ln_gamma, g.ln_beta, bias, res, t, mg)
