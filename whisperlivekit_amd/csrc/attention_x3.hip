@@ -11,7 +11,7 @@
 //           step 2 without any data movement between lanes.
 // Workgroup = (head, 64 queries), eight waves, all of them computing: wave (qs, ks) owns queries 16 qs .. 16 qs + 15 and
 // the key tiles t = ks (mod 2) (flash-style online softmax per wave, the two key streams of a query block merged at the
-// end); every wave also issues a sixth of the LDS-DMA that feeds a ring of three slots of two 32-key tiles (K tile
+// end); every wave also issues an eighth - six 1 KiB pieces - of the LDS-DMA that feeds a ring of three slots of two 32-key tiles (K tile
 // 12 KiB + V^T tile 12 KiB per stream); one workgroup barrier per pair of tiles.  Per tile and wave: 24
 // v_mfma_f32_16x16x32_bf16 for S^T, 24 for O^T += V^T P^T, an 8-value softmax per lane in between.
 #include <atomic>
