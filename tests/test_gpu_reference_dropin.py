@@ -1,8 +1,9 @@
 """The drop-in proven on the GPU: the REFERENCE's own SimulStreamingOnlineProcessor (only _create_alignatt
 overridden - whisperlivekit/simul_whisper/backend.py:61-71, the routing hook INTEGRATION.md describes) with the
 REFERENCE's own AlignAttBase.infer as the policy, over the real HIP hooks and a real HipWhisperModel, replaying golden
-streams the unmodified reference produced.  Needs a WhisperLiveKit tree next to the GPU: set WLK_REFERENCE_ROOT (the
-tree is not part of this repository and does not travel to the driver's box, where this module skips)."""
+streams the unmodified reference produced.  The reference's package comes from WLK_REFERENCE_ROOT, /root/reference, or -
+on the GPU box - from the archive `oracle/stage_reference.py` stages under git-ignored `oracle/_ref/` (test
+infrastructure, like the CPU baseline of bench.py; scripts/ref_stubs.py unpacks it outside the repository)."""
 import os
 import sys
 
@@ -13,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import ref_stubs  # noqa: E402
 
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not ref_stubs.reference_available(), reason="no WhisperLiveKit tree (WLK_REFERENCE_ROOT)")]
+              pytest.mark.skipif(not ref_stubs.reference_available(), reason="no WhisperLiveKit tree (WLK_REFERENCE_ROOT, /root/reference or oracle/_ref)")]
 
 import helpers as H  # noqa: E402
 
