@@ -240,10 +240,11 @@ __device__ __forceinline__ void publish_flag(unsigned* flag, unsigned seq) {
 
 __device__ __forceinline__ void topk_stage2_body(const SelPartial* __restrict__ parts, int k,
                                                  float* __restrict__ top_vals, int* __restrict__ top_ids, int row,
-                                                 const StepHostOut host = StepHostOut{}) {
+                                                 const StepHostOut host = StepHostOut{}, unsigned seq = 0) {
     const int lane = threadIdx.x;   // one lane per slice (the first wave of the workgroup)
     const SelPartial p = parts[(long)row * kSelBlocks + lane];
     float mx = wave_max(p.mx);
+    asm volatile("" : "+v"(seq));   // requested with the partials, not in front of the flag store at the very end
     float sum = p.mx > -INFINITY ? p.sum * expf(p.mx - mx) : 0.f;
     sum = wave_sum(sum);
     const float lse = logf(sum);
@@ -268,7 +269,7 @@ __device__ __forceinline__ void topk_stage2_body(const SelPartial* __restrict__ 
             }
         }
     }
-    if (host.result && lane == 0) publish_flag(&host.result[row].flag_topk, *host.seq);
+    if (host.result && lane == 0) publish_flag(&host.result[row].flag_topk, seq);
 }
 
 __global__ __launch_bounds__(64) void topk_stage2_kernel(const SelPartial* __restrict__ parts, int k,
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(256) void align_argmax_kernel(AlignArgs a) {
 
 // Step 2 variant for the common case (z of all alignment heads fits LDS): 1024 threads stage z with
 // coalesced loads once, then medians / head mean / arg-max run out of LDS.
-__device__ __forceinline__ void align_argmax_lds_body(AlignArgs a, int b, const StepHostOut host = StepHostOut{}) {
+__device__ __forceinline__ void align_argmax_lds_body(AlignArgs a, int b, const StepHostOut host = StepHostOut{}, unsigned seq = 0) {
     extern __shared__ __attribute__((aligned(16))) float zs[];   // [n_align][T]
     __shared__ float bestv[16];
     __shared__ int besti[16];
@@ -480,6 +481,7 @@ __device__ __forceinline__ void align_argmax_lds_body(AlignArgs a, int b, const 
     if (a.rows) a.content_len = a.rows[b].content_len;
     const float* zb = a.z + (long)b * a.n_align * a.T;
     for (int i = tid; i < a.n_align * a.T; i += 1024) zs[i] = zb[i];
+    asm volatile("" : "+v"(seq));   // requested with the z rows, not in front of the flag store at the very end
     __syncthreads();
     float bv = -INFINITY;
     int bi = 0x7fffffff;
@@ -515,7 +517,7 @@ __device__ __forceinline__ void align_argmax_lds_body(AlignArgs a, int b, const 
         a.frames[b] = frame;
         if (host.result) {
             host.result[b].frame = frame;
-            publish_flag(&host.result[b].flag_align, *host.seq);
+            publish_flag(&host.result[b].flag_align, seq);
         }
     }
 }
@@ -556,10 +558,14 @@ __global__ __launch_bounds__(256) void select_stage1_kernel(TopkArgs t, AlignArg
 
 __global__ __launch_bounds__(1024) void select_stage2_kernel(TopkArgs t, AlignArgs a) {
     WLK_PIN_SELECT_ARGS(t, a);
+    // the step's sequence number (echoed in the result flags) is requested here, not in front of the flag store at the
+    // very end of the step's last kernel - the host is waiting on exactly that store
+    unsigned seq = 0;
+    if (t.host.result) seq = *t.host.seq;     // (each role pins it behind its first batch of loads: one round trip with them)
     if ((int)blockIdx.x < a.n_beam) {
-        align_argmax_lds_body(a, blockIdx.x, t.host);
+        align_argmax_lds_body(a, blockIdx.x, t.host, seq);
     } else if ((int)blockIdx.x < a.n_beam + t.n_rows) {
-        if (threadIdx.x < 64) topk_stage2_body(t.parts, t.k, t.top_vals, t.top_ids, blockIdx.x - a.n_beam, t.host);
+        if (threadIdx.x < 64) topk_stage2_body(t.parts, t.k, t.top_vals, t.top_ids, blockIdx.x - a.n_beam, t.host, seq);
     } else {
         token_prob_body(t.ns_logits, t.n_vocab, t.ns_token, t.ns_probs, blockIdx.x - a.n_beam - t.n_rows);
     }
