@@ -142,7 +142,18 @@ typedef struct wlk_loop_params {
     int32_t no_speech_token;      /* < 0: no check */
     float no_speech_threshold;    /* cfg.nonspeech_prob */
     int32_t content_mel_len;      /* from wlk_encode, unclipped */
+    /* Teacher forcing of single decisions, for parity harnesses only (0 entries in production): when a decision of
+     * this library and the reference's differ inside an fp32 tie (two candidates closer than rounding), the harness
+     * replays the stream with the reference's choice forced at that step so that every later decision can still be
+     * compared.  Entry f applies to decode step force_step[f] of this loop (0 = the prefill's read-out): the attended
+     * frame becomes force_frame[f] (if >= 0); the selected token becomes force_token[f] (if >= 0) provided it is the
+     * runner-up of the step's top-2 and the winner is not end-of-text (the two are then swapped, log-probs included). */
+    int32_t n_force;              /* 0 .. WLK_MAX_FORCED */
+    int32_t force_step[4];
+    int32_t force_token[4];
+    int32_t force_frame[4];
 } wlk_loop_params;
+#define WLK_MAX_FORCED 4
 enum {
     WLK_STOP_NONE = 0,
     WLK_STOP_CONTEXT_FULL = 1,    /* tokens reached max_text_len */
@@ -211,6 +222,12 @@ int wlk_export(wlk_session* s, const char* what, float* host, uint64_t capacity,
 int wlk_prof_begin(wlk_session* s);
 int wlk_prof_end(wlk_session* s, int cap, const char** names, float* total_ms, int32_t* launches,
                  double* flops, double* bytes, int32_t* n_out);
+
+/* Wall time of the session's single-token decode steps so far (graph-replayed steps of wlk_decode_until_stop outside
+ * the batch engine): number of steps, nanoseconds from entering the step to holding its result (graph launch + the 46
+ * kernels + the flag wait), and the share of that spent inside hipGraphLaunch.  What bench.py's roofline.step divides the
+ * step's algorithmic bytes by. */
+int wlk_session_step_stats(wlk_session* s, uint64_t* steps, uint64_t* wall_ns, uint64_t* launch_ns);
 
 /* ---- a12 front end: log-mel features of the streaming Sortformer diarizer ----------------------
  * Replaces NeMo's AudioToMelSpectrogramPreprocessor.get_features as called at
@@ -286,6 +303,9 @@ int wlk_vad_stream_destroy(wlk_vad_stream* s);
 
 /* ---- diagnostics: one kernel on host data (used by the GPU parity tests only) ---------------- */
 const char* wlk_diag_last_error(void);
+/* environment switches the library caches on first use (WLK_PREFILL_LN_FUSE) are read again at their next use: for tests
+ * that flip one inside a process */
+int wlk_diag_env_refresh(void);
 /* c[m,n] = epilogue(a[m,k](row stride lda, a_floats floats in total) . w[n,k]^T + bias); flags:
  * 1 = exact-erf GELU, 2 = add r[m, ldr] after the activation, 4 = scale columns < scale_cols,
  * 8 = ReLU, 16 = Swish.  force_gemv: 0 = shape-based choice among the MFMA kernels, 1 = weight-streaming kernel
@@ -401,6 +421,11 @@ int wlk_diag_layernorm_x3(const float* x, const float* gamma, const float* beta,
  * its timing probe */
 int wlk_diag_encoder_attention_x3(const float* qkv, int t, int d, int n_head, float* out);
 int wlk_diag_encoder_attention_x3_time(int t, int d, int n_head, int reps, float* us_per_launch);
+/* the production operand route of that attention (qkv projection with the X3 epilogue -> attention) against the diagnostic
+ * one (fp32 projection -> x3 pack -> attention) on x [t][d], w [3 d][d], bias [3 d]: the two outputs [t][d] must be equal
+ * bit for bit */
+int wlk_diag_qkv_x3_attention(const float* x, const float* w, const float* bias, int t, int d, int n_head, float scale,
+                              float* out_epilogue, float* out_packed);
 
 #ifdef __cplusplus
 }

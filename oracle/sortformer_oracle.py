@@ -2,22 +2,34 @@
 TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import it; the product
 package never does).
 
-PARITY UNPINNED: the arithmetic restated here lives in NeMo (nemo-toolkit[asr] >=3,<4, pyproject.toml:80-83 of
-the reference; exact pin unknown, uv.lock is not in the tree), which is not installed where this code is
-built and measured, and the reference's own tests hold no numeric vectors for it
-(tests/test_sortformer_real_fixture.py is statistical and skipped without NeMo).  What follows restates
-the published algorithm of ``nemo.collections.asr.parts.preprocessing.features.FilterbankFeatures`` as
-configured at whisperlivekit/diarization/sortformer_backend.py:181-187:
+PARITY: PARTLY PINNED.  The arithmetic restated here lives in NeMo (nemo-toolkit[asr] >=3,<4, pyproject.toml:80-85
+of the reference; exact pin unknown, uv.lock is not in the tree), which is not installed where this code is built and
+measured, and the reference's own tests hold no numeric vectors for it (tests/test_sortformer_real_fixture.py is
+statistical and skipped without NeMo).  Since round 5 the front end and the FastConformer are pinned by the independent
+ports of those NeMo modules that ship with `transformers` (tests/golden/sortformer_hf_kat.npz, made by
+scripts/gen_golden_sortformer_hf.py; tests/test_sortformer_hf_golden.py):
+  * ``nemo_log_mel``  == ``ParakeetFeatureExtractor`` (log-mel, valid-frame rule, zero fill)          <= 2e-6
+  * ``pre_encode``, ``conformer_layer``, ``conformer_stack`` == ``ParakeetEncoder`` (stem / block / 17 blocks) <= 1e-5
+  * ``transformer_layer`` == ``BertEncoder``'s post-LN block (relu, eps 1e-5; an independent implementation of the same
+    published block, not a NeMo port)                                                                    <= 1e-5
+UNPINNED remainder: that NeMo wires its 18 Transformer blocks and the sigmoid head as restated, and the speaker-cache
+update (``streaming_update`` / ``compress_spkcache``; sortformer_backend.py:293-300).
+
+The front end restates ``nemo.collections.asr.parts.preprocessing.features.FilterbankFeatures`` as configured at
+whisperlivekit/diarization/sortformer_backend.py:181-187:
   window 25 ms (400 samples, symmetric hann), stride 10 ms, n_fft 512, 128 slaney mel bins 0-8000 Hz,
-  pre-emphasis 0.97, centred STFT with zero padding, power 2, log(x + 2^-24), normalize "NA", pad_to 0.
+  pre-emphasis 0.97, centred STFT with zero padding, power 2, log(x + 2^-24), normalize "NA", pad_to 0;
+  ``get_seq_len`` = len // hop valid frames, the frames behind them filled with pad_value 0.
 """
 import numpy as np
 import torch
 
 
 def nemo_log_mel(pcm: np.ndarray, filters: np.ndarray, n_fft: int = 512, win_length: int = 400, hop: int = 160,
-                 preemph: float = 0.97, log_guard: float = 2.0 ** -24) -> np.ndarray:
-    """-> [n_frames, n_mels], n_frames = len(pcm) // hop + 1 (FilterbankFeatures.get_seq_len)."""
+                 preemph: float = 0.97, log_guard: float = 2.0 ** -24, seq_len_plus_one: bool = False) -> np.ndarray:
+    """-> [n_frames, n_mels], n_frames = len(pcm) // hop + 1 = what the centred STFT yields and ``get_features`` hands
+    back; FilterbankFeatures.get_seq_len counts len(pcm) // hop of them as valid and the forward fills the rest with
+    pad_value 0 (``seq_len_plus_one``: the rule of NeMo < 2.0, every frame valid)."""
     x = torch.from_numpy(np.asarray(pcm, np.float32)).unsqueeze(0)
     x = torch.cat((x[:, :1], x[:, 1:] - preemph * x[:, :-1]), dim=1)
     window = torch.hann_window(win_length, periodic=False)
@@ -28,7 +40,10 @@ def nemo_log_mel(pcm: np.ndarray, filters: np.ndarray, n_fft: int = 512, win_len
     mel = torch.matmul(torch.from_numpy(np.asarray(filters, np.float32)), power)
     out = torch.log(mel + log_guard)
     n_frames = x.shape[1] // hop + 1
-    return out[0, :, :n_frames].transpose(0, 1).contiguous().numpy()
+    res = out[0, :, :n_frames].transpose(0, 1).contiguous().numpy()
+    if not seq_len_plus_one:
+        res[x.shape[1] // hop:] = 0.0
+    return res
 
 
 # ================================================================================================
@@ -148,14 +163,20 @@ def transformer_layer(sd, p: str, dims: SortformerDims, x: torch.Tensor) -> torc
     return F.layer_norm(z, (d,), sd[p + "layer_norm_2.weight"], sd[p + "layer_norm_2.bias"])
 
 
-def forward_embeddings(sd, dims: SortformerDims, embs: torch.Tensor) -> torch.Tensor:
-    """frontend_encoder(bypass_pre_encode=True) + forward_infer for one un-padded sequence of pre-encode
-    embeddings [T, fc_d_model] -> speaker activities [T, n_spk] in [0, 1]."""
+def conformer_stack(sd, dims: SortformerDims, embs: torch.Tensor) -> torch.Tensor:
+    """ConformerEncoder.forward_internal(bypass_pre_encode=True): xscaling, relative positions, the Conformer blocks."""
     T = embs.shape[0]
     x = embs * math.sqrt(dims.fc_d_model)                         # xscaling
     pos_emb = rel_positional_encoding(T, dims.fc_d_model)
     for i in range(dims.fc_layers):
         x = conformer_layer(sd, f"encoder.layers.{i}.", dims, x, pos_emb)
+    return x
+
+
+def forward_embeddings(sd, dims: SortformerDims, embs: torch.Tensor) -> torch.Tensor:
+    """frontend_encoder(bypass_pre_encode=True) + forward_infer for one un-padded sequence of pre-encode
+    embeddings [T, fc_d_model] -> speaker activities [T, n_spk] in [0, 1]."""
+    x = conformer_stack(sd, dims, embs)
     m = "sortformer_modules."
     x = F.linear(x, sd[m + "encoder_proj.weight"], sd[m + "encoder_proj.bias"])
     for i in range(dims.tf_layers):

@@ -44,8 +44,9 @@ def compare_decisions(g, decision_log, emitted=None):
     ``decision_log`` is HipAlignAttHooks.decision_log ([content_mel_len, [(token, frame), ...]] per infer), ``emitted``
     the per-chunk word lists [(start, end, text), ...].  Every decode decision (token id of beam 0, attended frame) is
     compared with the reference's; a mismatch where the reference's own winning margin is below TIE_EPS is reported as
-    a tie divergence (comparison stops there, as the stream legitimately takes another path), anything else as a
-    mismatch.  -> dict(decisions, identical, calls, tie_divergence, mismatch, words_identical)."""
+    a tie divergence (this pass stops there, as the stream legitimately takes another path; ``run_resynced`` replays
+    the stream with the reference's choice forced at that step and compares the rest), anything else as a mismatch.
+    -> dict(decisions, identical, calls, tie_divergence, mismatch, words_identical)."""
     out = dict(decisions=0, identical=0, calls=0, tie_divergence=None, mismatch=None, words_identical=None)
     stop = False
     for ci, ref in enumerate(g["calls"]):
@@ -89,6 +90,35 @@ def compare_decisions(g, decision_log, emitted=None):
         got = [[(round(s, 2), round(e, 2), x) for s, e, x in words] for words in emitted]
         out["words_identical"] = bool(want == got)
     return out
+
+
+def reference_decision(g, ci, si):
+    """(token, frame) the reference took at decision ``si`` of call ``ci`` - what a teacher-forced replay feeds back."""
+    ref_steps = [rs for rs in g["calls"][ci]["steps"] if rs.get("token") is not None]
+    return int(ref_steps[si]["token"]), int(ref_steps[si]["frame"])
+
+
+MAX_RESYNC = 8
+
+
+def run_resynced(run, g, compare):
+    """Re-synchronise after fp32 ties instead of giving up on the rest of the stream.  ``run(teacher)`` replays the whole
+    stream with the decisions in ``teacher`` ({(call, step): (token, frame)}) forced to the reference's side
+    (HipAlignAttHooks.teacher) and returns whatever ``compare`` needs; ``compare(result)`` -> (call, step, kind[, margin])
+    of the first divergence that is inside the tie margin, or None (it raises / reports real mismatches itself).
+    Every tie adds one forced decision and one replay, so all decisions behind it are compared as well.
+    -> (last result, [tie, ...]); more than MAX_RESYNC ties is an error (ties are 1-ulp events)."""
+    teacher, ties = {}, []
+    while True:
+        result = run(dict(teacher))
+        tie = compare(result)
+        if tie is None:
+            return result, ties
+        ci, si = int(tie[0]), int(tie[1])
+        if (ci, si) in teacher or len(ties) >= MAX_RESYNC:
+            raise AssertionError(f"re-synchronisation does not converge: {ties + [list(tie)]}")
+        teacher[(ci, si)] = reference_decision(g, ci, si)
+        ties.append(list(tie))
 
 
 def mel_case_audio(meta):

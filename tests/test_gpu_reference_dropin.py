@@ -35,19 +35,33 @@ def test_reference_processor_and_policy_over_real_hip_hooks(case):
     from test_reference_dropin import _make
     if not H.golden_exists(f"stream_{case}.json"):
         pytest.skip(f"golden stream {case} not generated")
-    g, proc, got = replay_stream(case, lambda m, c, seed=0: _make(m, c, seed, model_factory=_hip_model))
     from whisperlivekit.simul_whisper.align_att_base import AlignAttBase
     from whisperlivekit.simul_whisper.backend import SimulStreamingOnlineProcessor
     from whisperlivekit_amd.engine import HipSession
-    assert isinstance(proc, SimulStreamingOnlineProcessor)            # the reference's session object
-    assert type(proc).process_iter is SimulStreamingOnlineProcessor.process_iter
-    assert isinstance(proc.model, AlignAttBase) and type(proc.model).infer is AlignAttBase.infer
-    assert isinstance(proc.model.session, HipSession)                  # real C-ABI session, not the CPU fake
-    diverged = check_stream_against_golden(g, proc.trace, got, tol=1e-3, allow_ties=True)
+    opened = []
+
+    def run(teacher):
+        def mk(m, c, seed=0):
+            proc = _make(m, c, seed, model_factory=_hip_model)
+            proc.model.teacher = dict(teacher) or None       # fp32 ties: the reference's side is forced on a replay
+            return proc
+        g, proc, got = replay_stream(case, mk)
+        opened.append(proc)
+        assert isinstance(proc, SimulStreamingOnlineProcessor)            # the reference's session object
+        assert type(proc).process_iter is SimulStreamingOnlineProcessor.process_iter
+        assert isinstance(proc.model, AlignAttBase) and type(proc.model).infer is AlignAttBase.infer
+        assert isinstance(proc.model.session, HipSession)                  # real C-ABI session, not the CPU fake
+        return g, proc, got
+
+    (g, proc, got), ties = H.run_resynced(run, H.golden_json(f"stream_{case}.json"),
+                                          lambda res: check_stream_against_golden(res[0], res[1].trace, res[2], tol=1e-3,
+                                                                                  allow_ties=True))
     n = sum(len(r["steps"]) for r in proc.trace)
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "dropin_gpu_report.txt"), "a") as fh:
         fh.write(f"{case}: reference SimulStreamingOnlineProcessor + AlignAttBase.infer over HIP hooks, {n} decode steps, "
-                 f"{len(g['calls'])} calls, tie_divergence={diverged}\n")
+                 f"{len(g['calls'])} calls all compared, ties re-synchronised: {ties}\n")
+    for p in opened[:-1]:
+        p.model.close()
     proc.model.close()

@@ -187,15 +187,18 @@ def test_bench_checks_its_own_outputs_against_the_reference():
     """bench.py replays the reference's golden decisions on the sessions it times (1-stream headline + the 8-stream
     leg) and prints parity_checked; nothing it reports may come from unverified outputs."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-diarization"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--no-cpu-baseline", "--no-diarization", "--no-large-v3"], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     pc = line["parity_checked"]
     assert pc is not None and pc["sessions"] == 9 and not pc["missing_golden"], pc
     assert pc["mismatches"] == [], pc
     assert pc["decisions"] > 2000
-    if not pc["tie_divergences"]:
-        assert pc["identical"] == pc["decisions"] and pc["words_identical_sessions"] == pc["sessions"], pc
+    # ties are re-synchronised (the reference's choice forced at the tied step, the rest of the stream compared): every
+    # decision of every session ends up identical and no call stays unchecked
+    assert pc["identical"] == pc["decisions"] and pc["words_identical_sessions"] == pc["sessions"], pc
+    assert pc["unchecked_calls"] == 0 and pc["forced_decisions"] == len(pc["tie_divergences"]), pc
     assert line["n_gpus"] == 1 and line["eight_streams"]["streams"] == 8
     assert line["eight_streams"]["swallowed_errors"] == 0 and line["swallowed_errors"] == 0
     out = os.path.join(ROOT, "gpurun_out")
@@ -212,18 +215,21 @@ def test_bench_multi_rank_code_path_rehearsal():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["WLK_BENCH_REHEARSAL"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-                        "--no-cpu-baseline", "--no-diarization"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                        "--no-cpu-baseline", "--no-large-v3"], capture_output=True, text=True, timeout=900, cwd=ROOT,
                        env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and len(line["per_rank_audio_s_per_s"]) == 2
     assert line["weight_broadcast_ms"] is not None and "rehearsal" in line
+    assert len(line["weight_finalize_ms_per_rank"]) == 2 and all(t > 0 for t in line["weight_finalize_ms_per_rank"])
     e = line["eight_streams"]
     assert e["gpus"] == 2 and len(e["per_rank_audio_s_per_s"]) == 2 and e["swallowed_errors"] == 0
+    # configs[3] under --gpus N: every rank runs the (ASR + diarizer) pairs of its own streams
+    c4 = line["asr_plus_diarization_8_sessions"]
+    assert c4["gpus"] == 2 and c4["sessions"] == 8 and c4["per_rank_sessions"] == [4, 4] and c4["swallowed_errors"] == 0, c4
     pc = line["parity_checked"]
-    assert pc["sessions"] == 2 + 8 and pc["mismatches"] == [] and not pc["missing_golden"], pc
-    if not pc["tie_divergences"]:
-        assert pc["identical"] == pc["decisions"], pc
+    assert pc["sessions"] == 2 + 8 + 8 and pc["mismatches"] == [] and not pc["missing_golden"], pc
+    assert pc["identical"] == pc["decisions"] and pc["unchecked_calls"] == 0, pc
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "8", "--steps", "1",
                          "--warmup", "0", "--no-cpu-baseline", "--no-diarization", "--no-eight-streams"],
                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
@@ -231,6 +237,7 @@ def test_bench_multi_rank_code_path_rehearsal():
     strong = json.loads([l for l in r2.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert strong["scaling"] == "strong" and strong["config"]["streams_total"] == 8 and strong["config"]["streams_this_rank"] == 4
     assert strong["parity_checked"]["sessions"] == 8 and strong["parity_checked"]["mismatches"] == []
+    assert strong["parity_checked"]["unchecked_calls"] == 0
 
 
 def test_bench_refuses_more_gpus_than_visible():

@@ -1,6 +1,9 @@
 """a12 on the GPU: the Sortformer network through the C ABI (wlk_sf_*) against the torch-CPU restatement in
-oracle/sortformer_oracle.py on the same seeded weights and inputs.  PARITY UNPINNED with respect to NeMo itself
-(no NeMo / checkpoint offline) - what is checked here is HIP path == oracle, fp32 tolerance stated per test."""
+oracle/sortformer_oracle.py on the same seeded weights and inputs, and (round 5) against known answers from the independent
+ports of NeMo's modules in `transformers` - ParakeetFeatureExtractor (log-mel), ParakeetEncoder (sub-sampling stem,
+FastConformer) - in tests/golden/sortformer_hf_kat.npz.  Still unpinned with respect to NeMo itself (no NeMo / checkpoint
+offline): the wiring of the Transformer blocks + sigmoid head and the speaker-cache update; there HIP path == oracle is
+what is checked.  fp32 tolerance stated per test."""
 import math
 import os
 
@@ -141,6 +144,56 @@ def test_full_depth_streaming_session_teacher_forced(full):
     assert segs and all(s.end >= s.start for s in segs)
     assert abs(segs[-1].end - 18.0) < 0.05 and segs[0].start == 0.0
     assert all(abs(a.end - b.start) < 1e-6 for a, b in zip(segs, segs[1:]))
+
+
+HF_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sortformer_hf_kat.npz")
+
+
+@pytest.fixture(scope="module")
+def hf_weights_model():
+    """The weights scripts/gen_golden_sortformer_hf.py loaded into transformers' ParakeetEncoder: seed 0, full geometry."""
+    dims = sf.SortformerDims()
+    m = sf.HipSortformerModel(dims, sf.synth_sortformer_state_dict(dims, 0))
+    yield m
+    m.close()
+
+
+def test_log_mel_against_parakeet_feature_extractor(hf_weights_model):
+    """wlk_melspec_run == transformers' port of NeMo's FilterbankFeatures (<= 1e-3; the valid-frame rule and the zero
+    fill behind the valid frames included), un-normalised and through the extractor's own per-feature normalisation."""
+    from test_sortformer_hf_golden import FEATURE_CASES, feature_case_pcm, per_feature_normalized
+    g = np.load(HF_GOLDEN)
+    worst = worst_n = 0.0
+    for name, seconds, seed, cut in FEATURE_CASES:
+        pcm = feature_case_pcm(seconds, seed, cut)
+        valid = int(g[f"feat_{name}_valid"])
+        got = hf_weights_model.features(pcm)
+        raw = g[f"feat_{name}_raw"]
+        assert got.shape == raw.shape
+        assert np.all(got[valid:] == 0.0)
+        worst = max(worst, float(np.abs(got[:valid] - raw[:valid]).max()))
+        if valid > 1:
+            worst_n = max(worst_n, float(np.abs(per_feature_normalized(got, valid) - g[f"feat_{name}_normalized"]).max()))
+    assert worst <= 1e-3 and worst_n <= 1e-3, (worst, worst_n)
+
+
+def test_stem_and_fastconformer_against_parakeet_encoder(hf_weights_model):
+    """wlk_sf_step == transformers' port of NeMo's FastConformer on the same seeded weights (<= 1e-3 on O(1) values):
+    the dw-striding stem on the diarizer's second-chunk input (99 + 101 feature frames), the 17 Conformer blocks over
+    the chunk alone, and over [95 context embeddings | chunk] (the [speaker cache | FIFO | chunk] layout)."""
+    g = np.load(HF_GOLDEN)
+    m = hf_weights_model
+    chunk, _ = m.step(g["stem_in"], None)
+    assert chunk.shape == g["stem_out"].shape
+    e_stem = float(np.abs(chunk - g["stem_out"]).max())
+    fc = m.export("fc_out")
+    assert fc.shape == g["stack_chunk_out"].shape
+    e_stack = float(np.abs(fc - g["stack_chunk_out"]).max())
+    m.step(g["stem_in"], g["ctx_embs"])
+    fc = m.export("fc_out")
+    assert fc.shape == g["stack_ctx_out"].shape
+    e_ctx = float(np.abs(fc - g["stack_ctx_out"]).max())
+    assert e_stem <= 1e-4 and e_stack <= 1e-3 and e_ctx <= 1e-3, (e_stem, e_stack, e_ctx)
 
 
 NEMO_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sortformer_nemo.npz")

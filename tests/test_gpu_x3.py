@@ -89,3 +89,22 @@ def test_x3_encoder_attention_matches_float64_like_the_fp32_kernel(T, d, H):
     e3, e32 = _err(o3, ref), _err(o32, ref)
     print(f"T{T} d{d}: x3 max/mean {e3[0]:.2e} {e3[1]:.2e} | fp32 mfma {e32[0]:.2e} {e32[1]:.2e}")
     assert e3[1] <= 2.0 * e32[1] + 1e-7 and e3[0] <= 3.0 * e32[0] + 1e-6, (e3, e32)
+
+
+@pytest.mark.parametrize("T,d,H", [(1500, 512, 8), (1500, 384, 6), (1437, 128, 2), (97, 128, 2), (1500, 1280, 20)])
+def test_production_operand_route_of_the_x3_attention_equals_the_diagnostic_one(T, d, H):
+    """In the product the attention's operand image (q | k as X3 rows, V transposed in the lane order of the kernel) is
+    written by the qkv projection's X3 epilogue; the accuracy tests above feed the kernel through x3_pack_qkv instead.
+    Both routes on the same x, w: the attention outputs must be bit-identical (T = 1500 and tile counts that are not whole:
+    1437 = 14 x 96 + 93 rows, 97 = one tile + 1)."""
+    lib = _lib.load()
+    rng = np.random.default_rng(T + d)
+    x = rng.standard_normal((T, d)).astype(np.float32)
+    w = (rng.standard_normal((3 * d, d)) / np.sqrt(d)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(3 * d)).astype(np.float32)
+    o_epi = np.empty((T, d), np.float32)
+    o_pack = np.empty((T, d), np.float32)
+    rc = lib.wlk_diag_qkv_x3_attention(vp(x), vp(w), vp(b), T, d, H, 64 ** -0.25, vp(o_epi), vp(o_pack))
+    assert rc == 0, lib.wlk_diag_last_error()
+    assert np.isfinite(o_epi).all() and float(np.abs(o_epi).max()) > 1e-3
+    assert np.array_equal(o_epi.view(np.uint32), o_pack.view(np.uint32)), float(np.abs(o_epi - o_pack).max())

@@ -2,7 +2,7 @@
 oracle/sortformer_oracle.py, the weight re-packing algebra, the relative-position table and index map, and the
 packed-layout contract of the C ABI (no GPU needed: layout queries do not touch HIP).
 
-PARITY UNPINNED for everything NeMo-side (see the oracle's header): these tests pin the two restatements against
+PARITY of the host part (speaker-cache update) is UNPINNED NeMo-side (see the oracle's header): these tests pin the two restatements against
 each other and against closed-form properties, not against NeMo."""
 import ctypes as C
 import math

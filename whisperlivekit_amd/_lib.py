@@ -44,7 +44,19 @@ class LoopParams(C.Structure):
     """wlk_loop_params (include/wlk_hip.h)"""
     _fields_ = [(n, C.c_int32) for n in (
         "sot_index", "is_last", "frame_threshold", "rewind_threshold", "last_attend_frame", "max_text_len", "budget",
-        "eot", "dec_pad", "no_speech_token")] + [("no_speech_threshold", C.c_float), ("content_mel_len", C.c_int32)]
+        "eot", "dec_pad", "no_speech_token")] + [("no_speech_threshold", C.c_float), ("content_mel_len", C.c_int32),
+                                                   ("n_force", C.c_int32), ("force_step", C.c_int32 * 4),
+                                                   ("force_token", C.c_int32 * 4), ("force_frame", C.c_int32 * 4)]
+    MAX_FORCED = 4
+
+    def force(self, entries) -> None:
+        """entries: [(step, token or -1, frame or -1)] - teacher forcing of tied decisions (parity harnesses only)."""
+        entries = list(entries)
+        if len(entries) > self.MAX_FORCED:
+            raise ValueError(f"at most {self.MAX_FORCED} forced decisions per loop")
+        self.n_force = len(entries)
+        for i, (step, token, frame) in enumerate(entries):
+            self.force_step[i], self.force_token[i], self.force_frame[i] = int(step), int(token), int(frame)
 
 
 class LoopResult(C.Structure):
@@ -127,6 +139,7 @@ def _declare(lib: C.CDLL) -> None:
         "wlk_job_result": (cint, [p, C.POINTER(LoopResult), p, p, p, p, cint]),
         "wlk_job_destroy": (cint, [p]),
         "wlk_export": (cint, [p, C.c_char_p, p, u64, C.POINTER(u64)]),
+        "wlk_session_step_stats": (cint, [p, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
         "wlk_prof_begin": (cint, [p]),
         "wlk_prof_end": (cint, [p, cint, C.POINTER(C.c_char_p), p, p, p, p, C.POINTER(i32)]),
         "wlk_melspec_create": (cint, [cint, cint, cint, cint, cint, p, p, C.c_float, C.c_float, cint, C.POINTER(p)]),
@@ -182,11 +195,13 @@ def _declare(lib: C.CDLL) -> None:
         "wlk_diag_encoder_attention_time": (cint, [cint, cint, cint, cint, cint, C.POINTER(C.c_float)]),
         "wlk_diag_encoder_attention": (cint, [p, cint, cint, cint, p]),
         "wlk_diag_wave_ops": (cint, [p, p, p]),
+        "wlk_diag_env_refresh": (cint, []),
         "wlk_diag_linear_x3": (cint, [p, p, p, cint, cint, cint, cint, C.c_float, cint, p]),
         "wlk_diag_linear_x3_time": (cint, [cint, cint, cint, cint, cint, C.POINTER(C.c_float)]),
         "wlk_diag_layernorm_x3": (cint, [p, p, p, cint, cint, p]),
         "wlk_diag_encoder_attention_x3": (cint, [p, cint, cint, cint, p]),
         "wlk_diag_encoder_attention_x3_time": (cint, [cint, cint, cint, cint, C.POINTER(C.c_float)]),
+        "wlk_diag_qkv_x3_attention": (cint, [p, p, p, cint, cint, cint, C.c_float, p, p]),
     }
     for name, (res, args) in sig.items():
         try:
@@ -210,7 +225,7 @@ EXPORTED_SYMBOLS = (
     "wlk_no_speech_prob", "wlk_select", "wlk_kv_reorder", "wlk_sync", "wlk_decode_until_stop", "wlk_engine_attach", "wlk_engine_detach",
     "wlk_engine_stats", "wlk_engine_encode_stats", "wlk_engine_prefill_stats", "wlk_diag_prefill_stack", "wlk_job_create",
     "wlk_job_begin_step", "wlk_job_no_speech", "wlk_job_adjustments", "wlk_job_consume", "wlk_job_result",
-    "wlk_job_destroy", "wlk_export", "wlk_prof_begin",
+    "wlk_job_destroy", "wlk_export", "wlk_session_step_stats", "wlk_prof_begin",
     "wlk_prof_end", "wlk_melspec_create", "wlk_melspec_run", "wlk_melspec_destroy",
     "wlk_sf_arena_floats", "wlk_sf_tensor_lookup", "wlk_sf_tensor_name", "wlk_sf_create", "wlk_sf_upload",
     "wlk_sf_finalize", "wlk_sf_step", "wlk_sf_export", "wlk_sf_destroy",
@@ -222,9 +237,9 @@ EXPORTED_SYMBOLS = (
     "wlk_nllb_finalize", "wlk_nllb_destroy", "wlk_nllb_session_create", "wlk_nllb_session_destroy", "wlk_nllb_encode",
     "wlk_nllb_decode", "wlk_nllb_step", "wlk_nllb_kv_reorder", "wlk_nllb_topk", "wlk_nllb_export", "wlk_nllb_sync",
     "wlk_diag_last_error", "wlk_diag_linear", "wlk_diag_linear_time", "wlk_diag_linear_ln", "wlk_diag_layernorm",
-    "wlk_diag_encoder_attention", "wlk_diag_encoder_attention_time", "wlk_diag_wave_ops",
+    "wlk_diag_encoder_attention", "wlk_diag_encoder_attention_time", "wlk_diag_wave_ops", "wlk_diag_env_refresh",
     "wlk_diag_linear_x3", "wlk_diag_linear_x3_time", "wlk_diag_layernorm_x3",
-    "wlk_diag_encoder_attention_x3", "wlk_diag_encoder_attention_x3_time",
+    "wlk_diag_encoder_attention_x3", "wlk_diag_encoder_attention_x3_time", "wlk_diag_qkv_x3_attention",
 )
 
 

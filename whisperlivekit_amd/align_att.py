@@ -150,6 +150,13 @@ class HipAlignAttHooks:
         # optional decision trace (bench.py / tests switch it on by assigning a list): one entry per infer,
         # [content_mel_len, [(token of beam 0, attended frame of beam 0), ...]] - what a golden stream pins
         self.decision_log: Optional[List[list]] = None
+        # teacher forcing of single decisions, for parity harnesses only (None in production): {(infer index, decode step):
+        # (token or -1, frame or -1)} - when this backend and the reference land on different sides of an fp32 tie, the
+        # harness replays the stream with the reference's choice forced at that step, so every later decision is still
+        # compared (wlk_loop_params.force_* in the library loop, _update_tokens in the per-token path; beam 1 only)
+        self.teacher: Optional[dict] = None
+        self._infer_index = -1
+        self._step_index = 0
         self.state = P.StreamState()
         self.state.on_clean_cache = self._on_clean_cache
         self._init_state(cfg)
@@ -282,6 +289,8 @@ class HipAlignAttHooks:
         self._content_mel_len = self.session.encode()
         self.counters["encode"] += 1
         self._fresh_infer = True
+        self._infer_index += 1
+        self._step_index = 0
         if self.decision_log is not None:
             self.decision_log.append([self._content_mel_len, []])
         return EncoderFeature(self.session), self._content_mel_len
@@ -360,6 +369,17 @@ class HipAlignAttHooks:
             rows.append(r), ids.append(t), deltas.append(dl)
         k = 1 if self.state.decoder_type == "greedy" else self.cfg.beam_size + 1
         lp, top, frames = self.session.select(rows, ids, deltas, k, self._content_mel_len)
+        forced = self.teacher.get((self._infer_index, self._step_index)) if self.teacher else None
+        self._step_index += 1
+        if forced is not None:
+            if self.cfg.beam_size != 1:
+                raise RuntimeError("teacher forcing is defined for beam 1 only")
+            tok_f, frame_f = forced
+            lp, top, frames = np.array(lp), np.array(top), np.array(frames)
+            if frame_f >= 0:
+                frames[0] = frame_f
+            if tok_f >= 0 and top.shape[1] > 1 and int(top[0, 0]) != self.tokenizer.eot and int(top[0, 1]) == tok_f:
+                top[0, [0, 1]], lp[0, [0, 1]] = top[0, [1, 0]], lp[0, [1, 0]]
         self._last_frames = frames
         self.last_top = (lp, top)
         tokens, completed, sources = self._updater.update(np.asarray(current_tokens), lp, top, sum_logprobs)
@@ -392,6 +412,8 @@ class HipAlignAttHooks:
             max_text_len=int(self.max_text_len), budget=int(budget), eot=int(tok.eot), dec_pad=P.DEC_PAD,
             no_speech_token=-1 if tok.no_speech is None else int(tok.no_speech),
             no_speech_threshold=float(cfg.nonspeech_prob), content_mel_len=int(content_mel_len))
+        if self.teacher:
+            p.force([(si, t, f) for (ci, si), (t, f) in sorted(self.teacher.items()) if ci == self._infer_index])
         blank = list(tok.encode(" ")) + [tok.eot]
         out = self.session.decode_until_stop(np.asarray(tokens)[0], p, st.suppress_ids, blank)
         self._fresh_infer = False

@@ -164,7 +164,7 @@ static LayerW layer_weights(const wlk_model* m, const char* side, int i, bool cr
 extern "C" {
 
 const char* wlk_last_error(void) { return g_last_error.c_str(); }
-int wlk_abi_version(void) { return 1; }
+int wlk_abi_version(void) { return 2; }   // 2: wlk_loop_params carries the teacher-forcing block
 
 int wlk_device_count(void) {
     int n = 0;
@@ -279,6 +279,9 @@ int wlk_model_set_alignment_heads(wlk_model* m, const int32_t* pairs, int n_pair
         for (int i = 0; i < n_pairs; ++i) {
             const int l = pairs[2 * i], h = pairs[2 * i + 1];
             if (l < 0 || l >= L || h < 0 || h >= H) return fail(WLK_ERR_ARG, "alignment head out of range");
+            // the kernels launch one side block per PAIR of a layer but look heads up in a table of DISTINCT heads: a
+            // repeated (layer, head) would send a block to head 0 / rank -1 (an out-of-bounds window row)
+            if (rank[(size_t)l * H + h] >= 0) return fail(WLK_ERR_ARG, "alignment head listed twice");
             rank[(size_t)l * H + h] = i;
         }
         WLK_HIP(hipSetDevice(m->device));
@@ -348,6 +351,10 @@ int wlk_model_finalize(wlk_model* m) {
             c.stream = nullptr;
             hipStream_t st;
             WLK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            struct StreamGuard {      // a throwing pack / allocation must not leak the temporary stream
+                hipStream_t s;
+                ~StreamGuard() { (void)hipStreamDestroy(s); }
+            } st_guard{st};
             c.stream = st;
             auto pack = [&](const float* w, int n_rows) -> unsigned short* {
                 unsigned short* p3 = dev_alloc<unsigned short>((size_t)n_rows * 3 * da);
@@ -362,7 +369,6 @@ int wlk_model_finalize(wlk_model* m) {
             const int n_xkv = m->D.n_text_layer * 2 * m->D.n_text_state;
             if (gemm_x3_wide_applicable(T, n_xkv, da, da)) m->xkv_all_w3 = pack(m->xkv_all_w, n_xkv);
             WLK_HIP(hipStreamSynchronize(st));
-            (void)hipStreamDestroy(st);
         }
         m->w_tok_emb = m->w("dec.tok_emb");
         m->w_dec_pos = m->w("dec.pos");
@@ -425,9 +431,18 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         s->eatt = dev_alloc<float>(T * d);
         s->emlp = dev_alloc<float>(T * 4 * d);
         s->enc_out = dev_alloc<float>(T * d);
-        s->eh3 = dev_alloc<unsigned short>(T * 3 * d);
-        s->eqkv3 = dev_alloc_zero<unsigned short>(x3_attn_image_elems((int)T, (int)d), st);
-        s->enc_out3 = dev_alloc<unsigned short>(T * 3 * d);
+        {   // X3 operand buffers (6 bytes per element) only where this model's encode chain takes the X3 path (the choice is
+            // the model's: weights packed by wlk_model_finalize; WLK_X3=0 / WLK_X3_ATTN=0 leave them out)
+            bool any_x3 = m->xkv_all_w3 != nullptr, qkv_x3 = false;
+            for (const auto& L : m->enc_layers) {
+                any_x3 |= L.qkvw3 || L.fc1w3;
+                qkv_x3 |= L.qkvw3 != nullptr;
+            }
+            const bool attn_x3 = qkv_x3 && enc_attention_x3_enabled() && d == (size_t)D.n_audio_head * 64 && T >= 64 && (2 * d) % 128 == 0;
+            if (any_x3) s->eh3 = dev_alloc<unsigned short>(T * 3 * d);
+            if (attn_x3) s->eqkv3 = dev_alloc_zero<unsigned short>(x3_attn_image_elems((int)T, (int)d), st);
+            if (m->xkv_all_w3) s->enc_out3 = dev_alloc<unsigned short>(T * 3 * d);
+        }
         s->cross_kv = dev_alloc<float>((size_t)D.n_text_layer * T * 2 * d);
 
         s->max_rows = beam * (int)ctx;
@@ -491,7 +506,7 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
 
 int wlk_session_destroy(wlk_session* s) {
     if (!s) return WLK_OK;
-    if (s->step_count)
+    if (s->step_count && getenv("WLK_STEP_TIMING"))
         fprintf(stderr, "[wlk] one-replay steps: %llu, mean %.1f us per step (graph launch call %.1f us)\n",
                 (unsigned long long)s->step_count, s->step_ns / 1e3 / s->step_count, s->step_launch_ns / 1e3 / s->step_count);
     (void)wlk_engine_detach(s);
@@ -1000,7 +1015,9 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
         q.flags = kGemmScaleCols; q.scale = scale; q.scale_cols = d;
         // decode steps: the split cross-attention kernel derives its head's query values itself (same arithmetic) - one
         // launch less per layer
-        const bool fold_xq = fused && R == 1 && !s->debug && cross_split_folds_query(d);   // one row: saves a launch; several rows would each re-stream Wq
+        // (the fold leaves s->dq unwritten, so it must never meet the flash branch below, which reads it: that branch is
+        // taken for align_raw_scores - excluded here, not merely "never fed with R == 1 today")
+        const bool fold_xq = fused && R == 1 && !s->debug && !s->align_raw_scores && cross_split_folds_query(d);   // one row: saves a launch; several rows would each re-stream Wq
         if (fold_xq) {
         } else if (fused) {
             q.A = s->dx; q.ln_gamma = L.lnxw; q.ln_beta = L.lnxb;
@@ -1018,6 +1035,7 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
         GemmArgs xo_mg;   // carries the split-form operand description to the out projection when merged_xout
         if ((R > 8 || s->align_raw_scores) && !s->debug) {
             // prefill: MFMA flash kernel shares every K/V tile between 32 query rows
+            if (fold_xq) throw std::logic_error("decode: the folded query projection left no q for the flash kernel");
             FlashArgs fa;
             fa.q = s->dq; fa.ldq = d;
             fa.k = s->cross_kv + (size_t)i * 2 * d; fa.v = fa.k + d; fa.ldkv = (long)D.n_text_layer * 2 * d;
@@ -1520,7 +1538,6 @@ extern "C++" int wlk_step_select(wlk_session* s, int64_t token, const int32_t* a
         b.seq = seq;
         std::atomic_thread_fence(std::memory_order_release);
 
-        static const bool timing = getenv("WLK_STEP_TIMING") != nullptr;
         const auto t_enter = std::chrono::steady_clock::now();
         hipGraphExec_t& exec = s->fstep_exec[s->kv_cur];
         if (!exec) {
@@ -1551,7 +1568,7 @@ extern "C++" int wlk_step_select(wlk_session* s, int64_t token, const int32_t* a
         // the last kernel stores the two flags after the fields
         volatile StepResult* r = s->result_host;
         const auto t_start = std::chrono::steady_clock::now();
-        if (timing) s->step_launch_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_start - t_enter).count();
+        s->step_launch_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_start - t_enter).count();
         try {
             wlk_wait_step_flags(s->stream, s->result_host, 1, seq);
         } catch (...) {
@@ -1568,10 +1585,8 @@ extern "C++" int wlk_step_select(wlk_session* s, int64_t token, const int32_t* a
         s->n_steps += 1;
         s->last_rows = 1;
         s->last_ntok = 1;
-        if (timing) {
-            s->step_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_enter).count();
-            s->step_count += 1;
-        }
+        s->step_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_enter).count();
+        s->step_count += 1;       // three clock reads per ~200 us step: always on (wlk_session_step_stats)
         top_logprobs2[0] = r->top_vals[0]; top_logprobs2[1] = r->top_vals[1];
         top_ids2[0] = r->top_ids[0]; top_ids2[1] = r->top_ids[1];
         *frame = r->frame;
@@ -1796,6 +1811,14 @@ int wlk_prof_begin(wlk_session* s) {
     }
     s->prof.recs.clear();
     s->prof_on = true;
+    return WLK_OK;
+}
+
+int wlk_session_step_stats(wlk_session* s, uint64_t* steps, uint64_t* wall_ns, uint64_t* launch_ns) {
+    if (!s || !steps || !wall_ns || !launch_ns) return fail(WLK_ERR_ARG, "NULL argument");
+    *steps = s->step_count;
+    *wall_ns = s->step_ns;
+    *launch_ns = s->step_launch_ns;
     return WLK_OK;
 }
 

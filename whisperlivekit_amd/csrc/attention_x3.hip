@@ -312,7 +312,8 @@ __global__ __launch_bounds__(512) void enc_attention_x3_kernel(AttnX3Args a) {
 }
 
 // fp32 qkv [T][3 d] -> the operand image enc_attention_x3_kernel reads (the layout the qkv projection's X3 epilogue
-// writes): X3 rows [T][2 d] (q | k), then V^T as X3 rows [d][vt_ld] with the key order 0-3, 8-11, 4-7, 12-15 per 16-group.
+// writes): X3 rows [T][2 d] (q | k), then V^T as X3 rows [d][vt_ld] whose stored chunk u of every 32-key group holds the
+// keys 4 u .. 4 u + 3 and 16 + 4 u .. 16 + 4 u + 3 (ax_vt_key).
 // Diagnostics only (wlk_diag_encoder_attention_x3): in the product the GEMM epilogue produces this image directly.
 __global__ __launch_bounds__(256) void x3_pack_qkv_kernel(const float* __restrict__ qkv, unsigned short* __restrict__ out, int T, int d,
                                                           long vt_off, long vt_ld) {

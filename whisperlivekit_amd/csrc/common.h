@@ -220,6 +220,7 @@ inline bool gemv_applicable(int M, int K) {
 }
 // can launch_gemv take the cross-attention output in split form (single-row kernel, K = d)?
 bool gemv1_folds_merge(int K);
+void refresh_env_switches();                      // cached environment switches are read again at their next use (tests)
 bool gemm_fuses_layernorm(int M, int N, int K);   // launch_gemm takes ln_gamma / ln_beta for this problem (prefill rows)
 inline void launch_linear(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (gemv_applicable(g.M, g.K)) launch_gemv(ctx, g, tag);

@@ -302,6 +302,11 @@ int wlk_diag_encoder_attention(const float* qkv, int t, int d, int n_head, float
     });
 }
 
+int wlk_diag_env_refresh(void) {
+    wlk::refresh_env_switches();
+    return 0;
+}
+
 int wlk_diag_wave_ops(const float* in64, float* out640, float* ref640) {
     return run([&]() {
         DevBuf I(64, in64), O(640), R(640);
@@ -405,6 +410,46 @@ int wlk_diag_encoder_attention_x3(const float* qkv, int t, int d, int n_head, fl
         launch_encoder_attention_x3(ctx, img, 2L * d, x3_attn_vt_off(t, d), x3_attn_vt_ld(t), O.p, d, t, d, n_head, nullptr, 0);
         WLK_HIP(hipDeviceSynchronize());
         WLK_HIP(hipMemcpy(out, O.p, (size_t)t * d * sizeof(float), hipMemcpyDeviceToHost));
+        (void)hipFree(img);
+    });
+}
+
+/* The PRODUCTION operand route of the X3 attention against the diagnostic one: x [t][d] . w [3 d][d]^T (+ bias, q | k columns
+ * scaled) through gemm_x3 with the X3 epilogue (q | k as X3 rows, V transposed in the lane order of the attention kernel) ->
+ * enc_attention_x3 -> out_epilogue; the same projection with an fp32 result -> x3_pack_qkv -> attention -> out_packed.
+ * The two must agree bit for bit (same fp32 values split into the same planes, the same image). */
+int wlk_diag_qkv_x3_attention(const float* x, const float* w, const float* bias, int t, int d, int n_head, float scale,
+                              float* out_epilogue, float* out_packed) {
+    return run([&]() {
+        DevBuf X((size_t)t * d, x), W((size_t)3 * d * d, w), B((size_t)3 * d, bias), QKV((size_t)t * 3 * d), O((size_t)t * d);
+        unsigned short *x3 = nullptr, *w3 = nullptr, *img = nullptr;
+        const size_t n_img = x3_attn_image_elems(t, d);
+        WLK_HIP(hipMalloc(reinterpret_cast<void**>(&x3), (size_t)t * 3 * d * sizeof(unsigned short)));
+        WLK_HIP(hipMalloc(reinterpret_cast<void**>(&w3), (size_t)3 * d * 3 * d * sizeof(unsigned short)));
+        WLK_HIP(hipMalloc(reinterpret_cast<void**>(&img), n_img * sizeof(unsigned short)));
+        LaunchCtx ctx;
+        launch_x3_pack(ctx, X.p, d, x3, d, t, d);
+        launch_x3_pack(ctx, W.p, d, w3, d, 3 * d, d);
+        X3GemmArgs g;
+        g.A3 = x3; g.lda = d; g.W3 = w3; g.bias = B.p; g.M = t; g.N = 3 * d; g.K = d;
+        g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = 2 * d;
+        for (int route = 0; route < 2; ++route) {
+            WLK_HIP(hipMemset(img, 0, n_img * sizeof(unsigned short)));     // the session's image starts zeroed as well
+            X3GemmArgs r = g;
+            if (route == 0) {
+                r.x3_out = true; r.C3 = img; r.ldc3 = 2 * d; r.vt_col0 = 2 * d; r.vt_off = x3_attn_vt_off(t, d); r.vt_ld = x3_attn_vt_ld(t);
+                launch_gemm_x3(ctx, r, "diag_qkv_x3");
+            } else {
+                r.C = QKV.p; r.ldc = 3 * d;
+                launch_gemm_x3(ctx, r, "diag_qkv");
+                launch_x3_pack_qkv(ctx, QKV.p, img, t, d, x3_attn_vt_off(t, d), x3_attn_vt_ld(t));
+            }
+            launch_encoder_attention_x3(ctx, img, 2L * d, x3_attn_vt_off(t, d), x3_attn_vt_ld(t), O.p, d, t, d, n_head, nullptr, 0);
+            WLK_HIP(hipDeviceSynchronize());
+            WLK_HIP(hipMemcpy(route == 0 ? out_epilogue : out_packed, O.p, (size_t)t * d * sizeof(float), hipMemcpyDeviceToHost));
+        }
+        (void)hipFree(x3);
+        (void)hipFree(w3);
         (void)hipFree(img);
     });
 }

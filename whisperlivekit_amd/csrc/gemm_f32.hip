@@ -1230,9 +1230,16 @@ static bool gemm_can_fuse_layernorm(int M, int N, int K) {
 // less per prefill, but 128-512 workgroups each re-derive the statistics of their sixteen rows - 200.7-201.7 fused against
 // 200.5-203.5 audio-s/s, 8 streams 358-363 either way), so the separate launch stays the default; WLK_PREFILL_LN_FUSE=1
 // turns the fused form on (bit-identical: tests/test_gpu_parity.py::test_prefill_gemm_fuses_the_layernorm).
+static std::atomic<int> g_prefill_ln_fuse{-1};          // -1: not read yet; the switch is read ONCE (this sits on the decode path)
+void refresh_env_switches() { g_prefill_ln_fuse.store(-1, std::memory_order_relaxed); }   // wlk_diag_env_refresh: the parity test flips the switch inside one process
 bool gemm_fuses_layernorm(int M, int N, int K) {
-    const char* e = getenv("WLK_PREFILL_LN_FUSE");     // read per call: the parity test flips it inside one process
-    return e && e[0] == '1' && gemm_can_fuse_layernorm(M, N, K);
+    int on = g_prefill_ln_fuse.load(std::memory_order_relaxed);
+    if (on < 0) {
+        const char* e = getenv("WLK_PREFILL_LN_FUSE");
+        on = e && e[0] == '1';
+        g_prefill_ln_fuse.store(on, std::memory_order_relaxed);
+    }
+    return on && gemm_can_fuse_layernorm(M, N, K);
 }
 
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {

@@ -253,7 +253,7 @@ struct wlk_session {
     wlk::StepResult *result_host = nullptr, *result_host_dev = nullptr;
     hipGraphExec_t fstep_exec[2] = {nullptr, nullptr};
     unsigned step_seq = 0;
-    uint64_t step_ns = 0, step_launch_ns = 0, step_count = 0;   // WLK_STEP_TIMING=1: printed when the session is destroyed
+    uint64_t step_ns = 0, step_launch_ns = 0, step_count = 0;   // wlk_session_step_stats (WLK_STEP_TIMING=1: also printed when the session is destroyed)
 
     wlk::LaunchCtx ctx() { return wlk::LaunchCtx{stream, prof_on ? &prof : nullptr}; }
     // word-timestamp alignment (word_align.hip): the prefill leaves the alignment heads' raw scores in the window, and

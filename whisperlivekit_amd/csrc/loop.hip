@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/wlk_hip.h"
@@ -91,8 +92,20 @@ void DecodeJob::adjustments(std::vector<int32_t>& ids, std::vector<float>& delta
     }
 }
 
-bool DecodeJob::consume(const float* top_lp, const int32_t* top_ids, int frame) {
+bool DecodeJob::consume(const float* top_lp_in, const int32_t* top_ids_in, int frame) {
     fresh = false;
+    float top_lp[2] = {top_lp_in[0], top_lp_in[1]};
+    int32_t top_ids[2] = {top_ids_in[0], top_ids_in[1]};
+    // teacher forcing (parity harnesses; wlk_loop_params): this step takes the reference's side of an fp32 tie
+    const int step_index = (int)step_tokens.size();
+    for (int f = 0; f < P.n_force && f < WLK_MAX_FORCED; ++f) {
+        if (P.force_step[f] != step_index) continue;
+        if (P.force_frame[f] >= 0) frame = P.force_frame[f];
+        if (P.force_token[f] >= 0 && top_ids[0] != P.eot && top_ids[1] == P.force_token[f]) {
+            std::swap(top_ids[0], top_ids[1]);
+            std::swap(top_lp[0], top_lp[1]);
+        }
+    }
     // BeamSearchDecoder.update, beam_size 1: candidates are the two best tokens; an end-of-text candidate goes to the
     // finished list (and completes the search: max_candidates = 1), the best other candidate is the next token
     bool completed = false;
@@ -169,6 +182,7 @@ static int check_loop_args(const wlk_loop_params* p, const int64_t* tokens, int 
         return loop_fail(WLK_ERR_ARG, "decode loop: bad suppression lists");
     if (p->sot_index < 0 || p->sot_index >= n_tok) return loop_fail(WLK_ERR_ARG, "decode loop: sot_index out of range");
     if (p->max_text_len < 1 || p->budget < 0) return loop_fail(WLK_ERR_ARG, "decode loop: bad limits");
+    if (p->n_force < 0 || p->n_force > WLK_MAX_FORCED) return loop_fail(WLK_ERR_ARG, "decode loop: n_force out of range");
     return WLK_OK;
 }
 

@@ -146,10 +146,13 @@ __device__ __forceinline__ void topk_stage1_body(float* __restrict__ logits, int
     const int hi = min(n_vocab, lo + per);
     float* x = logits + (long)row * n_vocab;
     float xv[kSelKeep];
+    // (an EMPTY trailing slice - 63 * ceil(V / 64) >= V, i.e. vocabularies below ~4000 tokens - has lo >= n_vocab: the
+    // fallback element is clamped into the row so nothing is read behind it; its lanes all take the i >= hi path below)
+    const int lo_safe = lo < n_vocab ? lo : n_vocab - 1;
 #pragma unroll
     for (int j = 0; j < kSelKeep; ++j) {
         const int i = lo + tid + 256 * j;
-        xv[j] = x[i < hi ? i : lo];
+        xv[j] = x[i < hi ? i : lo_safe];
         adj_buf[tid + 256 * j] = 0.f;
     }
     __syncthreads();

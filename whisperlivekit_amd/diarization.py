@@ -13,7 +13,9 @@ implemented by the reference's ``SortformerDiarizationOnline``
 
 The Sortformer network itself (NeMo ``SortformerEncLabelModel``: FastConformer + Transformer + streaming
 speaker cache) is third-party code that is NOT part of the reference tree; its HIP port is the
-``SortformerBackend`` implementation.  Parity of anything NeMo-side is unpinned here (no NeMo, no weights).
+``SortformerBackend`` implementation.  Parity: the feature front end and the FastConformer are pinned by the independent
+ports of those NeMo modules in `transformers` (tests/golden/sortformer_hf_kat.npz); the Transformer blocks' wiring, the
+sigmoid head and the speaker-cache update are restatements (no NeMo, no weights offline).
 """
 from __future__ import annotations
 
@@ -76,13 +78,22 @@ class HipMelSpectrogram:
     """128-bin log-mel features on the GPU (wlk_melspec_*): NeMo FilterbankFeatures with window 25 ms,
     stride 10 ms, n_fft 512, pre-emphasis 0.97, log(x + 2^-24), normalize "NA".  ``dither`` (NeMo adds
     1e-5 * N(0,1) because the reference never puts its preprocessor in eval mode) is off by default so that
-    the features are reproducible; pass a numpy Generator to get it."""
+    the features are reproducible; pass a numpy Generator to get it.
+
+    Frame count: the centred STFT yields ``len // hop + 1`` frames and ``get_features`` returns all of them, but
+    ``FilterbankFeatures.get_seq_len`` of the NeMo the reference requires (nemo-toolkit >= 3, pyproject.toml:80-85)
+    counts ``len // hop`` VALID frames and fills the rest with pad_value 0 - the rule transformers' port of the module
+    (``ParakeetFeatureExtractor``: ``features_lengths``, ``input_features *= mask``) implements and
+    tests/golden/sortformer_hf_kat.npz pins.  So a 1.0 s chunk is 100 log-mel frames plus one all-zero frame, and the
+    reference hands all 101 to the network (sortformer_backend.py:279-296).  ``seq_len_plus_one=True`` gives the
+    pre-2.0 NeMo rule (``len // hop + 1`` valid frames, nothing zeroed)."""
 
     def __init__(self, device: int = 0, sample_rate: int = 16000, n_mels: int = 128, n_fft: int = 512,
                  window_size: float = 0.025, window_stride: float = 0.01, preemph: float = 0.97,
-                 max_seconds: float = 4.0):
+                 max_seconds: float = 4.0, seq_len_plus_one: bool = False):
         self.lib = _lib.load()
         self.n_mels, self.n_fft = n_mels, n_fft
+        self.seq_len_plus_one = seq_len_plus_one
         self.win_length = int(window_size * sample_rate)
         self.hop = int(window_stride * sample_rate)
         filters = np.ascontiguousarray(mel_filterbank(n_mels, sample_rate, n_fft))
@@ -93,7 +104,8 @@ class HipMelSpectrogram:
                                                preemph, 2.0 ** -24, int(max_seconds * sample_rate), C.byref(self._h)))
 
     def __call__(self, pcm: np.ndarray, dither: Optional[np.random.Generator] = None) -> np.ndarray:
-        """-> [n_frames, n_mels] float32 (time-major), n_frames = len(pcm) // hop + 1."""
+        """-> [n_frames, n_mels] float32 (time-major), n_frames = len(pcm) // hop + 1; frames from ``len(pcm) // hop``
+        on are zero unless ``seq_len_plus_one`` (see the class docstring)."""
         a = np.ascontiguousarray(pcm, dtype=np.float32).reshape(-1)
         if dither is not None:
             a = a + np.float32(1e-5) * dither.standard_normal(a.shape[0], dtype=np.float32)
@@ -102,6 +114,8 @@ class HipMelSpectrogram:
         n = C.c_int()
         _lib.check(self.lib.wlk_melspec_run(self._h, a.ctypes.data_as(C.c_void_p), a.shape[0],
                                             out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        if not self.seq_len_plus_one:
+            out[a.shape[0] // self.hop: n.value] = 0.0
         return out[: n.value]
 
     def close(self):

@@ -385,6 +385,12 @@ class HipSession:
         _lib.check(self.lib.wlk_export(self._h, what.encode(), buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(n)))
         return buf[: n.value].copy()
 
+    def step_stats(self) -> Dict[str, float]:
+        """Wall time of this session's graph-replayed single-token steps so far (wlk_session_step_stats)."""
+        n, wall, launch = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _lib.check(self.lib.wlk_session_step_stats(self._h, C.byref(n), C.byref(wall), C.byref(launch)))
+        return dict(steps=int(n.value), wall_ns=int(wall.value), launch_ns=int(launch.value))
+
     def prof_begin(self) -> None:
         _lib.check(self.lib.wlk_prof_begin(self._h))
 

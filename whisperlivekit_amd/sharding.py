@@ -74,7 +74,9 @@ def replicated_model(dims: ModelDims, packed: Optional[Mapping[str, np.ndarray]]
                      timing: Optional[dict] = None) -> HipWhisperModel:
     """Every rank gets a full weight replica: rank ``src`` packs the arena on the host, all ranks
     allocate it as a torch CUDA tensor, one RCCL broadcast fills it, the library adopts the pointer.
-    ``timing`` (optional dict) receives ``broadcast_ms``: wall time of the collective on this rank."""
+    ``timing`` (optional dict) receives ``broadcast_ms``: wall time of the collective on this rank, and ``finalize_ms``:
+    the rank's own wlk_model_finalize (the X3 weight images are packed per rank from the broadcast fp32 arena - 1.5 x its
+    bytes stay local instead of crossing xGMI)."""
     import time
     import torch
     import torch.distributed as dist
@@ -95,5 +97,8 @@ def replicated_model(dims: ModelDims, packed: Optional[Mapping[str, np.ndarray]]
         timing["arena_bytes"] = int(n) * 4
     model = HipWhisperModel(dims, device, arena=arena)
     model.set_alignment_heads(alignment_heads)
-    model.finalize()
+    t1 = time.perf_counter()
+    model.finalize()          # per rank, after the broadcast: derived weight images (X3 planes, the stacked cross-K|V matrix)
+    if timing is not None:
+        timing["finalize_ms"] = round(1e3 * (time.perf_counter() - t1), 3)
     return model

@@ -10,7 +10,9 @@ whisperlivekit/diarization/sortformer_backend.py:86-131, driven one chunk at a t
 
 ``HipSortformerModel`` implements ``diarization.SortformerBackend``; weights arrive as a NeMo-named state dict
 (``load_nemo_checkpoint``) or are synthesised for tests/benchmarks.  NeMo is not in the reference tree: the
-arithmetic here restates NeMo's published modules and its parity is UNPINNED (no NeMo, no checkpoint offline).
+arithmetic here restates NeMo's published modules.  Pinned since round 5 by transformers' independent ports
+(ParakeetFeatureExtractor, ParakeetEncoder: tests/golden/sortformer_hf_kat.npz): log-mel, sub-sampling stem, the 17
+Conformer blocks; still unpinned (no NeMo, no checkpoint offline): Transformer-block wiring, sigmoid head, cache update.
 There is no CPU fallback: without libwlk_hip.so / a GPU the constructor raises.
 """
 from __future__ import annotations
