@@ -1,0 +1,109 @@
+"""a15, the `.pt` branch (round 5 hygiene): an openai-layout checkpoint on disk - {"dims": {...}, "model_state_dict": {...}},
+the first branch of the reference's load_model (whisper/__init__.py:520-560) - through `backend.load_openai_checkpoint` and
+`HipSimulStreamingASR(model_path=...)`.  Real checkpoints hold fp16 tensors that the reference loads into fp32 parameters
+("fp16 checkpoint values are loaded into fp32 nn.Parameters"): the fp16 file must behave exactly like its values
+upcast to fp32."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from whisperlivekit_amd import backend as B
+from whisperlivekit_amd.dims import MODEL_DIMS
+from whisperlivekit_amd.engine import pack_state_dict
+
+
+def write_checkpoint(path, name, dtype):
+    from dataclasses import asdict
+    dims = MODEL_DIMS[name]
+    sd = {k: torch.from_numpy(v).to(dtype) for k, v in H.synth_sd(name).items()}
+    torch.save({"dims": asdict(dims), "model_state_dict": sd}, path)
+    return dims, sd
+
+
+def test_openai_layout_checkpoint_is_read_back(tmp_path):
+    path = str(tmp_path / "micro.pt")
+    dims, sd = write_checkpoint(path, "micro.en", torch.float16)
+    got_dims, got_sd = B.load_openai_checkpoint(path)
+    assert got_dims == dims and set(got_sd) == set(sd)
+    assert all(v.dtype == torch.float16 for v in got_sd.values())
+    # the packed arena holds the fp16 VALUES as fp32 (what nn.Parameter.copy_ does in the reference)
+    packed = pack_state_dict(dims, got_sd)
+    up = pack_state_dict(dims, {k: v.float().numpy() for k, v in sd.items()})
+    assert all(packed[k].dtype == np.float32 and np.array_equal(packed[k], up[k]) for k in up)
+    w = packed["dec.tok_emb"]
+    assert np.array_equal(w, w.astype(np.float16).astype(np.float32)) and float(np.abs(w).max()) > 0
+
+
+def test_a_file_that_is_not_an_openai_checkpoint_is_refused(tmp_path):
+    path = str(tmp_path / "other.pt")
+    torch.save({"state_dict": {}}, path)
+    with pytest.raises(ValueError):
+        B.load_openai_checkpoint(path)
+
+
+def _run(asr, audio, n_chunks):
+    proc = B.HipSimulStreamingOnlineProcessor(asr)
+    proc.model.decision_log = []
+    words = []
+    for i in range(n_chunks):
+        proc.insert_audio_chunk(audio[i * 8000:(i + 1) * 8000].copy(), (i + 1) * 0.5)
+        words.append([(t.start, t.end, t.text) for t in proc.process_iter()[0]])
+    log = proc.model.decision_log
+    proc.close()
+    return log, words
+
+
+@pytest.mark.gpu
+def test_model_path_streams_like_the_reference_and_fp16_values_are_upcast(tmp_path):
+    """fp32 file: `HipSimulStreamingASR(model_path=...)` replays stream_micro_12s decision for decision (the golden trace of
+    the reference on the same weights).  fp16 file: identical, bit for bit, to the same values handed over as an fp32
+    state dict."""
+    from test_gpu_parity import with_teacher
+    from test_oracle_golden import replay_stream
+    from test_policy_golden import check_loop_stream
+    case = "micro_12s"
+    p32 = str(tmp_path / "micro32.pt")
+    write_checkpoint(p32, "micro.en", torch.float32)
+    g0 = H.golden_json(f"stream_{case}.json")
+    opened = []
+
+    def make(model_name, cfg_over, seed=0):
+        asr = B.HipSimulStreamingASR(model_name, model_path=p32, **H.asr_kwargs(cfg_over))
+        from whisperlivekit_amd import policy as P
+
+        class P2(B.HipSimulStreamingOnlineProcessor):
+            def new_speaker(self, speaker, start):
+                return super().new_speaker(P.ChangeSpeaker(speaker=speaker, start=start))
+        proc = P2(asr)
+        proc.model.decision_log = []
+        opened.append((proc, asr))
+        return proc
+
+    def run(teacher):
+        g, proc, got = replay_stream(case, with_teacher(make, teacher))
+        emitted = [[(t.start, t.end, t.text) for t in toks] for ev, toks, _ in got if ev["kind"] == "chunk"]
+        return g, proc, got, H.compare_decisions(g, proc.model.decision_log, emitted)
+
+    def compare(res):
+        assert res[3]["mismatch"] is None, res[3]
+        return res[3]["tie_divergence"]
+
+    try:
+        (g, proc, got, r), ties = H.run_resynced(run, g0, compare)
+        assert r["calls"] == len(g["calls"]) and r["identical"] == r["decisions"] and r["words_identical"], r
+        check_loop_stream(g, proc, got)
+    finally:
+        for proc, asr in opened:
+            proc.close()
+            asr.hip_model.close()
+    p16 = str(tmp_path / "micro16.pt")
+    _, sd16 = write_checkpoint(p16, "micro.en", torch.float16)
+    audio = H.stream_audio(case)
+    a = B.HipSimulStreamingASR("micro.en", model_path=p16)
+    b = B.HipSimulStreamingASR("micro.en", state_dict={k: v.float().numpy() for k, v in sd16.items()})
+    try:
+        assert _run(a, audio, 12) == _run(b, audio, 12)
+    finally:
+        a.hip_model.close()
+        b.hip_model.close()

@@ -1,5 +1,7 @@
 """NLLB-200 / M2M-100 translation network: oracle and HIP library against `transformers`' own
 M2M100ForConditionalGeneration on seeded weights (tests/golden/nllb_kat.npz, scripts/gen_golden_nllb.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -245,6 +247,60 @@ def test_hip_600m_shape_matches_the_oracle():
             got = sess.logits()[0]
             np.testing.assert_allclose(got, want, rtol=0, atol=5e-3, err_msg=f"step {i}")
             assert int(got.argmax()) == int(want.argmax()) or abs(want[int(got.argmax())] - want.max()) < 1e-3
+    finally:
+        sess.close()
+        model.close()
+
+
+# ---- the 600M shape against `transformers`' own M2M100 (scripts/gen_golden_nllb_600m.py -> tests/golden/nllb_600m_kat.npz)
+def _kat_600m():
+    z = np.load(os.path.join(H.GOLDEN, "nllb_600m_kat.npz"))
+    steps, flat, off = [], z["step_tokens"], 0
+    for n in z["steps"]:
+        steps.append(flat[off:off + int(n)][None].astype(np.int64))
+        off += int(n)
+    return z, steps
+
+
+def _check_600m_row(z, i, row, atol):
+    probe = z["probe_ids"]
+    np.testing.assert_allclose(row[probe], z[f"probe{i}"], rtol=0, atol=atol, err_msg=f"step {i}: probes")
+    np.testing.assert_allclose(row[z[f"top_ids{i}"]], z[f"top_vals{i}"], rtol=0, atol=atol, err_msg=f"step {i}: top-16 values")
+    m = float(row.max())
+    lse = m + float(np.log(np.exp((row - m).astype(np.float64)).sum()))
+    assert abs(lse - float(z[f"lse{i}"])) <= atol, (i, lse, float(z[f"lse{i}"]))
+    best = int(row.argmax())
+    assert best == int(z[f"top_ids{i}"][0]) or float(z[f"top_vals{i}"][0]) - float(row[int(z[f"top_ids{i}"][0])]) < atol
+
+
+def test_oracle_600m_shape_matches_transformers():
+    """oracle/nllb_oracle.py at NLLB-200-distilled-600M's dimensions == transformers' M2M100ForConditionalGeneration on the
+    same seeded weights: encoder output and four cached decoder steps (top-16, log-sum-exp, 1 024 probe logits)."""
+    z, steps = _kat_600m()
+    cfg = nllb.NLLB_200_DISTILLED_600M
+    torch.set_num_threads(8)
+    oracle = NllbOracle(cfg, nllb.synth_state_dict(cfg, int(z["seed"])))
+    enc = oracle.encode(z["src"])
+    np.testing.assert_allclose(enc.numpy(), z["enc"], rtol=0, atol=2e-4)
+    cache = oracle.new_cache()
+    for i, toks in enumerate(steps):
+        row = oracle.decode(torch.from_numpy(toks), enc, cache)[0, -1].numpy()
+        _check_600m_row(z, i, row, 5e-4)
+
+
+@pytest.mark.gpu
+def test_hip_600m_shape_matches_transformers():
+    """The HIP NLLB path at the 600M dimensions against the same transformers known answers, logits <= 1e-3."""
+    z, steps = _kat_600m()
+    cfg = nllb.NLLB_200_DISTILLED_600M
+    model = nllb.HipNllbModel.from_hf_state_dict(cfg, nllb.synth_state_dict(cfg, int(z["seed"])), device=0, max_src=64, max_tgt=32)
+    sess = model.new_session(1)
+    try:
+        sess.encode(z["src"])
+        np.testing.assert_allclose(sess.encoder_output(), z["enc"], rtol=0, atol=1e-3)
+        for i, toks in enumerate(steps):
+            sess.decode(toks, first=(i == 0))
+            _check_600m_row(z, i, sess.logits()[0], 1e-3)
     finally:
         sess.close()
         model.close()
