@@ -108,3 +108,32 @@ def test_production_operand_route_of_the_x3_attention_equals_the_diagnostic_one(
     assert rc == 0, lib.wlk_diag_last_error()
     assert np.isfinite(o_epi).all() and float(np.abs(o_epi).max()) > 1e-3
     assert np.array_equal(o_epi.view(np.uint32), o_pack.view(np.uint32)), float(np.abs(o_epi - o_pack).max())
+
+
+@pytest.mark.parametrize("M,N,K,flags", [(1500, 6144, 512, 4), (1500, 5120, 1280, 1), (1500, 2048, 512, 3), (2999, 1536, 384, 0),
+                                         (700, 1152, 64, 0)])
+def test_persistent_walk_is_bit_identical_to_one_workgroup_per_tile(M, N, K, flags, monkeypatch):
+    """Round 5: a workgroup of the wide kernel walks several tiles with ONE slab stream through its LDS ring (the next tile's
+    first slabs land under the previous tile's epilogue).  Same MFMA sequence per tile, so the results must equal, bit for
+    bit, the launch with one workgroup per tile (WLK_X3_PERSIST=0): 768 tiles = 3 per workgroup, 640 = ragged 3 / 2,
+    GELU + residual-free epilogue, M that is no multiple of 96, K = two slabs (the ring never holds a whole tile ahead)."""
+    lib = _lib.load()
+    rng = np.random.default_rng(M + N)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    out = {}
+    for persist in ("1", "0"):
+        monkeypatch.setenv("WLK_X3_PERSIST", persist)
+        assert lib.wlk_diag_env_refresh() == 0
+        c = np.full((M, N), np.nan, np.float32)
+        assert lib.wlk_diag_linear_x3(vp(a), vp(w), vp(bias), M, N, K, flags & 5, 0.5, N // 2, vp(c)) == 0, lib.wlk_diag_last_error()
+        out[persist] = c
+    monkeypatch.delenv("WLK_X3_PERSIST")
+    assert lib.wlk_diag_env_refresh() == 0
+    assert np.isfinite(out["1"]).all()
+    assert np.array_equal(out["1"].view(np.uint32), out["0"].view(np.uint32)), float(np.abs(out["1"] - out["0"]).max())
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
+    if not flags & 1:
+        ref[:, :N // 2] *= 0.5 if flags & 4 else 1.0
+        assert float(np.abs(out["1"] - ref).max()) < 1e-4 * max(1.0, float(np.abs(ref).max()))

@@ -242,8 +242,10 @@ struct X3GemmArgs {
     float scale = 1.f;
     int scale_cols = 0;
     int scale_period = 0;
-    int batch = 0;                        // > 0: grid.y = batch; A3 = z.in[i] (X3), C = z.out[i], R = z.res[i]
-    int map_mode = 0;                     // probe only (WLK_X3_MAP): 1 = plain tile order, 2 = 2 x 4 bands
+    int batch = 0;                        // > 0: `batch` sessions in one launch; A3 = z.in[i] (X3), C = z.out[i], R = z.res[i]
+    int walk_banded = 0;                  // set by launch_gemm_x3: the tile walk of the persistent workgroups (gemm_x3.hip) -
+    int pair_probe = 0;                   // timing probe only (WLK_X3_PAIRPROBE): operand addresses of a row-pair-interleaved layout (wrong results)
+    int walk_slots = 0;                   // XCD bands or plain row-major order; slots per XCD (banded) or in total, sessions included
     // Result in the X3 format instead of fp32 (the operands of enc_attention_x3_kernel): columns [0, vt_col0) as X3 rows
     // (row m at C3 + m * 3 * ldc3), columns [vt_col0, N) TRANSPOSED - column n is row n - vt_col0 of a [N - vt_col0][vt_ld]
     // X3 matrix at C3 + vt_off whose chunks run along m; stored chunk u of every 32-row group holds rows 4 u .. 4 u + 3 and

@@ -1231,7 +1231,11 @@ static bool gemm_can_fuse_layernorm(int M, int N, int K) {
 // 200.5-203.5 audio-s/s, 8 streams 358-363 either way), so the separate launch stays the default; WLK_PREFILL_LN_FUSE=1
 // turns the fused form on (bit-identical: tests/test_gpu_parity.py::test_prefill_gemm_fuses_the_layernorm).
 static std::atomic<int> g_prefill_ln_fuse{-1};          // -1: not read yet; the switch is read ONCE (this sits on the decode path)
-void refresh_env_switches() { g_prefill_ln_fuse.store(-1, std::memory_order_relaxed); }   // wlk_diag_env_refresh: the parity test flips the switch inside one process
+void x3_refresh_env_switches();                          // gemm_x3.hip: WLK_X3_PERSIST
+void refresh_env_switches() {
+    g_prefill_ln_fuse.store(-1, std::memory_order_relaxed);
+    x3_refresh_env_switches();
+}   // wlk_diag_env_refresh: the parity test flips the switch inside one process
 bool gemm_fuses_layernorm(int M, int N, int K) {
     int on = g_prefill_ln_fuse.load(std::memory_order_relaxed);
     if (on < 0) {

@@ -12,6 +12,7 @@
 // Per slab and compute wave: 36 MFMAs (2 k-steps x 3 row blocks x 6 plane products; 1152 cycles of matrix pipe), 24
 // fragment reads; per loader wave 11 DMA pieces.  Algorithmic work = 2 M N K flop at fp32 accuracy; the matrix pipe executes 6x that in bf16.
 #include <atomic>
+#include <cstdint>
 #include <cstdlib>
 #include <type_traits>
 
@@ -89,9 +90,9 @@ constexpr int XW_SLAB_BYTES = XW_ROWS * XW_ROW_BYTES;     // 43 008
 constexpr int XW_PIECES = XW_SLAB_BYTES / 1024;           // 42 DMA pieces per slab
 constexpr int XW_NPW = 11;                                // per loader wave (loaders 2 and 3 issue piece 41 once more: same bytes)
 constexpr int XW_NB = 3;                                  // ring slots
-constexpr int XW_DT = XW_NB - 1;                          // slabs in flight beyond the one being multiplied
 constexpr int XW_NF = 12;                                 // fragments per k-step and wave: 3 x 3 A + 3 B
-constexpr size_t XW_LDS_BYTES = (size_t)XW_NB * XW_SLAB_BYTES;
+constexpr int XW_STAGE_SPLIT = XW_SLAB_BYTES / ((XW_BN + 4) * 4);   // rows of an X3 result's LDS transpose that fit one ring slot (81)
+constexpr size_t XW_LDS_BYTES = (size_t)XW_NB * XW_SLAB_BYTES + (size_t)(XW_BM - XW_STAGE_SPLIT) * (XW_BN + 4) * 4;
 // plane products of one fp32 product, small terms first: (lo, hi) (hi, lo) (mid, mid) (mid, hi) (hi, mid) (hi, hi)
 constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 static_assert(XW_PIECES * 1024 == XW_SLAB_BYTES, "a slab is a whole number of 1 KiB pieces");
@@ -121,6 +122,16 @@ __device__ __forceinline__ void xw_read_frags(xf32x4 (&f)[XW_NF], const unsigned
 // wave beside each compute wave on every SIMD the two instruction streams overlap.
 // One workgroup barrier per slab: the loaders arrive when their pieces of slab t + 1 have landed, the compute waves when
 // they have read the last fragments of slab t; behind it slab t + 1 is readable and the slot of slab t - 1 is free.
+//
+// Round 5 - PERSISTENT workgroups, one slab stream across tiles.  The launch is at most one workgroup per CU (the ring
+// is 126 KB, so a CU holds one anyway); a workgroup walks its XCD's tile list with stride = workgroups per XCD, and the
+// slabs of all its tiles form ONE stream through the ring: when the compute waves multiply the last slab of tile i the
+// loaders have slabs 0 and 1 of tile i + 1 landed / in flight and issue slab 2 behind the next barrier - the cold start
+// of a tile (two slabs from L2 / the fabric) and the epilogue stores of the previous one overlap instead of adding up
+// (round 4, one workgroup per tile: 81 us for the 768-tile cross-K|V projection whose loaders alone need 58 and whose
+// MFMAs alone 52).  Barrier count per tile = slabs (+ 2 around the LDS transpose of an X3 result), identical on both
+// sides; a workgroup whose list is empty returns before the first barrier.  A launch of <= one tile per CU is the round-4
+// schedule, instruction for instruction in the loop.
 // ABL (timing probe only, WLK_X3_ABL): 1 = the loaders run, the compute waves skip their MFMAs and fragment reads;
 // 2 = the compute waves run, the loaders issue nothing; 3 = MFMAs only (no fragment reads, no DMA)
 template <int ABL>
@@ -132,78 +143,115 @@ __global__ __launch_bounds__(512) void gemm_x3_wide_kernel(X3GemmArgs g) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool batched = g.batch > 0;
-    const unsigned short* const gA = batched ? reinterpret_cast<const unsigned short*>(table_at(g.z.in, blockIdx.y)) : g.A3;
-    float* const gC = batched ? table_at(g.z.out, blockIdx.y) : g.C;
-    const float* const gR = batched ? table_at(g.z.res, blockIdx.y) : g.R;
-    // XCD-aware tile mapping, as in gemm_nt_f32_kernel: 4 row bands x 2 column bands, one per XCD
+    // ---- the tile walk: slot -> (session, tile row, tile column).  Banded (tiles_m >= 8): XCD-aware as in
+    // gemm_nt_f32_kernel - 4 row bands x 2 column bands, one per XCD (workgroup id & 7), slots of a band row-major, sessions
+    // outermost; this workgroup takes slots first, first + stride, ... of its XCD.  Plain: slots = tiles, row-major.
     const int tiles_m = (g.M + XW_BM - 1) / XW_BM, tiles_n = (g.N + XW_BN - 1) / XW_BN;
-    int tile_m, tile_n;
-    if (tiles_m >= 8 && g.map_mode == 2) {          // probe: 2 row bands x 4 column bands
-        const int band_m = (tiles_m + 1) / 2, band_n = (tiles_n + 3) / 4;
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        tile_m = (xcd >> 2) * band_m + slot / band_n;
-        tile_n = (xcd & 3) * band_n + slot % band_n;
-        if (slot >= band_m * band_n || tile_m >= tiles_m || tile_n >= tiles_n) return;
-    } else if (tiles_m >= 8 && g.map_mode == 0) {
-        const int band_m = (tiles_m + 3) / 4, band_n = (tiles_n + 1) / 2;
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        tile_m = (xcd >> 1) * band_m + slot / band_n;
-        tile_n = (xcd & 1) * band_n + slot % band_n;
-        if (slot >= band_m * band_n || tile_m >= tiles_m || tile_n >= tiles_n) return;   // padding workgroups
-    } else {
-        tile_m = blockIdx.x / tiles_n;
-        tile_n = blockIdx.x - tile_m * tiles_n;
-        if (tile_m >= tiles_m) return;
-    }
-    const int m0 = tile_m * XW_BM, n0 = tile_n * XW_BN;
+    const bool banded = g.walk_banded != 0;
+    const int band_m = banded ? (tiles_m + 3) / 4 : tiles_m, band_n = banded ? (tiles_n + 1) / 2 : tiles_n;
+    const int per_session = band_m * band_n;
+    const int xcd = banded ? (int)(blockIdx.x & 7) : 0;
+    const int first = banded ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int stride = banded ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int limit = g.walk_slots;
+    const int band_m0 = banded ? (xcd >> 1) * band_m : 0, band_n0 = banded ? (xcd & 1) * band_n : 0;
+    auto decode = [&](int slot, int& tm, int& tn, int& b) -> bool {
+        b = slot / per_session;
+        const int r = slot - b * per_session;
+        const int rm = r / band_n;
+        tm = band_m0 + rm;
+        tn = band_n0 + (r - rm * band_n);
+        return tm < tiles_m && tn < tiles_n;
+    };
+    auto advance = [&](int slot) {          // first slot >= `slot` (in this workgroup's sequence) that is a tile
+        int tm, tn, b;
+        while (slot < limit && !decode(slot, tm, tn, b)) slot += stride;
+        return slot;
+    };
+    const int slot0 = advance(first);
+    if (slot0 >= limit) return;             // padding workgroup (both roles leave before any barrier)
     const int nslab = g.K / 32;
+    const bool x3_out = g.x3_out;
 
     if (wave >= 4) {
         // ---- loader: piece j covers LDS bytes [1024 j, 1024 j + 1024) of a slab; lane l lands at byte 1024 j + 16 l = a
         // (row, swizzled unit) of the slab image, and fetches that row's logical unit from the X3 operand -----------------
         const int lw = wave - 4;
         const char* src[XW_NPW];
-        int piece_of[XW_NPW];
+        int piece_of[XW_NPW], row_of[XW_NPW], unit_of[XW_NPW];
 #pragma unroll
         for (int i = 0; i < XW_NPW; ++i) {
             const int j = min(lw + 4 * i, XW_PIECES - 1);
             piece_of[i] = j;
             const int byte = 1024 * j + 16 * lane;
-            const int row = byte / XW_ROW_BYTES;
-            const int unit = ((byte - row * XW_ROW_BYTES) >> 4) ^ ((row >> 2) & 3);
-            if (row < XW_BM)
-                src[i] = reinterpret_cast<const char*>(gA) + ((long)min(m0 + row, g.M - 1) * 3 * g.lda) * 2 + unit * 16;
-            else
-                src[i] = reinterpret_cast<const char*>(g.W3) + ((long)min(n0 + row - XW_BM, g.N - 1) * 3 * g.K) * 2 + unit * 16;
+            row_of[i] = byte / XW_ROW_BYTES;
+            unit_of[i] = (((byte - row_of[i] * XW_ROW_BYTES) >> 4) ^ ((row_of[i] >> 2) & 3)) * 16;
         }
-        auto issue_slab = [&](int slab) {     // slab (clamped: the tail re-fetches the last one into a free slot)
-            if constexpr (ABL >= 2) return;
-            const int slot = slab % XW_NB;
-            const long adv = (long)min(slab, nslab - 1) * XW_ROW_BYTES;
-            x3_static_for<XW_NPW>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + adv),
-                                                 (__attribute__((address_space(3))) void*)(lds + slot * XW_SLAB_BYTES + piece_of[i] * 1024),
-                                                 16, 0, 0);
-            });
+        auto set_src = [&](int slot) {
+            int tm, tn, b;
+            decode(slot, tm, tn, b);
+            const int m0 = tm * XW_BM, n0 = tn * XW_BN;
+            const unsigned short* const gA = batched ? reinterpret_cast<const unsigned short*>(table_at(g.z.in, (unsigned)b)) : g.A3;
+#pragma unroll
+            for (int i = 0; i < XW_NPW; ++i) {
+                const int row = row_of[i];
+                const bool is_a = row < XW_BM;
+                const int grow = is_a ? min(m0 + row, g.M - 1) : min(n0 + row - XW_BM, g.N - 1);
+                const char* const base = is_a ? reinterpret_cast<const char*>(gA) : reinterpret_cast<const char*>(g.W3);
+                const long row_bytes = (is_a ? g.lda : (long)g.K) * 6;
+                if (g.pair_probe)      // timing probe (WLK_X3_PAIRPROBE): the addresses a row-pair-interleaved operand would have
+                    src[i] = base + (long)(grow >> 1) * 2 * row_bytes + (grow & 1) * XW_ROW_BYTES + unit_of[i];
+                else
+                    src[i] = base + (long)grow * row_bytes + unit_of[i];
+            }
         };
-        issue_slab(0);
-        issue_slab(1);
+        int issue_slot = slot0, s_next = 0, ring = 0;
+        bool more = true;
+        set_src(issue_slot);
+        auto issue_one = [&]() {     // the next slab of the stream into the next ring slot (past the end: the last slab again, into a free slot)
+            if constexpr (ABL < 2) {
+                const long adv = (long)s_next * (g.pair_probe ? 2 * XW_ROW_BYTES : XW_ROW_BYTES);
+                unsigned char* const dst = lds + ring * XW_SLAB_BYTES;
+                x3_static_for<XW_NPW>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + adv),
+                                                     (__attribute__((address_space(3))) void*)(dst + piece_of[i] * 1024), 16, 0, 0);
+                });
+            }
+            ring = ring == XW_NB - 1 ? 0 : ring + 1;
+            if (more && ++s_next == nslab) {
+                const int ns = advance(issue_slot + stride);
+                if (ns < limit) {
+                    issue_slot = ns;
+                    set_src(ns);
+                    s_next = 0;
+                } else {
+                    more = false;
+                    s_next = nslab - 1;
+                }
+            }
+        };
+        issue_one();
+        issue_one();
         xw_wait_vmcnt<XW_NPW>();
         __builtin_amdgcn_s_barrier();
-        for (int tt = 0; tt < nslab; ++tt) {
-            issue_slab(tt + XW_DT);
-            xw_wait_vmcnt<XW_NPW>();           // this loader's pieces of slab tt + 1 have landed
-            __builtin_amdgcn_s_barrier();
+        for (int slot = slot0; slot < limit; slot = advance(slot + stride)) {
+            for (int tt = 0; tt < nslab; ++tt) {
+                issue_one();
+                xw_wait_vmcnt<XW_NPW>();           // this loader's pieces of the slab behind the one being multiplied have landed
+                __builtin_amdgcn_s_barrier();
+            }
+            if (x3_out) {                          // the compute waves transpose the tile through the ring slot just drained
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
+            }
         }
         xw_wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();          // nothing of this loader is in flight any more: the ring may be reused (epilogue staging)
+        __builtin_amdgcn_s_barrier();          // nothing of this loader is in flight any more
         return;
     }
 
     // ---- compute waves ------------------------------------------------------------------------------------------------
-    const int col = n0 + 32 * wave + (lane & 31);
-    const float bias = g.bias ? g.bias[min(col, g.N - 1)] : 0.f;
     // fragment byte addresses inside a ring slot: lane (r, hi) reads row r (+ 32 i), chunk 2 s + hi, plane p
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const int r = lane & 31, hi = lane >> 5, swz = (r >> 2) & 3;
@@ -218,114 +266,156 @@ __global__ __launch_bounds__(512) void gemm_x3_wide_kernel(X3GemmArgs g) {
             f_addr[s][9 + p] = lds_base + (unsigned)((XW_BM + 32 * wave + r) * XW_ROW_BYTES) + unit;
         }
     }
-    auto read_frags = [&](xf32x4 (&f)[XW_NF], int slab, const unsigned (&addr)[XW_NF]) {
-        xw_read_frags(f, addr, (unsigned)(slab % XW_NB) * (unsigned)XW_SLAB_BYTES);
-    };
     xf32x16 acc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
     auto mfma_step = [&](const xf32x4 (&f)[XW_NF]) {     // 18 MFMAs: product t of row block i - three independent chains
         x3_static_for<18>([&](auto X) {
             constexpr int x = decltype(X)::value;
             constexpr int t = x / 3, i = x % 3;
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[i * 3 + PA[t]]),
-                                                             __builtin_bit_cast(bf16x8, f[9 + PB[t]]), acc[i], 0, 0, 0);
+            // the WEIGHT rows are the instruction's row operand: accumulator register q of lane (r, hi) is
+            // C[m = 32 i + r][n = (q & 3) + 8 (q >> 2) + 4 hi] - four consecutive columns of ONE row per register quad, so the
+            // epilogue stores 16 bytes per instruction and lane (round 5; with the activations as the row operand a lane held
+            // one column of 16 rows: 48 four-byte stores per lane, and the store tail was issue-bound)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[9 + PB[t]]),
+                                                             __builtin_bit_cast(bf16x8, f[i * 3 + PA[t]]), acc[i], 0, 0, 0);
         });
     };
+    // this lane's sixteen columns of a tile: n0 + 32 wave + 8 j + 4 hi + (0 .. 3), j = 0 .. 3
+    const int col_in_tile = 32 * wave + 4 * hi;
+    auto load_bias = [&](int slot, xf32x4 (&b)[4]) {
+        int tm, tn, bz;
+        decode(slot, tm, tn, bz);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = min(tn * XW_BN + col_in_tile + 8 * j, g.N - 4);
+            b[j] = g.bias ? *reinterpret_cast<const xf32x4*>(g.bias + c) : xf32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    xf32x4 bias_next[4];
+    load_bias(slot0, bias_next);
 
     __builtin_amdgcn_s_barrier();              // slab 0 has landed
+    unsigned ring_off = 0;                     // byte offset of the ring slot of the slab being multiplied
     xf32x4 g0[XW_NF], g1[XW_NF];
-    read_frags(g0, 0, f_addr[0]);
+    xw_read_frags(g0, f_addr[0], ring_off);
     xw_wait_frags(g0);
-    for (int tt = 0; tt < nslab; ++tt) {
-        if constexpr (ABL != 1 && ABL != 3) read_frags(g1, tt, f_addr[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ABL != 1) mfma_step(g0);
-        __builtin_amdgcn_sched_barrier(0);
-        xw_wait_frags(g1);
-        __builtin_amdgcn_s_barrier();          // slab tt + 1 readable; everybody is done with slab tt's fragments
-        if constexpr (ABL != 1 && ABL != 3) read_frags(g0, tt + 1, f_addr[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ABL != 1) mfma_step(g1);
-        __builtin_amdgcn_sched_barrier(0);
-        xw_wait_frags(g0);
-    }
-
-    __builtin_amdgcn_s_barrier();              // the loaders' tail fetches have landed
-    if (g.x3_out) {
-        // ---- result in the X3 format: the tile goes through LDS (the ring is free) so that 8 consecutive columns - or, for
-        // the transposed part, 8 rows in the attention kernel's key order - meet in one thread, which splits them into the
-        // three planes and writes the chunk's 48 contiguous bytes
-        constexpr int PITCH = XW_BN + 4;
-        float* stage = reinterpret_cast<float*>(lds);
-        const bool do_scale = (g.flags & kGemmScaleCols) && (g.scale_period ? col % g.scale_period : col) < g.scale_cols;
+    for (int slot = slot0; slot < limit;) {
+        int tile_m, tile_n, bz;
+        decode(slot, tile_m, tile_n, bz);
+        const int next_slot = advance(slot + stride);
+        const int m0 = tile_m * XW_BM, n0 = tile_n * XW_BN;
+        const int col0 = n0 + col_in_tile;           // + 8 j + e
+        xf32x4 bias[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias[j] = bias_next[j];
+        if (next_slot < limit) load_bias(next_slot, bias_next);       // requested a whole tile ahead of its use
+        auto scaled = [&](int col) { return (g.flags & kGemmScaleCols) && (g.scale_period ? col % g.scale_period : col) < g.scale_cols; };
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float v = acc[i][q] + bias;
-                if (do_scale) v *= g.scale;
-                stage[(32 * i + (q & 3) + 8 * (q >> 2) + 4 * hi) * PITCH + 32 * wave + (lane & 31)] = v;
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        unsigned short* const c3 = batched ? reinterpret_cast<unsigned short*>(table_at(g.z.out, blockIdx.y)) : g.C3;
-        const int tid = threadIdx.x;           // 0 .. 255: the compute waves
-        if (n0 < g.vt_col0) {                  // (tiles do not straddle vt_col0: it is a multiple of the tile width)
-            for (int item = tid; item < XW_BM * (XW_BN / 8); item += 256) {
-                const int row = item >> 4, c = item & 15;
-                if (m0 + row < g.M && n0 + 8 * c < g.N) {
-                    const float4 a = *reinterpret_cast<const float4*>(stage + row * PITCH + 8 * c);
-                    const float4 b = *reinterpret_cast<const float4*>(stage + row * PITCH + 8 * c + 4);
-                    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                    x3_store_chunk(c3 + (long)(m0 + row) * 3 * g.ldc3 + (long)((n0 >> 3) + c) * 24, v);
-                }
-            }
-        } else {
-            unsigned short* const vt = c3 + g.vt_off;
-            for (int item = tid; item < XW_BN * (XW_BM / 8); item += 256) {
-                const int dcol = item / (XW_BM / 8), u = item - dcol * (XW_BM / 8);
-                // stored chunk u of the tile's 96 rows = 32-row group u >> 2, chunk u & 3: rows 4 (u & 3) .. + 3 and 16 more
-                const int r0 = 32 * (u >> 2) + 4 * (u & 3);
-                if (n0 + dcol < g.N && m0 + 32 * (u >> 2) < g.vt_ld) {
-                    float v[8];
+            for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+        for (int tt = 0; tt < nslab; ++tt) {
+            if constexpr (ABL != 1 && ABL != 3) xw_read_frags(g1, f_addr[1], ring_off);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ABL != 1) mfma_step(g0);
+            __builtin_amdgcn_sched_barrier(0);
+            xw_wait_frags(g1);
+            __builtin_amdgcn_s_barrier();          // the next slab of the stream is readable; everybody is done with this slab's fragments
+            ring_off = ring_off == (unsigned)((XW_NB - 1) * XW_SLAB_BYTES) ? 0u : ring_off + (unsigned)XW_SLAB_BYTES;
+            if constexpr (ABL != 1 && ABL != 3) xw_read_frags(g0, f_addr[0], ring_off);     // (last slab of a tile: slab 0 of the next)
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ABL != 1) mfma_step(g1);
+            __builtin_amdgcn_sched_barrier(0);
+            xw_wait_frags(g0);
+        }
+        float* const gC = batched ? table_at(g.z.out, (unsigned)bz) : g.C;
+        const float* const gR = batched ? table_at(g.z.res, (unsigned)bz) : g.R;
+        if (x3_out) {
+            // ---- result in the X3 format: the tile goes through LDS so that 8 consecutive columns - or, for the
+            // transposed part, 8 rows in the attention kernel's key order - meet in one thread, which splits them into the
+            // three planes and writes the chunk's 48 contiguous bytes.  Staging = the ring slot of the slab just multiplied
+            // (the loaders issue nothing into it before the second barrier below; the other two slots hold the next tile's
+            // first slabs) for rows 0 .. 80, plus a small tail region behind the ring for rows 81 .. 95
+            constexpr int PITCH = XW_BN + 4;
+            const unsigned prev_off = ring_off == 0u ? (unsigned)((XW_NB - 1) * XW_SLAB_BYTES) : ring_off - (unsigned)XW_SLAB_BYTES;
+            float* const stage_lo = reinterpret_cast<float*>(lds + prev_off);
+            float* const stage_hi = reinterpret_cast<float*>(lds + XW_NB * XW_SLAB_BYTES) - XW_STAGE_SPLIT * PITCH;
+            auto stage_row = [&](int row) -> float* { return (row < XW_STAGE_SPLIT ? stage_lo : stage_hi) + row * PITCH; };
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int row = r0 + (e & 3) + 16 * (e >> 2);
-                        v[e] = m0 + row < g.M ? stage[row * PITCH + dcol] : 0.f;
+            for (int i = 0; i < 3; ++i) {
+                float* const srow = stage_row(32 * i + r) + col_in_tile;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xf32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[i][4 * j + e] + bias[j][e];
+                        if (scaled(col0 + 8 * j + e)) v[e] *= g.scale;
                     }
-                    x3_store_chunk(vt + (long)(n0 + dcol - g.vt_col0) * 3 * g.vt_ld + (long)((m0 >> 3) + u) * 24, v);
+                    *reinterpret_cast<xf32x4*>(srow + 8 * j) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            unsigned short* const c3 = batched ? reinterpret_cast<unsigned short*>(gC) : g.C3;
+            const int tid = threadIdx.x;           // 0 .. 255: the compute waves
+            if (n0 < g.vt_col0) {                  // (tiles do not straddle vt_col0: it is a multiple of the tile width)
+                for (int item = tid; item < XW_BM * (XW_BN / 8); item += 256) {
+                    const int row = item >> 4, c = item & 15;
+                    if (m0 + row < g.M && n0 + 8 * c < g.N) {
+                        const float4 a = *reinterpret_cast<const float4*>(stage_row(row) + 8 * c);
+                        const float4 b = *reinterpret_cast<const float4*>(stage_row(row) + 8 * c + 4);
+                        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                        x3_store_chunk(c3 + (long)(m0 + row) * 3 * g.ldc3 + (long)((n0 >> 3) + c) * 24, v);
+                    }
+                }
+            } else {
+                unsigned short* const vt = c3 + g.vt_off;
+                for (int item = tid; item < XW_BN * (XW_BM / 8); item += 256) {
+                    const int dcol = item / (XW_BM / 8), u = item - dcol * (XW_BM / 8);
+                    // stored chunk u of the tile's 96 rows = 32-row group u >> 2, chunk u & 3: rows 4 (u & 3) .. + 3 and 16 more
+                    const int r0 = 32 * (u >> 2) + 4 * (u & 3);
+                    if (n0 + dcol < g.N && m0 + 32 * (u >> 2) < g.vt_ld) {
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int row = r0 + (e & 3) + 16 * (e >> 2);
+                            v[e] = m0 + row < g.M ? stage_row(row)[dcol] : 0.f;
+                        }
+                        x3_store_chunk(vt + (long)(n0 + dcol - g.vt_col0) * 3 * g.vt_ld + (long)((m0 >> 3) + u) * 24, v);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // the staging slot is the loaders' again
+        } else {
+            // epilogue: acc[i][4 j + e] is C[m0 + 32 i + r][col0 + 8 j + e]: 16-byte stores (and residual loads)
+            const bool gelu = (g.flags & kGemmGelu) != 0, has_res = (g.flags & kGemmResidual) != 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int row = m0 + 32 * i + r;
+                const bool row_ok = row < g.M;
+                xf32x4 res[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    res[j] = has_res ? *reinterpret_cast<const xf32x4*>(gR + (long)min(row, g.M - 1) * g.ldr + min(col0 + 8 * j, g.N - 4))
+                                     : xf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xf32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[i][4 * j + e] + bias[j][e];
+                        if (scaled(col0 + 8 * j + e)) v[e] *= g.scale;
+                        if (gelu) v[e] = x3_gelu_erf(v[e]);
+                        v[e] += res[j][e];
+                    }
+                    if (row_ok && col0 + 8 * j < g.N) *reinterpret_cast<xf32x4*>(gC + (long)row * g.ldc + col0 + 8 * j) = v;
                 }
             }
         }
-        return;
+        slot = next_slot;
     }
-    // epilogue: acc[i][q] is C[row = 32 i + (q & 3) + 8 (q >> 2) + 4 (lane >> 5)][col] of the tile
-    if (col < g.N) {
-        const bool do_scale = (g.flags & kGemmScaleCols) && (g.scale_period ? col % g.scale_period : col) < g.scale_cols;
-        const bool gelu = (g.flags & kGemmGelu) != 0, has_res = (g.flags & kGemmResidual) != 0;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int row_base = m0 + 32 * i + 4 * hi;
-            float res[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int row = row_base + (q & 3) + 8 * (q >> 2);
-                res[q] = has_res ? gR[(long)min(row, g.M - 1) * g.ldr + col] : 0.f;
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int row = row_base + (q & 3) + 8 * (q >> 2);
-                float v = acc[i][q] + bias;
-                if (do_scale) v *= g.scale;
-                if (gelu) v = x3_gelu_erf(v);
-                v += res[q];
-                if (row < g.M) gC[(long)row * g.ldc + col] = v;
-            }
-        }
-    }
+    __builtin_amdgcn_s_barrier();              // the loaders' tail fetches have landed: the workgroup may leave
 }
 
 bool gemm_x3_wide_applicable(int M, int N, int K, long lda) {
@@ -333,12 +423,20 @@ bool gemm_x3_wide_applicable(int M, int N, int K, long lda) {
         const char* e = getenv("WLK_X3");
         return !(e && e[0] == '0');
     }();
-    return on && M >= 256 && N >= 1024 && K >= 64 && K % 32 == 0 && lda % 8 == 0;
+    return on && M >= 256 && N >= 1024 && N % 4 == 0 && K >= 64 && K % 32 == 0 && lda % 8 == 0;
 }
+
+static std::atomic<int> g_x3_persist{-1};                // -1: WLK_X3_PERSIST not read yet
+void x3_refresh_env_switches() { g_x3_persist.store(-1, std::memory_order_relaxed); }
 
 void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) {
     if (g.M <= 0 || g.N <= 0) return;
     if (g.K % 32 != 0 || g.lda % 8 != 0 || g.K < 64) throw std::invalid_argument("x3 gemm: K must be a multiple of 32 (>= 64), lda of 8");
+    if (g.N % 4 != 0 || (!g.x3_out && g.ldc % 4 != 0) || ((g.flags & kGemmResidual) && g.ldr % 4 != 0))
+        throw std::invalid_argument("x3 gemm: N, ldc and ldr must be multiples of 4 (16-byte epilogue accesses)");
+    if (g.batch <= 0 && (((uintptr_t)g.bias | (g.x3_out ? 0 : (uintptr_t)g.C) | ((g.flags & kGemmResidual) ? (uintptr_t)g.R : 0)) & 15))
+        throw std::invalid_argument("x3 gemm: bias, C and R must be 16-byte aligned");
+    if (g.batch > 0 && ((uintptr_t)g.bias & 15)) throw std::invalid_argument("x3 gemm: bias must be 16-byte aligned");
     if (g.flags & ~(kGemmGelu | kGemmResidual | kGemmScaleCols)) throw std::invalid_argument("x3 gemm: unsupported epilogue flag");
     if (g.x3_out && ((g.flags & (kGemmGelu | kGemmResidual)) || g.vt_col0 % XW_BN != 0 || g.ldc3 % 8 != 0 || g.vt_ld % 32 != 0 ||
                      g.vt_ld < g.M))
@@ -354,16 +452,41 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
         configured.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const int tiles_m = (g.M + XW_BM - 1) / XW_BM, tiles_n = (g.N + XW_BN - 1) / XW_BN;
+    const int batch = g.batch > 0 ? g.batch : 1;
+    // WLK_X3_MAP=1 (probe): plain row-major tile order instead of the XCD bands; WLK_X3_PERSIST=0: one workgroup per
+    // tile (the round-4 launch: same kernel, every list has one entry)
     static const int map_mode = [] {
         const char* e = getenv("WLK_X3_MAP");
         return e ? atoi(e) : 0;
     }();
+    int persist = g_x3_persist.load(std::memory_order_relaxed);
+    if (persist < 0) {
+        const char* e = getenv("WLK_X3_PERSIST");
+        persist = !(e && e[0] == '0');
+        g_x3_persist.store(persist, std::memory_order_relaxed);
+    }
+    static std::atomic<int> cu_count[64];
+    int cus = cu_count[dev & 63].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        WLK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (cus < 8) cus = 8;
+        cu_count[dev & 63].store(cus, std::memory_order_relaxed);
+    }
+    static const int pair_probe = [] {
+        const char* e = getenv("WLK_X3_PAIRPROBE");
+        return e ? atoi(e) : 0;
+    }();
     X3GemmArgs gg = g;
-    gg.map_mode = map_mode;
-    int blocks = tiles_m * tiles_n;
-    if (tiles_m >= 8 && map_mode == 0) blocks = 8 * ((tiles_m + 3) / 4) * ((tiles_n + 1) / 2);
-    if (tiles_m >= 8 && map_mode == 2) blocks = 8 * ((tiles_m + 1) / 2) * ((tiles_n + 3) / 4);
-    const int batch = g.batch > 0 ? g.batch : 1;
+    gg.pair_probe = pair_probe && g.M % 2 == 0 && g.N % 2 == 0;
+    gg.walk_banded = tiles_m >= 8 && map_mode == 0;
+    int blocks;
+    if (gg.walk_banded) {           // per XCD: slots of its band, all sessions; at most one resident workgroup per CU of the XCD
+        gg.walk_slots = ((tiles_m + 3) / 4) * ((tiles_n + 1) / 2) * batch;
+        blocks = 8 * (persist ? std::min(gg.walk_slots, cus / 8) : gg.walk_slots);
+    } else {
+        gg.walk_slots = tiles_m * tiles_n * batch;
+        blocks = persist ? std::min(gg.walk_slots, cus) : gg.walk_slots;
+    }
     // algorithmic work (what the roofline fraction is computed from): 2 M N K flop, operands and result once
     KernelScope ks(ctx, tag, 2.0 * batch * (double)g.M * g.N * g.K,
                    batch * (6.0 * ((double)g.M * g.K) + 4.0 * (double)g.M * g.N) + 6.0 * (double)g.N * g.K);
@@ -371,7 +494,7 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
         const char* e = getenv("WLK_X3_ABL");
         return e ? atoi(e) : 0;
     }();
-    const dim3 grid(blocks, batch);
+    const dim3 grid(blocks);
     if (abl == 1) hipLaunchKernelGGL(gemm_x3_wide_kernel<1>, grid, dim3(512), XW_LDS_BYTES, ctx.stream, gg);
     else if (abl == 2) hipLaunchKernelGGL(gemm_x3_wide_kernel<2>, grid, dim3(512), XW_LDS_BYTES, ctx.stream, gg);
     else if (abl == 3) hipLaunchKernelGGL(gemm_x3_wide_kernel<3>, grid, dim3(512), XW_LDS_BYTES, ctx.stream, gg);
