@@ -357,9 +357,9 @@ int wlk_model_finalize(wlk_model* m) {
             } st_guard{st};
             c.stream = st;
             auto pack = [&](const float* w, int n_rows) -> unsigned short* {
-                unsigned short* p3 = dev_alloc<unsigned short>((size_t)n_rows * 3 * da);
+                unsigned short* p3 = dev_alloc<unsigned short>(x3_w_elems(n_rows, da));
                 m->x3_owned.push_back(p3);
-                launch_x3_pack(c, w, da, p3, da, n_rows, da);
+                launch_x3_pack_w(c, w, da, p3, n_rows, da);      // fragment-major: the wide kernel's waves load it straight into registers
                 return p3;
             };
             for (auto& L : m->enc_layers) {

@@ -231,7 +231,7 @@ inline void launch_linear(const LaunchCtx& ctx, const GemmArgs& g, const char* t
 struct X3GemmArgs {
     const unsigned short* A3 = nullptr;   // activations in X3: row m at A3 + m * 3 * lda (bf16 units)
     long lda = 0;                         // in fp32-element units (a row holds 3 * lda bf16)
-    const unsigned short* W3 = nullptr;   // weights [N][K] in X3 (row n at W3 + n * 3 * K)
+    const unsigned short* W3 = nullptr;   // weights [N][K] in the FRAGMENT-MAJOR X3 form (launch_x3_pack_w, x3_w_elems(N, K) bf16)
     const float* bias = nullptr;
     float* C = nullptr;                   // fp32 result
     long ldc = 0;
@@ -244,7 +244,7 @@ struct X3GemmArgs {
     int scale_period = 0;
     int batch = 0;                        // > 0: `batch` sessions in one launch; A3 = z.in[i] (X3), C = z.out[i], R = z.res[i]
     int walk_banded = 0;                  // set by launch_gemm_x3: the tile walk of the persistent workgroups (gemm_x3.hip) -
-    int pair_probe = 0;                   // timing probe only (WLK_X3_PAIRPROBE): operand addresses of a row-pair-interleaved layout (wrong results)
+    int walk_colmajor = 0;                // slots of a band column by column instead of row by row
     int walk_slots = 0;                   // XCD bands or plain row-major order; slots per XCD (banded) or in total, sessions included
     // Result in the X3 format instead of fp32 (the operands of enc_attention_x3_kernel): columns [0, vt_col0) as X3 rows
     // (row m at C3 + m * 3 * ldc3), columns [vt_col0, N) TRANSPOSED - column n is row n - vt_col0 of a [N - vt_col0][vt_ld]
@@ -261,6 +261,9 @@ struct X3GemmArgs {
 };
 bool gemm_x3_wide_applicable(int M, int N, int K, long lda);
 void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag);
+// fp32 weights [n][ld_src] (k used) -> the wide kernel's weight operand (fragment-major, rows padded to 32: gemm_x3.hip)
+size_t x3_w_elems(int n, int k);             // bf16 elements of that operand
+void launch_x3_pack_w(const LaunchCtx& ctx, const float* src, long ld_src, unsigned short* dst, int n, int k);
 // fp32 [rows][ld_src] (cols used) -> X3 [rows][3 * ld_dst]
 void launch_x3_pack(const LaunchCtx& ctx, const float* src, long ld_src, unsigned short* dst, long ld_dst, int rows, int cols);
 // X3 [rows][3 * ld_src] -> fp32 [rows][ld_dst]: (hi + mid) + lo, the exact fp32 value the planes were split from

@@ -326,10 +326,10 @@ int wlk_diag_linear_x3(const float* a, const float* w, const float* bias, int m,
         DevBuf A((size_t)m * k, a), W((size_t)n * k, w), B(n, bias), Cc((size_t)m * n);
         unsigned short *a3 = nullptr, *w3 = nullptr;
         WLK_HIP(hipMalloc(reinterpret_cast<void**>(&a3), (size_t)m * 3 * k * sizeof(unsigned short)));
-        WLK_HIP(hipMalloc(reinterpret_cast<void**>(&w3), (size_t)n * 3 * k * sizeof(unsigned short)));
+        WLK_HIP(hipMalloc(reinterpret_cast<void**>(&w3), x3_w_elems(n, k) * sizeof(unsigned short)));
         LaunchCtx ctx;
         launch_x3_pack(ctx, A.p, k, a3, k, m, k);
-        launch_x3_pack(ctx, W.p, k, w3, k, n, k);
+        launch_x3_pack_w(ctx, W.p, k, w3, n, k);
         X3GemmArgs g;
         g.A3 = a3; g.lda = k; g.W3 = w3; g.bias = bias ? B.p : nullptr; g.C = Cc.p; g.ldc = n; g.M = m; g.N = n; g.K = k;
         g.flags = flags; g.scale = scale; g.scale_cols = scale_cols;
@@ -353,12 +353,12 @@ int wlk_diag_linear_x3_time(int m, int n, int k, int flags, int reps, float* us_
         WLK_HIP(hipMemset(B.p, 0, n * sizeof(float)));
         unsigned short *a3 = nullptr, *w3 = nullptr;
         WLK_HIP(hipMalloc(reinterpret_cast<void**>(&a3), (size_t)m * 3 * k * sizeof(unsigned short)));
-        WLK_HIP(hipMalloc(reinterpret_cast<void**>(&w3), (size_t)n * 3 * k * sizeof(unsigned short)));
+        WLK_HIP(hipMalloc(reinterpret_cast<void**>(&w3), x3_w_elems(n, k) * sizeof(unsigned short)));
         hipStream_t st;
         WLK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         LaunchCtx ctx{st, nullptr};
         launch_x3_pack(ctx, A.p, k, a3, k, m, k);
-        launch_x3_pack(ctx, W.p, k, w3, k, n, k);
+        launch_x3_pack_w(ctx, W.p, k, w3, n, k);
         X3GemmArgs g;
         g.A3 = a3; g.lda = k; g.W3 = w3; g.bias = B.p; g.C = Cc.p; g.ldc = n; g.M = m; g.N = n; g.K = k; g.flags = flags;
         g.scale = 0.5f; g.scale_cols = n / 2;
@@ -425,11 +425,11 @@ int wlk_diag_qkv_x3_attention(const float* x, const float* w, const float* bias,
         unsigned short *x3 = nullptr, *w3 = nullptr, *img = nullptr;
         const size_t n_img = x3_attn_image_elems(t, d);
         WLK_HIP(hipMalloc(reinterpret_cast<void**>(&x3), (size_t)t * 3 * d * sizeof(unsigned short)));
-        WLK_HIP(hipMalloc(reinterpret_cast<void**>(&w3), (size_t)3 * d * 3 * d * sizeof(unsigned short)));
+        WLK_HIP(hipMalloc(reinterpret_cast<void**>(&w3), x3_w_elems(3 * d, d) * sizeof(unsigned short)));
         WLK_HIP(hipMalloc(reinterpret_cast<void**>(&img), n_img * sizeof(unsigned short)));
         LaunchCtx ctx;
         launch_x3_pack(ctx, X.p, d, x3, d, t, d);
-        launch_x3_pack(ctx, W.p, d, w3, d, 3 * d, d);
+        launch_x3_pack_w(ctx, W.p, d, w3, 3 * d, d);
         X3GemmArgs g;
         g.A3 = x3; g.lda = d; g.W3 = w3; g.bias = B.p; g.M = t; g.N = 3 * d; g.K = d;
         g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = 2 * d;

@@ -80,62 +80,115 @@ void launch_x3_unpack(const LaunchCtx& ctx, const unsigned short* src, long ld_s
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// the weight operand of the wide kernel: FRAGMENT-MAJOR ("W3F").  A compute wave multiplies ITS 32 weight rows only, so the
+// weight fragments never need to meet other waves' data in LDS - they go from global memory straight into the registers the
+// MFMA reads.  For that the packed weight is laid out in the order the wave's loads want it: for every block of 32 rows,
+// K-slab t (32 elements), k-step s (2) and plane p (3): 1 KiB = lane l's 16 bytes at 16 l, lane (r = l & 31, hi = l >> 5)
+// holding row r's elements 32 t + 16 s + 8 hi .. + 7 of plane p - one fully coalesced global_load_dwordx4 per fragment.
+// Rows are padded to a multiple of 32 with zeros; same 6 bytes per element as the row format.
+// ---------------------------------------------------------------------------------------------------------------------
+size_t x3_w_elems(int n, int k) { return (size_t)((n + 31) / 32 * 32) * 3 * (size_t)k; }
+
+__global__ __launch_bounds__(256) void x3_pack_w_kernel(const float* __restrict__ src, long ld_src, unsigned short* __restrict__ dst,
+                                                        int n, int k) {
+    const int nslab = k >> 5;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;           // one (row block, slab, k-step, lane): the three planes
+    const long total = (long)((n + 31) / 32) * nslab * 2 * 64;
+    if (idx >= total) return;
+    const int l = (int)(idx & 63), s2 = (int)((idx >> 6) & 1);
+    const long bt = idx >> 7;
+    const int t = (int)(bt % nslab), nb = (int)(bt / nslab);
+    const int row = 32 * nb + (l & 31), k0 = 32 * t + 16 * s2 + 8 * (l >> 5);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = row < n ? src[(long)row * ld_src + k0 + e] : 0.f;
+    unsigned h[4], m[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const X3Triple x = x3_split(v[2 * i]), y = x3_split(v[2 * i + 1]);
+        h[i] = x3_bits(x.h) | (x3_bits(y.h) << 16);
+        m[i] = x3_bits(x.m) | (x3_bits(y.m) << 16);
+        lo[i] = x3_bits(x.l) | (x3_bits(y.l) << 16);
+    }
+    x3_u32x4* d = reinterpret_cast<x3_u32x4*>(reinterpret_cast<char*>(dst) + (((long)nb * nslab + t) * 2 + s2) * 3072 + 16 * l);
+    d[0] = x3_u32x4{h[0], h[1], h[2], h[3]};
+    d[64] = x3_u32x4{m[0], m[1], m[2], m[3]};
+    d[128] = x3_u32x4{lo[0], lo[1], lo[2], lo[3]};
+}
+
+void launch_x3_pack_w(const LaunchCtx& ctx, const float* src, long ld_src, unsigned short* dst, int n, int k) {
+    if (k % 32 != 0 || n <= 0) throw std::invalid_argument("x3 weight pack: K must be a multiple of 32");
+    const long total = (long)((n + 31) / 32) * (k / 32) * 128;
+    KernelScope ks(ctx, "x3_pack_w");
+    hipLaunchKernelGGL(x3_pack_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx.stream, src, ld_src, dst, n, k);
+    WLK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // the wide kernel
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int XW_BM = 96, XW_BN = 128;
 constexpr int XW_ROW_BYTES = 192;                         // one slab row: 4 chunks x 3 planes x 16 bytes
-constexpr int XW_ROWS = XW_BM + XW_BN;                    // A rows, then W rows
-constexpr int XW_SLAB_BYTES = XW_ROWS * XW_ROW_BYTES;     // 43 008
-constexpr int XW_PIECES = XW_SLAB_BYTES / 1024;           // 42 DMA pieces per slab
-constexpr int XW_NPW = 11;                                // per loader wave (loaders 2 and 3 issue piece 41 once more: same bytes)
-constexpr int XW_NB = 3;                                  // ring slots
-constexpr int XW_NF = 12;                                 // fragments per k-step and wave: 3 x 3 A + 3 B
-constexpr int XW_STAGE_SPLIT = XW_SLAB_BYTES / ((XW_BN + 4) * 4);   // rows of an X3 result's LDS transpose that fit one ring slot (81)
-constexpr size_t XW_LDS_BYTES = (size_t)XW_NB * XW_SLAB_BYTES + (size_t)(XW_BM - XW_STAGE_SPLIT) * (XW_BN + 4) * 4;
+constexpr int XW_SLAB_BYTES = XW_BM * XW_ROW_BYTES;       // 18 432: the ACTIVATION rows of a slab (the weights bypass LDS)
+constexpr int XW_PIECES = XW_SLAB_BYTES / 1024;           // 18 DMA pieces per slab
+constexpr int XW_LOADERS = 3;                             // loader waves
+constexpr int XW_NPW = XW_PIECES / XW_LOADERS;            // 6 pieces per loader wave and slab
+constexpr int XW_NB = 5;                                  // ring slots
+constexpr int XW_DT = XW_NB - 1;                          // slabs in flight beyond the one being multiplied
+constexpr int XW_THREADS = (4 + XW_LOADERS) * 64;
+constexpr int XW_NFA = 9;                                 // activation fragments per k-step: 3 row blocks x 3 planes
+constexpr int XW_WSLAB_BYTES = 6 * 1024;                  // one slab of one 32-row weight block in W3F
+constexpr int XW_STAGE_PITCH = XW_BN + 4;                 // fp32 words per row of an X3 result's LDS transpose
+constexpr int XW_STAGE_OFF = XW_NB * XW_SLAB_BYTES;       // ... which has its own region behind the ring
+constexpr int XW_WPITCH = 36;                             // fp32 words per row of a wave's PRIVATE 96 x 32 transpose (fp32 result)
+constexpr size_t XW_LDS_BYTES = (size_t)XW_STAGE_OFF + (size_t)4 * XW_BM * XW_WPITCH * 4;       // 147 456 (>= the X3 transpose's 50 688)
+static_assert((size_t)4 * XW_BM * XW_WPITCH >= (size_t)XW_BM * XW_STAGE_PITCH, "the staging region holds either transpose");
 // plane products of one fp32 product, small terms first: (lo, hi) (hi, lo) (mid, mid) (mid, hi) (hi, mid) (hi, hi)
 constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-static_assert(XW_PIECES * 1024 == XW_SLAB_BYTES, "a slab is a whole number of 1 KiB pieces");
+static_assert(XW_PIECES * 1024 == XW_SLAB_BYTES && XW_NPW * XW_LOADERS == XW_PIECES, "a slab is a whole number of 1 KiB pieces per loader");
 
-template <int N>
-__device__ __forceinline__ void xw_wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-    else static_assert(N < 0, "add the vmcnt literal");
+__device__ __forceinline__ void xw_wait_landed() {      // all but the newest XW_DT - 1 slabs of this loader have landed
+    static_assert((XW_DT - 1) * XW_NPW == 18, "update the vmcnt literal");
+    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
 }
 // s_waitcnt lgkmcnt(0) tied to the fragment registers it makes valid: no MFMA that reads them is scheduled above it
-__device__ __forceinline__ void xw_wait_frags(xf32x4 (&f)[XW_NF]) {
+__device__ __forceinline__ void xw_wait_frags(xf32x4 (&f)[XW_NFA]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]));
-    asm volatile("" : "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11]));
+    asm volatile("" : "+v"(f[6]), "+v"(f[7]), "+v"(f[8]));
 }
-__device__ __forceinline__ void xw_read_frags(xf32x4 (&f)[XW_NF], const unsigned (&addr)[XW_NF], unsigned off) {
+__device__ __forceinline__ void xw_read_frags(xf32x4 (&f)[XW_NFA], const unsigned (&addr)[XW_NFA], unsigned off) {
 #pragma unroll
-    for (int t = 0; t < XW_NF; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(f[t]) : "v"(addr[t] + off));
+    for (int t = 0; t < XW_NFA; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(f[t]) : "v"(addr[t] + off));
 }
 }  // namespace
 
-// Eight waves: waves 0-3 multiply (wave w owns the tile's columns 32 w .. 32 w + 31: three 32 x 32 accumulators, no
-// cross-wave fold), waves 4-7 only feed the ring.  Why loaders: a 1 KiB LDS-DMA piece costs its issuing wave 60-180
-// cycles of issue time, a bf16 MFMA 32 - with the compute waves issuing their own pieces (the fp32 k-pipe kernel's
-// schedule, where a piece hides behind a 64-cycle MFMA) the first version of this kernel spent two thirds of every slab
-// issuing DMA instead of MFMAs (32 us on the 1500 x 2048 x 512 problem against 34.6 for the fp32 kernel).  With a loader
-// wave beside each compute wave on every SIMD the two instruction streams overlap.
+// Seven waves: waves 0-3 multiply (wave w owns the tile's columns 32 w .. 32 w + 31: three 32 x 32 accumulators, no
+// cross-wave fold), waves 4-6 only feed the ring of ACTIVATION slabs.  Why loaders: a 1 KiB LDS-DMA piece costs its issuing
+// wave 60-180 cycles of issue time, a bf16 MFMA 32 - compute waves that issue their own pieces spend more time on DMA
+// than on MFMAs.  Round 5: with activations AND weights going through LDS (42 pieces per slab) the four loaders of round 4
+// were themselves issue-bound next to a compute wave on their SIMD (the loaders alone ran a 16-slab tile in 0.8 us per
+// slab, the MFMAs alone in 0.65, together 1.3).  The weights are now read by the wave that multiplies them, straight into
+// registers (W3F above: six coalesced 1 KiB loads per slab, issued one slab ahead), which leaves 18 pieces per slab for
+// three loaders, 18 KB per ring slot - so five slots, four slabs in flight - and frees the LDS of 57 % of its traffic.
 // One workgroup barrier per slab: the loaders arrive when their pieces of slab t + 1 have landed, the compute waves when
 // they have read the last fragments of slab t; behind it slab t + 1 is readable and the slot of slab t - 1 is free.
+// The WEIGHT rows are the MFMA's row operand: accumulator register q of lane (r, hi) is C[m = 32 i + r][n = (q & 3) +
+// 8 (q >> 2) + 4 hi] - four consecutive columns of ONE row per register quad, so the epilogue stores 16 bytes per
+// instruction and lane (with the activations as the row operand a lane held one column of 16 rows: 48 four-byte stores
+// per lane; that store tail cost 3 us of a 96 x 128 tile).
 //
-// Round 5 - PERSISTENT workgroups, one slab stream across tiles.  The launch is at most one workgroup per CU (the ring
-// is 126 KB, so a CU holds one anyway); a workgroup walks its XCD's tile list with stride = workgroups per XCD, and the
-// slabs of all its tiles form ONE stream through the ring: when the compute waves multiply the last slab of tile i the
-// loaders have slabs 0 and 1 of tile i + 1 landed / in flight and issue slab 2 behind the next barrier - the cold start
-// of a tile (two slabs from L2 / the fabric) and the epilogue stores of the previous one overlap instead of adding up
-// (round 4, one workgroup per tile: 81 us for the 768-tile cross-K|V projection whose loaders alone need 58 and whose
-// MFMAs alone 52).  Barrier count per tile = slabs (+ 2 around the LDS transpose of an X3 result), identical on both
-// sides; a workgroup whose list is empty returns before the first barrier.  A launch of <= one tile per CU is the round-4
-// schedule, instruction for instruction in the loop.
-// ABL (timing probe only, WLK_X3_ABL): 1 = the loaders run, the compute waves skip their MFMAs and fragment reads;
-// 2 = the compute waves run, the loaders issue nothing; 3 = MFMAs only (no fragment reads, no DMA)
+// PERSISTENT workgroups, one slab stream across tiles.  The launch is at most one workgroup per CU; a workgroup walks its
+// XCD's tile list with stride = workgroups per XCD, and the slabs of all its tiles form ONE stream through the ring (and
+// through the weight registers): the cold start of a tile overlaps the epilogue stores of the previous one.  Barrier
+// count per tile = slabs (+ 2 around the LDS transpose of an X3 result), identical on both sides; a workgroup whose list
+// is empty returns before the first barrier.  (Measured neutral by itself - profiles/r05c_x3_persist_probe.txt - the loop
+// was the loss, not the tile boundary; kept because the deeper ring makes the boundary visible.)
+// ABL (timing probe only, WLK_X3_ABL): 1 = loaders and weight loads run, no MFMAs and fragment reads; 2 = no DMA;
+// 3 = MFMAs only; 4 = no weight loads; 5 = weight loads from one cached address; 6 = weight loads in front of a k-step's MFMAs
+// instead of between them
 template <int ABL>
-__global__ __launch_bounds__(512) void gemm_x3_wide_kernel(X3GemmArgs g) {
+__global__ __launch_bounds__(XW_THREADS) void gemm_x3_wide_kernel(X3GemmArgs g) {
     asm volatile("" ::"s"(g.A3), "s"(g.lda), "s"(g.W3), "s"(g.bias), "s"(g.C), "s"(g.ldc), "s"(g.R), "s"(g.ldr), "s"(g.M),
                  "s"(g.N), "s"(g.K), "s"(g.flags), "s"(g.scale), "s"(g.scale_cols), "s"(g.scale_period), "s"(g.batch));
     __builtin_amdgcn_sched_barrier(0);
@@ -158,9 +211,16 @@ __global__ __launch_bounds__(512) void gemm_x3_wide_kernel(X3GemmArgs g) {
     auto decode = [&](int slot, int& tm, int& tn, int& b) -> bool {
         b = slot / per_session;
         const int r = slot - b * per_session;
-        const int rm = r / band_n;
+        int rm, cn;
+        if (g.walk_colmajor) {          // consecutive slots = the band's rows of ONE column, then the next column: the workgroups
+            cn = r / band_m;            // resident at a time share weight blocks 4-fold (and a persistent workgroup keeps its
+            rm = r - cn * band_m;       // activation rows from tile to tile)
+        } else {
+            rm = r / band_n;
+            cn = r - rm * band_n;
+        }
         tm = band_m0 + rm;
-        tn = band_n0 + (r - rm * band_n);
+        tn = band_n0 + cn;
         return tm < tiles_m && tn < tiles_n;
     };
     auto advance = [&](int slot) {          // first slot >= `slot` (in this workgroup's sequence) that is a tile
@@ -170,52 +230,40 @@ __global__ __launch_bounds__(512) void gemm_x3_wide_kernel(X3GemmArgs g) {
     };
     const int slot0 = advance(first);
     if (slot0 >= limit) return;             // padding workgroup (both roles leave before any barrier)
-    const int nslab = g.K / 32;
+    const int nslab = g.K / 32;             // even (launch_gemm_x3)
     const bool x3_out = g.x3_out;
 
     if (wave >= 4) {
         // ---- loader: piece j covers LDS bytes [1024 j, 1024 j + 1024) of a slab; lane l lands at byte 1024 j + 16 l = a
-        // (row, swizzled unit) of the slab image, and fetches that row's logical unit from the X3 operand -----------------
+        // (row, swizzled unit) of the slab image, and fetches that row's logical unit from the X3 activations ---------------
         const int lw = wave - 4;
         const char* src[XW_NPW];
-        int piece_of[XW_NPW], row_of[XW_NPW], unit_of[XW_NPW];
+        int row_of[XW_NPW], unit_of[XW_NPW];
 #pragma unroll
         for (int i = 0; i < XW_NPW; ++i) {
-            const int j = min(lw + 4 * i, XW_PIECES - 1);
-            piece_of[i] = j;
-            const int byte = 1024 * j + 16 * lane;
+            const int byte = 1024 * (lw + XW_LOADERS * i) + 16 * lane;
             row_of[i] = byte / XW_ROW_BYTES;
             unit_of[i] = (((byte - row_of[i] * XW_ROW_BYTES) >> 4) ^ ((row_of[i] >> 2) & 3)) * 16;
         }
         auto set_src = [&](int slot) {
             int tm, tn, b;
             decode(slot, tm, tn, b);
-            const int m0 = tm * XW_BM, n0 = tn * XW_BN;
-            const unsigned short* const gA = batched ? reinterpret_cast<const unsigned short*>(table_at(g.z.in, (unsigned)b)) : g.A3;
+            const int m0 = tm * XW_BM;
+            const char* const gA = reinterpret_cast<const char*>(batched ? reinterpret_cast<const unsigned short*>(table_at(g.z.in, (unsigned)b)) : g.A3);
 #pragma unroll
-            for (int i = 0; i < XW_NPW; ++i) {
-                const int row = row_of[i];
-                const bool is_a = row < XW_BM;
-                const int grow = is_a ? min(m0 + row, g.M - 1) : min(n0 + row - XW_BM, g.N - 1);
-                const char* const base = is_a ? reinterpret_cast<const char*>(gA) : reinterpret_cast<const char*>(g.W3);
-                const long row_bytes = (is_a ? g.lda : (long)g.K) * 6;
-                if (g.pair_probe)      // timing probe (WLK_X3_PAIRPROBE): the addresses a row-pair-interleaved operand would have
-                    src[i] = base + (long)(grow >> 1) * 2 * row_bytes + (grow & 1) * XW_ROW_BYTES + unit_of[i];
-                else
-                    src[i] = base + (long)grow * row_bytes + unit_of[i];
-            }
+            for (int i = 0; i < XW_NPW; ++i) src[i] = gA + (long)min(m0 + row_of[i], g.M - 1) * g.lda * 6 + unit_of[i];
         };
         int issue_slot = slot0, s_next = 0, ring = 0;
         bool more = true;
         set_src(issue_slot);
         auto issue_one = [&]() {     // the next slab of the stream into the next ring slot (past the end: the last slab again, into a free slot)
-            if constexpr (ABL < 2) {
-                const long adv = (long)s_next * (g.pair_probe ? 2 * XW_ROW_BYTES : XW_ROW_BYTES);
-                unsigned char* const dst = lds + ring * XW_SLAB_BYTES;
+            if constexpr (ABL != 2 && ABL != 3) {
+                const long adv = (long)s_next * XW_ROW_BYTES;
+                unsigned char* const dst = lds + ring * XW_SLAB_BYTES + lw * 1024;
                 x3_static_for<XW_NPW>([&](auto I) {
                     constexpr int i = decltype(I)::value;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + adv),
-                                                     (__attribute__((address_space(3))) void*)(dst + piece_of[i] * 1024), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)(dst + i * XW_LOADERS * 1024), 16, 0, 0);
                 });
             }
             ring = ring == XW_NB - 1 ? 0 : ring + 1;
@@ -231,79 +279,152 @@ __global__ __launch_bounds__(512) void gemm_x3_wide_kernel(X3GemmArgs g) {
                 }
             }
         };
-        issue_one();
-        issue_one();
-        xw_wait_vmcnt<XW_NPW>();
+#pragma unroll
+        for (int i = 0; i < XW_DT; ++i) issue_one();
+        xw_wait_landed();
         __builtin_amdgcn_s_barrier();
         for (int slot = slot0; slot < limit; slot = advance(slot + stride)) {
             for (int tt = 0; tt < nslab; ++tt) {
                 issue_one();
-                xw_wait_vmcnt<XW_NPW>();           // this loader's pieces of the slab behind the one being multiplied have landed
+                xw_wait_landed();                  // this loader's pieces of the slab behind the one being multiplied have landed
                 __builtin_amdgcn_s_barrier();
             }
-            if (x3_out) {                          // the compute waves transpose the tile through the ring slot just drained
+            if (x3_out) {                          // the compute waves' two barriers around the LDS transpose of the tile
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_s_barrier();
             }
         }
-        xw_wait_vmcnt<0>();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // nothing of this loader is in flight any more
         return;
     }
 
     // ---- compute waves ------------------------------------------------------------------------------------------------
-    // fragment byte addresses inside a ring slot: lane (r, hi) reads row r (+ 32 i), chunk 2 s + hi, plane p
+    // activation fragment byte addresses inside a ring slot: lane (r, hi) reads row r (+ 32 i), chunk 2 s + hi, plane p
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const int r = lane & 31, hi = lane >> 5, swz = (r >> 2) & 3;
-    unsigned f_addr[2][XW_NF];
+    unsigned f_addr[2][XW_NFA];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const unsigned unit = (unsigned)(((2 * s + hi) * 3 + p) ^ swz) * 16u;
 #pragma unroll
             for (int i = 0; i < 3; ++i) f_addr[s][i * 3 + p] = lds_base + (unsigned)((32 * i + r) * XW_ROW_BYTES) + unit;
-            f_addr[s][9 + p] = lds_base + (unsigned)((XW_BM + 32 * wave + r) * XW_ROW_BYTES) + unit;
         }
-    }
     xf32x16 acc[3];
-    auto mfma_step = [&](const xf32x4 (&f)[XW_NF]) {     // 18 MFMAs: product t of row block i - three independent chains
-        x3_static_for<18>([&](auto X) {
-            constexpr int x = decltype(X)::value;
+    // MFMAs [LO, HI) of the 18 of one k-step: product t = x / 3 of row block i = x % 3 - three independent chains; w0 .. w2 =
+    // this k-step's three weight planes
+    auto mfma_range = [&](auto LO, auto HI, const xf32x4 (&f)[XW_NFA], const xf32x4& w0, const xf32x4& w1, const xf32x4& w2) {
+        constexpr int lo = decltype(LO)::value, hi_ = decltype(HI)::value;
+        x3_static_for<hi_ - lo>([&](auto X) {
+            constexpr int x = lo + decltype(X)::value;
             constexpr int t = x / 3, i = x % 3;
-            // the WEIGHT rows are the instruction's row operand: accumulator register q of lane (r, hi) is
-            // C[m = 32 i + r][n = (q & 3) + 8 (q >> 2) + 4 hi] - four consecutive columns of ONE row per register quad, so the
-            // epilogue stores 16 bytes per instruction and lane (round 5; with the activations as the row operand a lane held
-            // one column of 16 rows: 48 four-byte stores per lane, and the store tail was issue-bound)
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[9 + PB[t]]),
-                                                             __builtin_bit_cast(bf16x8, f[i * 3 + PA[t]]), acc[i], 0, 0, 0);
+            const xf32x4& w = PB[t] == 0 ? w0 : (PB[t] == 1 ? w1 : w2);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, f[i * 3 + PA[t]]),
+                                                             acc[i], 0, 0, 0);
         });
+    };
+    // the weight stream of this wave: block (4 tile_n + wave) of W3F, one 6 KiB slab after the other
+    const int n_blocks = (g.N + 31) / 32;
+    typedef const __attribute__((address_space(1))) xf32x4* wptr_t;
+    auto w_base = [&](int slot) -> const char* {
+        int tm, tn, bz;
+        decode(slot, tm, tn, bz);
+        return reinterpret_cast<const char*>(g.W3) + (long)min(4 * tn + wave, n_blocks - 1) * nslab * XW_WSLAB_BYTES + 16 * lane;
+    };
+    const char* const w_fixed = reinterpret_cast<const char*>(g.W3) + 16 * lane;
+    // one of a slab's six weight fragments: requested BETWEEN the MFMAs of the slab before (k_step below)
+    auto load_w1 = [&](xf32x4 (&w)[6], const char* p, int x) {
+        if constexpr (ABL == 5) p = w_fixed;          // probe: every weight load hits the same (cached) kilobytes
+        if constexpr (ABL != 3 && ABL != 4) w[x] = *(wptr_t)(p + 1024 * x);
     };
     // this lane's sixteen columns of a tile: n0 + 32 wave + 8 j + 4 hi + (0 .. 3), j = 0 .. 3
     const int col_in_tile = 32 * wave + 4 * hi;
+    // ... for an X3 result (bias added before the shared transpose); an fp32 result adds it after its wave-private
+    // transpose, where a lane holds columns 4 (lane & 7) .. + 3 of eight-row groups: one quad, in b[0]
     auto load_bias = [&](int slot, xf32x4 (&b)[4]) {
         int tm, tn, bz;
         decode(slot, tm, tn, bz);
+        if (x3_out) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = min(tn * XW_BN + col_in_tile + 8 * j, g.N - 4);
-            b[j] = g.bias ? *reinterpret_cast<const xf32x4*>(g.bias + c) : xf32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j) {
+                const int c = min(tn * XW_BN + col_in_tile + 8 * j, g.N - 4);
+                b[j] = g.bias ? *reinterpret_cast<const xf32x4*>(g.bias + c) : xf32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+            const int c = min(tn * XW_BN + 32 * wave + 4 * (lane & 7), g.N - 4);
+            b[0] = g.bias ? *reinterpret_cast<const xf32x4*>(g.bias + c) : xf32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
+    xf32x4 wa[6], wb[6];                       // weight fragments of the slab being multiplied / of the next one
+#pragma unroll
+    for (int x = 0; x < 6; ++x) wa[x] = wb[x] = xf32x4{0.f, 0.f, 0.f, 0.f};
+    const char* w_cur = w_base(slot0);
+#pragma unroll
+    for (int x = 0; x < 6; ++x) load_w1(wa, w_cur, x);
     xf32x4 bias_next[4];
     load_bias(slot0, bias_next);
 
     __builtin_amdgcn_s_barrier();              // slab 0 has landed
     unsigned ring_off = 0;                     // byte offset of the ring slot of the slab being multiplied
-    xf32x4 g0[XW_NF], g1[XW_NF];
+    xf32x4 g0[XW_NFA], g1[XW_NFA];
     xw_read_frags(g0, f_addr[0], ring_off);
     xw_wait_frags(g0);
+    // one slab: k-step 0 from g0 (already read), k-step 1 from g1; behind the barrier the next slab's first fragments.
+    // The next slab's weight fragments are requested one at a time between the MFMAs (a vector-memory instruction costs its
+    // wave ~100 cycles of issue: six in a row in front of the MFMAs were 0.34 us per slab, profiles/r05e, r05f)
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 6> I6;
+    typedef std::integral_constant<int, 12> I12;
+    typedef std::integral_constant<int, 18> I18;
+    // one k-step (`half` of the slab): 18 MFMAs from fragments f and weight planes w[3 half ..], and the loads of the NEXT
+    // slab's planes of the same half, one after every six MFMAs (ABL 6, probe: all three in front)
+    auto k_step = [&](const xf32x4 (&f)[XW_NFA], const xf32x4 (&w)[6], xf32x4 (&nxt)[6], const char* p_next, int half) {
+        const xf32x4 &w0 = w[3 * half], &w1 = w[3 * half + 1], &w2 = w[3 * half + 2];
+        if constexpr (ABL == 6) {
+#pragma unroll
+            for (int x = 0; x < 3; ++x) load_w1(nxt, p_next, 3 * half + x);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_range(I0{}, I18{}, f, w0, w1, w2);
+        } else if constexpr (ABL == 1) {
+#pragma unroll
+            for (int x = 0; x < 3; ++x) load_w1(nxt, p_next, 3 * half + x);
+        } else {
+            mfma_range(I0{}, I6{}, f, w0, w1, w2);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w1(nxt, p_next, 3 * half);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_range(I6{}, I12{}, f, w0, w1, w2);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w1(nxt, p_next, 3 * half + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_range(I12{}, I18{}, f, w0, w1, w2);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w1(nxt, p_next, 3 * half + 2);
+        }
+    };
+    auto slab = [&](const xf32x4 (&w)[6], xf32x4 (&nxt)[6], const char* p_next) {
+        if constexpr (ABL != 1 && ABL != 3) xw_read_frags(g1, f_addr[1], ring_off);
+        __builtin_amdgcn_sched_barrier(0);
+        k_step(g0, w, nxt, p_next, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        xw_wait_frags(g1);
+        __builtin_amdgcn_s_barrier();          // the next slab of the stream is readable; everybody is done with this slab's fragments
+        ring_off = ring_off == (unsigned)((XW_NB - 1) * XW_SLAB_BYTES) ? 0u : ring_off + (unsigned)XW_SLAB_BYTES;
+        if constexpr (ABL != 1 && ABL != 3) xw_read_frags(g0, f_addr[0], ring_off);     // (last slab of a tile: slab 0 of the next)
+        __builtin_amdgcn_sched_barrier(0);
+        k_step(g1, w, nxt, p_next, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        xw_wait_frags(g0);
+    };
     for (int slot = slot0; slot < limit;) {
         int tile_m, tile_n, bz;
         decode(slot, tile_m, tile_n, bz);
         const int next_slot = advance(slot + stride);
         const int m0 = tile_m * XW_BM, n0 = tile_n * XW_BN;
         const int col0 = n0 + col_in_tile;           // + 8 j + e
+        const char* const w_next = next_slot < limit ? w_base(next_slot) : w_cur;      // (no next tile: a harmless re-read)
         xf32x4 bias[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bias[j] = bias_next[j];
@@ -313,36 +434,22 @@ __global__ __launch_bounds__(512) void gemm_x3_wide_kernel(X3GemmArgs g) {
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
-        for (int tt = 0; tt < nslab; ++tt) {
-            if constexpr (ABL != 1 && ABL != 3) xw_read_frags(g1, f_addr[1], ring_off);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ABL != 1) mfma_step(g0);
-            __builtin_amdgcn_sched_barrier(0);
-            xw_wait_frags(g1);
-            __builtin_amdgcn_s_barrier();          // the next slab of the stream is readable; everybody is done with this slab's fragments
-            ring_off = ring_off == (unsigned)((XW_NB - 1) * XW_SLAB_BYTES) ? 0u : ring_off + (unsigned)XW_SLAB_BYTES;
-            if constexpr (ABL != 1 && ABL != 3) xw_read_frags(g0, f_addr[0], ring_off);     // (last slab of a tile: slab 0 of the next)
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ABL != 1) mfma_step(g1);
-            __builtin_amdgcn_sched_barrier(0);
-            xw_wait_frags(g0);
+        for (int tt = 0; tt < nslab; tt += 2) {
+            slab(wa, wb, w_cur + (long)(tt + 1) * XW_WSLAB_BYTES);           // weights one slab ahead of their MFMAs
+            slab(wb, wa, tt + 2 < nslab ? w_cur + (long)(tt + 2) * XW_WSLAB_BYTES : w_next);
         }
+        w_cur = w_next;
         float* const gC = batched ? table_at(g.z.out, (unsigned)bz) : g.C;
         const float* const gR = batched ? table_at(g.z.res, (unsigned)bz) : g.R;
         if (x3_out) {
-            // ---- result in the X3 format: the tile goes through LDS so that 8 consecutive columns - or, for the
-            // transposed part, 8 rows in the attention kernel's key order - meet in one thread, which splits them into the
-            // three planes and writes the chunk's 48 contiguous bytes.  Staging = the ring slot of the slab just multiplied
-            // (the loaders issue nothing into it before the second barrier below; the other two slots hold the next tile's
-            // first slabs) for rows 0 .. 80, plus a small tail region behind the ring for rows 81 .. 95
-            constexpr int PITCH = XW_BN + 4;
-            const unsigned prev_off = ring_off == 0u ? (unsigned)((XW_NB - 1) * XW_SLAB_BYTES) : ring_off - (unsigned)XW_SLAB_BYTES;
-            float* const stage_lo = reinterpret_cast<float*>(lds + prev_off);
-            float* const stage_hi = reinterpret_cast<float*>(lds + XW_NB * XW_SLAB_BYTES) - XW_STAGE_SPLIT * PITCH;
-            auto stage_row = [&](int row) -> float* { return (row < XW_STAGE_SPLIT ? stage_lo : stage_hi) + row * PITCH; };
+            // ---- result in the X3 format: the tile goes through LDS (its own region behind the ring) so that 8 consecutive
+            // columns - or, for the transposed part, 8 rows in the attention kernel's key order - meet in one thread, which
+            // splits them into the three planes and writes the chunk's 48 contiguous bytes
+            constexpr int PITCH = XW_STAGE_PITCH;
+            float* const stage = reinterpret_cast<float*>(lds + XW_STAGE_OFF);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                float* const srow = stage_row(32 * i + r) + col_in_tile;
+                float* const srow = stage + (32 * i + r) * PITCH + col_in_tile;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     xf32x4 v;
@@ -362,8 +469,8 @@ __global__ __launch_bounds__(512) void gemm_x3_wide_kernel(X3GemmArgs g) {
                 for (int item = tid; item < XW_BM * (XW_BN / 8); item += 256) {
                     const int row = item >> 4, c = item & 15;
                     if (m0 + row < g.M && n0 + 8 * c < g.N) {
-                        const float4 a = *reinterpret_cast<const float4*>(stage_row(row) + 8 * c);
-                        const float4 b = *reinterpret_cast<const float4*>(stage_row(row) + 8 * c + 4);
+                        const float4 a = *reinterpret_cast<const float4*>(stage + row * PITCH + 8 * c);
+                        const float4 b = *reinterpret_cast<const float4*>(stage + row * PITCH + 8 * c + 4);
                         const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
                         x3_store_chunk(c3 + (long)(m0 + row) * 3 * g.ldc3 + (long)((n0 >> 3) + c) * 24, v);
                     }
@@ -379,38 +486,47 @@ __global__ __launch_bounds__(512) void gemm_x3_wide_kernel(X3GemmArgs g) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const int row = r0 + (e & 3) + 16 * (e >> 2);
-                            v[e] = m0 + row < g.M ? stage_row(row)[dcol] : 0.f;
+                            v[e] = m0 + row < g.M ? stage[row * PITCH + dcol] : 0.f;
                         }
                         x3_store_chunk(vt + (long)(n0 + dcol - g.vt_col0) * 3 * g.vt_ld + (long)((m0 >> 3) + u) * 24, v);
                     }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();          // the staging slot is the loaders' again
+            __builtin_amdgcn_s_barrier();          // the staging region may be written again
         } else {
-            // epilogue: acc[i][4 j + e] is C[m0 + 32 i + r][col0 + 8 j + e]: 16-byte stores (and residual loads)
-            const bool gelu = (g.flags & kGemmGelu) != 0, has_res = (g.flags & kGemmResidual) != 0;
+            // ---- fp32 result.  acc[i][4 j + e] is C[m0 + 32 i + r][col0 + 8 j + e]: stored from there, an instruction would
+            // touch 32 rows with 32 bytes each (a quarter of a line per request).  The wave turns its 96 x 32 part around in a
+            // PRIVATE LDS region instead (no barrier: a wave's LDS operations execute in order) and stores eight whole
+            // 128-byte rows per instruction; bias and residual quads are then one coalesced access each as well
+            float* const wst = reinterpret_cast<float*>(lds + XW_STAGE_OFF) + wave * (XW_BM * XW_WPITCH);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int row = m0 + 32 * i + r;
-                const bool row_ok = row < g.M;
-                xf32x4 res[4];
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    res[j] = has_res ? *reinterpret_cast<const xf32x4*>(gR + (long)min(row, g.M - 1) * g.ldr + min(col0 + 8 * j, g.N - 4))
-                                     : xf32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<xf32x4*>(wst + (32 * i + r) * XW_WPITCH + 8 * j + 4 * hi) =
+                        xf32x4{acc[i][4 * j], acc[i][4 * j + 1], acc[i][4 * j + 2], acc[i][4 * j + 3]};
+            const bool gelu = (g.flags & kGemmGelu) != 0, has_res = (g.flags & kGemmResidual) != 0;
+            const int colq = lane & 7, rsub = lane >> 3;
+            const int col = n0 + 32 * wave + 4 * colq;
+            const bool col_ok = col < g.N;
+            bool sc[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    xf32x4 v;
+            for (int e = 0; e < 4; ++e) sc[e] = scaled(col + e);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[i][4 * j + e] + bias[j][e];
-                        if (scaled(col0 + 8 * j + e)) v[e] *= g.scale;
-                        if (gelu) v[e] = x3_gelu_erf(v[e]);
-                        v[e] += res[j][e];
-                    }
-                    if (row_ok && col0 + 8 * j < g.N) *reinterpret_cast<xf32x4*>(gC + (long)row * g.ldc + col0 + 8 * j) = v;
+            for (int it = 0; it < XW_BM / 8; ++it) {
+                const int row = m0 + 8 * it + rsub;
+                xf32x4 v = *reinterpret_cast<const xf32x4*>(wst + (8 * it + rsub) * XW_WPITCH + 4 * colq);
+                const xf32x4 res = has_res ? *reinterpret_cast<const xf32x4*>(gR + (long)min(row, g.M - 1) * g.ldr + min(col, g.N - 4))
+                                           : xf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] += bias[0][e];
+                    if (sc[e]) v[e] *= g.scale;
+                    if (gelu) v[e] = x3_gelu_erf(v[e]);
+                    v[e] += res[e];
                 }
+                if (row < g.M && col_ok) *reinterpret_cast<xf32x4*>(gC + (long)row * g.ldc + col) = v;
             }
         }
         slot = next_slot;
@@ -423,7 +539,7 @@ bool gemm_x3_wide_applicable(int M, int N, int K, long lda) {
         const char* e = getenv("WLK_X3");
         return !(e && e[0] == '0');
     }();
-    return on && M >= 256 && N >= 1024 && N % 4 == 0 && K >= 64 && K % 32 == 0 && lda % 8 == 0;
+    return on && M >= 256 && N >= 1024 && N % 4 == 0 && K >= 64 && K % 64 == 0 && lda % 8 == 0;
 }
 
 static std::atomic<int> g_x3_persist{-1};                // -1: WLK_X3_PERSIST not read yet
@@ -431,7 +547,7 @@ void x3_refresh_env_switches() { g_x3_persist.store(-1, std::memory_order_relaxe
 
 void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) {
     if (g.M <= 0 || g.N <= 0) return;
-    if (g.K % 32 != 0 || g.lda % 8 != 0 || g.K < 64) throw std::invalid_argument("x3 gemm: K must be a multiple of 32 (>= 64), lda of 8");
+    if (g.K % 64 != 0 || g.lda % 8 != 0 || g.K < 64) throw std::invalid_argument("x3 gemm: K must be a multiple of 64, lda of 8");
     if (g.N % 4 != 0 || (!g.x3_out && g.ldc % 4 != 0) || ((g.flags & kGemmResidual) && g.ldr % 4 != 0))
         throw std::invalid_argument("x3 gemm: N, ldc and ldr must be multiples of 4 (16-byte epilogue accesses)");
     if (g.batch <= 0 && (((uintptr_t)g.bias | (g.x3_out ? 0 : (uintptr_t)g.C) | ((g.flags & kGemmResidual) ? (uintptr_t)g.R : 0)) & 15))
@@ -449,6 +565,9 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
         WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
         WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
         WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
         configured.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const int tiles_m = (g.M + XW_BM - 1) / XW_BM, tiles_n = (g.N + XW_BN - 1) / XW_BN;
@@ -472,12 +591,16 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
         if (cus < 8) cus = 8;
         cu_count[dev & 63].store(cus, std::memory_order_relaxed);
     }
-    static const int pair_probe = [] {
-        const char* e = getenv("WLK_X3_PAIRPROBE");
-        return e ? atoi(e) : 0;
+    // column-major walk inside a band: the workgroups resident at a time share weight blocks 4-fold and a persistent
+    // workgroup keeps its activation rows from tile to tile (cross-K|V 71 -> 67 us, large-v3 fc1 154 -> 147); with several
+    // sessions in one launch the row-major order measured better (212 vs 222 us at 8 sessions), so it is taken for one
+    // session only.  WLK_X3_COLMAJOR=0 / 1 forces either
+    static const int colmajor = [] {
+        const char* e = getenv("WLK_X3_COLMAJOR");
+        return e ? atoi(e) : -1;
     }();
     X3GemmArgs gg = g;
-    gg.pair_probe = pair_probe && g.M % 2 == 0 && g.N % 2 == 0;
+    gg.walk_colmajor = colmajor >= 0 ? colmajor : (batch <= 1);
     gg.walk_banded = tiles_m >= 8 && map_mode == 0;
     int blocks;
     if (gg.walk_banded) {           // per XCD: slots of its band, all sessions; at most one resident workgroup per CU of the XCD
@@ -495,10 +618,13 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
         return e ? atoi(e) : 0;
     }();
     const dim3 grid(blocks);
-    if (abl == 1) hipLaunchKernelGGL(gemm_x3_wide_kernel<1>, grid, dim3(512), XW_LDS_BYTES, ctx.stream, gg);
-    else if (abl == 2) hipLaunchKernelGGL(gemm_x3_wide_kernel<2>, grid, dim3(512), XW_LDS_BYTES, ctx.stream, gg);
-    else if (abl == 3) hipLaunchKernelGGL(gemm_x3_wide_kernel<3>, grid, dim3(512), XW_LDS_BYTES, ctx.stream, gg);
-    else hipLaunchKernelGGL(gemm_x3_wide_kernel<0>, grid, dim3(512), XW_LDS_BYTES, ctx.stream, gg);
+    if (abl == 1) hipLaunchKernelGGL(gemm_x3_wide_kernel<1>, grid, dim3(XW_THREADS), XW_LDS_BYTES, ctx.stream, gg);
+    else if (abl == 2) hipLaunchKernelGGL(gemm_x3_wide_kernel<2>, grid, dim3(XW_THREADS), XW_LDS_BYTES, ctx.stream, gg);
+    else if (abl == 3) hipLaunchKernelGGL(gemm_x3_wide_kernel<3>, grid, dim3(XW_THREADS), XW_LDS_BYTES, ctx.stream, gg);
+    else if (abl == 4) hipLaunchKernelGGL(gemm_x3_wide_kernel<4>, grid, dim3(XW_THREADS), XW_LDS_BYTES, ctx.stream, gg);
+    else if (abl == 5) hipLaunchKernelGGL(gemm_x3_wide_kernel<5>, grid, dim3(XW_THREADS), XW_LDS_BYTES, ctx.stream, gg);
+    else if (abl == 6) hipLaunchKernelGGL(gemm_x3_wide_kernel<6>, grid, dim3(XW_THREADS), XW_LDS_BYTES, ctx.stream, gg);
+    else hipLaunchKernelGGL(gemm_x3_wide_kernel<0>, grid, dim3(XW_THREADS), XW_LDS_BYTES, ctx.stream, gg);
     WLK_HIP(hipGetLastError());
 }
 
