@@ -35,6 +35,7 @@ def test_reference_processor_and_policy_over_real_hip_hooks(case):
     from test_reference_dropin import _make
     if not H.golden_exists(f"stream_{case}.json"):
         pytest.skip(f"golden stream {case} not generated")
+    ref_stubs.install(synthetic_vocab=True)       # puts the reference package on sys.path (idempotent; _make does it too, but later)
     from whisperlivekit.simul_whisper.align_att_base import AlignAttBase
     from whisperlivekit.simul_whisper.backend import SimulStreamingOnlineProcessor
     from whisperlivekit_amd.engine import HipSession

@@ -205,6 +205,26 @@ def test_hip_rows_and_reorder(micro_hip):
 
 
 @pytest.mark.gpu
+def test_hip_session_reused_for_sources_of_different_lengths(micro_hip):
+    """One session, several sentences (what a translation stream does): the graph-replayed step carries the source length of
+    its recording - a sentence of another length must not replay it (round 5: it did, and the cross-attention read the
+    previous sentence's key count).  Every generate on the reused session == the same generate on a fresh one."""
+    reused = micro_hip.new_session(1)
+    try:
+        for ci in (1, 2, 0, 3, 1, 4, 2):                       # 5, 17, 1, 64, 5, 90, 17 source tokens
+            lang, max_new = (int(v) for v in KAT["cases"][ci])
+            fresh = micro_hip.new_session(1)
+            try:
+                want = nllb.generate(fresh, KAT[f"src{ci}"], lang, max_new_tokens=max_new)
+            finally:
+                fresh.close()
+            assert want == KAT[f"gen{ci}"].tolist()
+            assert nllb.generate(reused, KAT[f"src{ci}"], lang, max_new_tokens=max_new) == want, f"case {ci} on the reused session"
+    finally:
+        reused.close()
+
+
+@pytest.mark.gpu
 def test_hip_rejects_bad_input(micro_hip):
     from whisperlivekit_amd._lib import WlkError
     sess = micro_hip.new_session(1)

@@ -233,6 +233,47 @@ __global__ __launch_bounds__(XW_THREADS) void gemm_x3_wide_kernel(X3GemmArgs g) 
     const int nslab = g.K / 32;             // even (launch_gemm_x3)
     const bool x3_out = g.x3_out;
 
+    // ---- the fp32 epilogue, shared by ALL seven waves.  The compute waves have turned their 96 x 32 parts of the tile around
+    // in LDS (below); the tile is then 48 items of 8 rows x 32 columns (part wp = k / 12, row group k % 12), item k for wave
+    // k % 7: bias, scale, exact-erf GELU, residual, one store instruction = eight whole 128-byte rows.  With the loaders
+    // taking their share the erf epilogue of fc1 (48 calls per lane on four waves, ~8 us of a 28 us launch) is 28 calls
+    // per lane.  The bias quads are requested in front of the barrier that publishes the transposed tile.  No second
+    // barrier: a part is rewritten only behind the next tile's slab barriers, which every wave reaches after its items.
+    auto shared_epilogue = [&](int m0, int n0, int bz) {
+        float* const gC = batched ? table_at(g.z.out, (unsigned)bz) : g.C;
+        const float* const gR = batched ? table_at(g.z.res, (unsigned)bz) : g.R;
+        const float* const stage = reinterpret_cast<const float*>(lds + XW_STAGE_OFF);
+        const int colq = lane & 7, rsub = lane >> 3;
+        constexpr int ITEMS = 4 * (XW_BM / 8);
+        auto bias_of_item = [&](int k) -> xf32x4 {       // the quad of item k's columns (clamped: an item past the end reads item 47's)
+            const int c = min(n0 + 32 * (min(k, ITEMS - 1) / (XW_BM / 8)) + 4 * colq, g.N - 4);
+            return g.bias ? *reinterpret_cast<const xf32x4*>(g.bias + c) : xf32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        xf32x4 bq = bias_of_item(wave);                  // requested in front of the barrier, the next item's during the current one
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (compute waves: their part of the transpose is written)
+        __builtin_amdgcn_s_barrier();
+        const bool gelu = (g.flags & kGemmGelu) != 0, has_res = (g.flags & kGemmResidual) != 0;
+#pragma unroll 1
+        for (int k = wave; k < ITEMS; k += XW_THREADS / 64) {
+            const xf32x4 bq_next = bias_of_item(k + XW_THREADS / 64);
+            const int wp = k / (XW_BM / 8), it = k - wp * (XW_BM / 8);
+            const int row_t = 8 * it + rsub, row = m0 + row_t;
+            const int col = n0 + 32 * wp + 4 * colq;
+            xf32x4 v = *reinterpret_cast<const xf32x4*>(stage + (wp * XW_BM + row_t) * XW_WPITCH + 4 * colq);
+            const xf32x4 res = has_res ? *reinterpret_cast<const xf32x4*>(gR + (long)min(row, g.M - 1) * g.ldr + min(col, g.N - 4))
+                                       : xf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] += bq[e];
+                if ((g.flags & kGemmScaleCols) && (g.scale_period ? (col + e) % g.scale_period : col + e) < g.scale_cols) v[e] *= g.scale;
+                if (gelu) v[e] = x3_gelu_erf(v[e]);
+                v[e] += res[e];
+            }
+            if (row < g.M && col < g.N) *reinterpret_cast<xf32x4*>(gC + (long)row * g.ldc + col) = v;
+            bq = bq_next;
+        }
+    };
+
     if (wave >= 4) {
         // ---- loader: piece j covers LDS bytes [1024 j, 1024 j + 1024) of a slab; lane l lands at byte 1024 j + 16 l = a
         // (row, swizzled unit) of the slab image, and fetches that row's logical unit from the X3 activations ---------------
@@ -292,6 +333,10 @@ __global__ __launch_bounds__(XW_THREADS) void gemm_x3_wide_kernel(X3GemmArgs g) 
             if (x3_out) {                          // the compute waves' two barriers around the LDS transpose of the tile
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_s_barrier();
+            } else {
+                int tm, tn, bz;
+                decode(slot, tm, tn, bz);
+                shared_epilogue(tm * XW_BM, tn * XW_BN, bz);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -341,8 +386,7 @@ __global__ __launch_bounds__(XW_THREADS) void gemm_x3_wide_kernel(X3GemmArgs g) 
     };
     // this lane's sixteen columns of a tile: n0 + 32 wave + 8 j + 4 hi + (0 .. 3), j = 0 .. 3
     const int col_in_tile = 32 * wave + 4 * hi;
-    // ... for an X3 result (bias added before the shared transpose); an fp32 result adds it after its wave-private
-    // transpose, where a lane holds columns 4 (lane & 7) .. + 3 of eight-row groups: one quad, in b[0]
+    // ... for an X3 result (bias added before the shared transpose; an fp32 result gets it in shared_epilogue)
     auto load_bias = [&](int slot, xf32x4 (&b)[4]) {
         int tm, tn, bz;
         decode(slot, tm, tn, bz);
@@ -352,9 +396,6 @@ __global__ __launch_bounds__(XW_THREADS) void gemm_x3_wide_kernel(X3GemmArgs g) 
                 const int c = min(tn * XW_BN + col_in_tile + 8 * j, g.N - 4);
                 b[j] = g.bias ? *reinterpret_cast<const xf32x4*>(g.bias + c) : xf32x4{0.f, 0.f, 0.f, 0.f};
             }
-        } else {
-            const int c = min(tn * XW_BN + 32 * wave + 4 * (lane & 7), g.N - 4);
-            b[0] = g.bias ? *reinterpret_cast<const xf32x4*>(g.bias + c) : xf32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     xf32x4 wa[6], wb[6];                       // weight fragments of the slab being multiplied / of the next one
@@ -440,7 +481,6 @@ __global__ __launch_bounds__(XW_THREADS) void gemm_x3_wide_kernel(X3GemmArgs g) 
         }
         w_cur = w_next;
         float* const gC = batched ? table_at(g.z.out, (unsigned)bz) : g.C;
-        const float* const gR = batched ? table_at(g.z.res, (unsigned)bz) : g.R;
         if (x3_out) {
             // ---- result in the X3 format: the tile goes through LDS (its own region behind the ring) so that 8 consecutive
             // columns - or, for the transposed part, 8 rows in the attention kernel's key order - meet in one thread, which
@@ -496,9 +536,8 @@ __global__ __launch_bounds__(XW_THREADS) void gemm_x3_wide_kernel(X3GemmArgs g) 
             __builtin_amdgcn_s_barrier();          // the staging region may be written again
         } else {
             // ---- fp32 result.  acc[i][4 j + e] is C[m0 + 32 i + r][col0 + 8 j + e]: stored from there, an instruction would
-            // touch 32 rows with 32 bytes each (a quarter of a line per request).  The wave turns its 96 x 32 part around in a
-            // PRIVATE LDS region instead (no barrier: a wave's LDS operations execute in order) and stores eight whole
-            // 128-byte rows per instruction; bias and residual quads are then one coalesced access each as well
+            // touch 32 rows with 32 bytes each (a quarter of a line per request).  The wave turns its 96 x 32 part around in
+            // its own LDS region instead; shared_epilogue (all seven waves) then works on items of eight whole 128-byte rows
             float* const wst = reinterpret_cast<float*>(lds + XW_STAGE_OFF) + wave * (XW_BM * XW_WPITCH);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
@@ -506,28 +545,7 @@ __global__ __launch_bounds__(XW_THREADS) void gemm_x3_wide_kernel(X3GemmArgs g) 
                 for (int j = 0; j < 4; ++j)
                     *reinterpret_cast<xf32x4*>(wst + (32 * i + r) * XW_WPITCH + 8 * j + 4 * hi) =
                         xf32x4{acc[i][4 * j], acc[i][4 * j + 1], acc[i][4 * j + 2], acc[i][4 * j + 3]};
-            const bool gelu = (g.flags & kGemmGelu) != 0, has_res = (g.flags & kGemmResidual) != 0;
-            const int colq = lane & 7, rsub = lane >> 3;
-            const int col = n0 + 32 * wave + 4 * colq;
-            const bool col_ok = col < g.N;
-            bool sc[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sc[e] = scaled(col + e);
-#pragma unroll
-            for (int it = 0; it < XW_BM / 8; ++it) {
-                const int row = m0 + 8 * it + rsub;
-                xf32x4 v = *reinterpret_cast<const xf32x4*>(wst + (8 * it + rsub) * XW_WPITCH + 4 * colq);
-                const xf32x4 res = has_res ? *reinterpret_cast<const xf32x4*>(gR + (long)min(row, g.M - 1) * g.ldr + min(col, g.N - 4))
-                                           : xf32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] += bias[0][e];
-                    if (sc[e]) v[e] *= g.scale;
-                    if (gelu) v[e] = x3_gelu_erf(v[e]);
-                    v[e] += res[e];
-                }
-                if (row < g.M && col_ok) *reinterpret_cast<xf32x4*>(gC + (long)row * g.ldc + col) = v;
-            }
+            shared_epilogue(m0, n0, bz);
         }
         slot = next_slot;
     }

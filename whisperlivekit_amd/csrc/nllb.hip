@@ -178,6 +178,9 @@ struct wlk_nllb_session {
     int step_k = 1;
     hipGraphExec_t step_exec[2] = {nullptr, nullptr};
     int step_exec_k[2] = {0, 0};
+    int step_exec_src[2] = {0, 0};     // the source length a captured step was recorded with: the cross-attention launch carries it
+                                       // by value, so a sentence of another length needs a new recording (round 5: a session
+                                       // that translated a 5-token and then a 7-token source replayed the 5-token graph)
     template <typename T>
     T* alloc(size_t n) {
         void* p = nullptr;
@@ -548,7 +551,7 @@ int wlk_nllb_step(wlk_nllb_session* s, const int64_t* tokens, int32_t n_rows, in
         for (int r = 0; r < n_rows; ++r) s->step_host[r] = (int)tokens[r];
         s->step_host[n_rows] = s->self_len;
         hipGraphExec_t& exec = s->step_exec[s->kv_cur];
-        if (!exec || s->step_exec_k[s->kv_cur] != k) {
+        if (!exec || s->step_exec_k[s->kv_cur] != k || s->step_exec_src[s->kv_cur] != s->src_len) {
             if (exec) { WLK_HIP(hipGraphExecDestroy(exec)); exec = nullptr; }
             s->step_k = k;
             hipGraph_t graph = nullptr;
@@ -565,6 +568,7 @@ int wlk_nllb_step(wlk_nllb_session* s, const int64_t* tokens, int32_t n_rows, in
             (void)hipGraphDestroy(graph);
             WLK_HIP(e);
             s->step_exec_k[s->kv_cur] = k;
+            s->step_exec_src[s->kv_cur] = s->src_len;
         }
         WLK_HIP(hipGraphLaunch(exec, s->stream));
         WLK_HIP(hipStreamSynchronize(s->stream));
