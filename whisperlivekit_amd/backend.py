@@ -67,7 +67,7 @@ class HipSimulStreamingASR:
                  state_dict=None, dims: Optional[ModelDims] = None, alignment_heads=None,
                  synthetic_seed: Optional[int] = None, hip_model: Optional[HipWhisperModel] = None,
                  custom_alignment_heads: Optional[Sequence[Tuple[int, int]]] = None,
-                 hw_queues: Optional[int] = None, **cfg_kwargs):
+                 hw_queues: Optional[int] = None, lora_path: Optional[str] = None, **cfg_kwargs):
         if hw_queues is not None:     # explicit deployment knob (process-wide, see _lib.configure_hw_queues); default: off
             from . import _lib
             _lib.configure_hw_queues(hw_queues)
@@ -81,9 +81,12 @@ class HipSimulStreamingASR:
         if hip_model is not None:
             self.hip_model = hip_model
         elif model_path is not None:
-            d, sd = load_openai_checkpoint(model_path)
+            # any LOCAL checkpoint load_model takes (whisper/__init__.py:466-596): file or directory, .pt / .bin /
+            # .safetensors / shards, openai / HuggingFace / MLX names, an optional LoRA adapter merged in
+            from .checkpoint import load_whisper_checkpoint
+            d, sd, own_heads = load_whisper_checkpoint(model_path, lora_path)
             self.hip_model = HipWhisperModel.from_state_dict(
-                d, sd, heads or ALIGNMENT_HEADS.get(model_size), device)
+                d, sd, heads or own_heads or ALIGNMENT_HEADS.get(model_size), device)
         elif state_dict is not None:
             d = dims or MODEL_DIMS[model_size]
             self.hip_model = HipWhisperModel.from_state_dict(

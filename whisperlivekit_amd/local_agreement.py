@@ -39,9 +39,9 @@ class HipWhisperASR:
         self.buffer_trimming = "segment"
         self.buffer_trimming_sec = 15
         self.backend_choice = "whisper"
-        if lora_path is not None:
-            raise NotImplementedError("LoRA adapters are merged at load time by the reference (whisper/__init__.py); "
-                                      "hand the merged state_dict in instead")
+        if lora_path is not None and model_dir is None:
+            raise ValueError("lora_path needs model_dir: the adapter is merged into the checkpoint's weights at load time "
+                             "(whisper/__init__.py:337-391)")
         if hip_model is not None:
             self.model = hip_model
         else:
@@ -50,11 +50,14 @@ class HipWhisperASR:
 
     def load_model(self, model_size=None, cache_dir=None, model_dir=None, *, device: int = 0, state_dict=None,
                    synthetic_seed: Optional[int] = None) -> HipWhisperModel:
-        """An openai-layout ``.pt`` (``model_dir`` is the file, backends.py:44-61), a state_dict for a named size, or
-        seeded random weights of a named size (parity / timing runs: there is no checkpoint where this is built)."""
+        """A local checkpoint in any layout the reference's load_model takes (``model_dir`` = file or directory,
+        backends.py:44-61; openai / HuggingFace / MLX names, safetensors, shards, a LoRA adapter merged in:
+        checkpoint.load_whisper_checkpoint), a state_dict for a named size, or seeded random weights of a named size (parity /
+        timing runs: there is no checkpoint where this is built)."""
         if model_dir is not None:
-            dims, sd = load_openai_checkpoint(str(model_dir))
-            return HipWhisperModel.from_state_dict(dims, sd, ALIGNMENT_HEADS.get(model_size), device)
+            from .checkpoint import load_whisper_checkpoint
+            dims, sd, own_heads = load_whisper_checkpoint(str(model_dir), self.lora_path)
+            return HipWhisperModel.from_state_dict(dims, sd, own_heads or ALIGNMENT_HEADS.get(model_size), device)
         if model_size is None:
             raise ValueError("Either model_size or model_dir must be set for HipWhisperASR")
         if state_dict is not None:
