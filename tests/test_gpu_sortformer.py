@@ -92,6 +92,41 @@ def test_network_matches_oracle_two_blocks(shallow, n_ctx, n_feat):
     assert ref.std() > 0.01
 
 
+def test_concurrent_steps_on_one_model_equal_serial_steps(shallow):
+    """Round 5: a step runs in one of the model's workspaces on that workspace's stream, so sessions that share the model
+    (config 4) overlap instead of queueing behind one set of buffers.  Eight threads x five steps of different shapes on one
+    model: every result bit-identical to the same step run alone."""
+    import threading
+    dims, _tsd, m = shallow
+    rng = np.random.default_rng(77)
+    jobs = []
+    for t in range(8):
+        for k in range(5):
+            n_feat = int(rng.choice([0, 9, 101, 200]))
+            n_ctx = int(rng.integers(1 if n_feat == 0 else 0, 300))
+            feats = logmel_like(np.random.default_rng(1000 * t + k), n_feat) if n_feat else None
+            ctx = (0.3 * np.random.default_rng(2000 * t + k).standard_normal((n_ctx, 512))).astype(np.float32) if n_ctx else None
+            jobs.append((t, feats, ctx))
+    serial = [m.step(f, c) for _t, f, c in jobs]
+    got = [None] * len(jobs)
+    errors = []
+
+    def worker(t):
+        try:
+            for i, (jt, f, c) in enumerate(jobs):
+                if jt == t:
+                    got[i] = m.step(f, c)
+        except Exception as e:            # pragma: no cover
+            errors.append(e)
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    [th.start() for th in threads]
+    [th.join() for th in threads]
+    assert not errors, errors
+    for (chunk_s, preds_s), (chunk_g, preds_g) in zip(serial, got):
+        assert np.array_equal(chunk_s.view(np.uint32), chunk_g.view(np.uint32))
+        assert np.array_equal(preds_s.view(np.uint32), preds_g.view(np.uint32))
+
+
 def test_capacity_and_argument_errors(shallow):
     dims, _, m = shallow
     with pytest.raises(_lib.WlkError):

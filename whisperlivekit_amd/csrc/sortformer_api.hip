@@ -1,9 +1,11 @@
 // C ABI of the streaming Sortformer diarizer network (include/wlk_hip.h, "a12 network"): packed weight arena,
 // workspace, and the launch sequence of one streaming step.  Kernels: sortformer.hip, gemm_f32.hip, layernorm.hip.
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -121,7 +123,6 @@ using namespace wlk;
 struct wlk_sortformer {
     wlk_sf_dims D{};
     int device = 0;
-    hipStream_t stream = nullptr;
     float* arena = nullptr;
     uint64_t arena_floats = 0;
     std::vector<SfSlot> layout;
@@ -130,11 +131,22 @@ struct wlk_sortformer {
     std::mutex mu;
     std::vector<SfFcLayer> fc;
     std::vector<SfTfLayer> tf;
-    // workspace
-    float *feats = nullptr, *ca = nullptr, *cb = nullptr, *emb_raw = nullptr, *x = nullptr, *xn = nullptr, *wide = nullptr,
-          *qkv = nullptr, *att = nullptr, *pos_full = nullptr, *tx = nullptr, *ty = nullptr, *tqkv = nullptr, *tatt = nullptr,
-          *th = nullptr, *preds = nullptr;
-    int last_T = 0;
+    // Workspaces: one step runs in one of them, on its own stream - sessions that share the model (config 4: eight
+    // diarizer sessions per GPU) no longer queue behind ONE set of buffers (round 5: their p50 per chunk was the queue, not
+    // the GPU).  A step takes the lowest free workspace, so a single caller always lands in workspace 0 (what wlk_sf_export
+    // reads when no other step ran since).  WLK_SF_WORKSPACES=n (default 4, 1 = the round-4 behaviour).
+    struct Workspace {
+        hipStream_t stream = nullptr;
+        float *feats = nullptr, *ca = nullptr, *cb = nullptr, *emb_raw = nullptr, *x = nullptr, *xn = nullptr, *wide = nullptr,
+              *qkv = nullptr, *att = nullptr, *tx = nullptr, *ty = nullptr, *tqkv = nullptr, *tatt = nullptr, *th = nullptr,
+              *preds = nullptr;
+        int last_T = 0;
+        bool busy = false;
+    };
+    std::vector<Workspace> ws;
+    std::condition_variable ws_free;
+    int last_ws = 0;                      // the workspace of the most recent step (exports)
+    float* pos_full = nullptr;            // read-only after finalize
     std::vector<float*> owned;
     const float* P(const std::string& n) const {
         auto it = index.find(n);
@@ -160,56 +172,56 @@ static void sf_linear(const LaunchCtx& c, const float* A, long lda, const float*
     launch_linear(c, g, tag);
 }
 
-// the network over m->emb_raw[0:T] -> m->preds[0:T]
-static void sf_network(wlk_sortformer* m, const LaunchCtx& c, int T) {
+// the network over w_->emb_raw[0:T] -> w_->preds[0:T] of one workspace
+static void sf_network(wlk_sortformer* m, wlk_sortformer::Workspace* w_, const LaunchCtx& c, int T) {
     const wlk_sf_dims& D = m->D;
     const int d = D.fc_d_model, ff = D.fc_ff, dh = d / D.fc_heads, L = D.max_frames;
-    launch_sf_scale_copy(c, m->emb_raw, m->x, (long)T * d, D.xscale);
+    launch_sf_scale_copy(c, w_->emb_raw, w_->x, (long)T * d, D.xscale);
     for (int l = 0; l < D.fc_layers; ++l) {
         const SfFcLayer& w = m->fc[l];
         // x += 0.5 * FF1(LN(x))   (the 0.5 is folded into ff1b at pack time: exact, a power of two)
-        launch_layernorm(c, m->x, d, w.ln_ff1_w, w.ln_ff1_b, m->xn, d, T, d, "sf_ln");
-        sf_linear(c, m->xn, d, w.ff1a_w, w.ff1a_b, m->wide, ff, T, ff, d, kGemmSwish, nullptr, 0, "sf_ff_a");
-        sf_linear(c, m->wide, ff, w.ff1b_w, w.ff1b_b, m->x, d, T, d, ff, kGemmResidual, m->x, d, "sf_ff_b");
+        launch_layernorm(c, w_->x, d, w.ln_ff1_w, w.ln_ff1_b, w_->xn, d, T, d, "sf_ln");
+        sf_linear(c, w_->xn, d, w.ff1a_w, w.ff1a_b, w_->wide, ff, T, ff, d, kGemmSwish, nullptr, 0, "sf_ff_a");
+        sf_linear(c, w_->wide, ff, w.ff1b_w, w.ff1b_b, w_->x, d, T, d, ff, kGemmResidual, w_->x, d, "sf_ff_b");
         // x += RelPosMHA(LN(x))
-        launch_layernorm(c, m->x, d, w.ln_att_w, w.ln_att_b, m->xn, d, T, d, "sf_ln");
-        sf_linear(c, m->xn, d, w.qkv_w, w.qkv_b, m->qkv, 3 * d, T, 3 * d, d, 0, nullptr, 0, "sf_qkv");
+        launch_layernorm(c, w_->x, d, w.ln_att_w, w.ln_att_b, w_->xn, d, T, d, "sf_ln");
+        sf_linear(c, w_->xn, d, w.qkv_w, w.qkv_b, w_->qkv, 3 * d, T, 3 * d, d, 0, nullptr, 0, "sf_qkv");
         SfAttnArgs a;
-        a.q = m->qkv; a.k = m->qkv + d; a.v = m->qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
-        a.out = m->att; a.ldo = d; a.T = T; a.n_head = D.fc_heads; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
+        a.q = w_->qkv; a.k = w_->qkv + d; a.v = w_->qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
+        a.out = w_->att; a.ldo = d; a.T = T; a.n_head = D.fc_heads; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
         a.pos = m->pos_full + (size_t)l * (2 * L - 1) * d; a.ldp = d; a.pos_row0 = L - 1;
         a.bias_u = w.bias_u; a.bias_v = w.bias_v;
         launch_sf_attention(c, a);
-        sf_linear(c, m->att, d, w.out_w, w.out_b, m->x, d, T, d, d, kGemmResidual, m->x, d, "sf_att_out");
+        sf_linear(c, w_->att, d, w.out_w, w.out_b, w_->x, d, T, d, d, kGemmResidual, w_->x, d, "sf_att_out");
         // x += Conv(LN(x))
-        launch_layernorm(c, m->x, d, w.ln_conv_w, w.ln_conv_b, m->xn, d, T, d, "sf_ln");
-        sf_linear(c, m->xn, d, w.pw1_w, w.pw1_b, m->wide, 2 * d, T, 2 * d, d, 0, nullptr, 0, "sf_conv_pw1");
-        launch_sf_glu_dwconv(c, m->wide, w.dw_w, w.dw_b, w.bn_mean, w.bn_invstd, w.bn_w, w.bn_b, m->att, T, d, D.conv_kernel);
-        sf_linear(c, m->att, d, w.pw2_w, w.pw2_b, m->x, d, T, d, d, kGemmResidual, m->x, d, "sf_conv_pw2");
+        launch_layernorm(c, w_->x, d, w.ln_conv_w, w.ln_conv_b, w_->xn, d, T, d, "sf_ln");
+        sf_linear(c, w_->xn, d, w.pw1_w, w.pw1_b, w_->wide, 2 * d, T, 2 * d, d, 0, nullptr, 0, "sf_conv_pw1");
+        launch_sf_glu_dwconv(c, w_->wide, w.dw_w, w.dw_b, w.bn_mean, w.bn_invstd, w.bn_w, w.bn_b, w_->att, T, d, D.conv_kernel);
+        sf_linear(c, w_->att, d, w.pw2_w, w.pw2_b, w_->x, d, T, d, d, kGemmResidual, w_->x, d, "sf_conv_pw2");
         // x += 0.5 * FF2(LN(x)); x = LN_out(x)
-        launch_layernorm(c, m->x, d, w.ln_ff2_w, w.ln_ff2_b, m->xn, d, T, d, "sf_ln");
-        sf_linear(c, m->xn, d, w.ff2a_w, w.ff2a_b, m->wide, ff, T, ff, d, kGemmSwish, nullptr, 0, "sf_ff_a");
-        sf_linear(c, m->wide, ff, w.ff2b_w, w.ff2b_b, m->x, d, T, d, ff, kGemmResidual, m->x, d, "sf_ff_b");
-        launch_layernorm(c, m->x, d, w.ln_out_w, w.ln_out_b, m->x, d, T, d, "sf_ln");
+        launch_layernorm(c, w_->x, d, w.ln_ff2_w, w.ln_ff2_b, w_->xn, d, T, d, "sf_ln");
+        sf_linear(c, w_->xn, d, w.ff2a_w, w.ff2a_b, w_->wide, ff, T, ff, d, kGemmSwish, nullptr, 0, "sf_ff_a");
+        sf_linear(c, w_->wide, ff, w.ff2b_w, w.ff2b_b, w_->x, d, T, d, ff, kGemmResidual, w_->x, d, "sf_ff_b");
+        launch_layernorm(c, w_->x, d, w.ln_out_w, w.ln_out_b, w_->x, d, T, d, "sf_ln");
     }
     const int dt = D.tf_d_model, dht = dt / D.tf_heads, inner = D.tf_inner;
-    sf_linear(c, m->x, d, m->P("proj.w"), m->P("proj.b"), m->tx, dt, T, dt, d, 0, nullptr, 0, "sf_proj");
+    sf_linear(c, w_->x, d, m->P("proj.w"), m->P("proj.b"), w_->tx, dt, T, dt, d, 0, nullptr, 0, "sf_proj");
     const float qk_scale = 1.0f / sqrtf(sqrtf((float)dht));
     for (int l = 0; l < D.tf_layers; ++l) {
         const SfTfLayer& w = m->tf[l];
-        sf_linear(c, m->tx, dt, w.qkv_w, w.qkv_b, m->tqkv, 3 * dt, T, 3 * dt, dt, kGemmScaleCols, nullptr, 0, "sf_tf_qkv",
+        sf_linear(c, w_->tx, dt, w.qkv_w, w.qkv_b, w_->tqkv, 3 * dt, T, 3 * dt, dt, kGemmScaleCols, nullptr, 0, "sf_tf_qkv",
                   qk_scale, 2 * dt);
         SfAttnArgs a;
-        a.q = m->tqkv; a.k = m->tqkv + dt; a.v = m->tqkv + 2 * dt; a.ldq = a.ldk = a.ldv = 3 * dt;
-        a.out = m->tatt; a.ldo = dt; a.T = T; a.n_head = D.tf_heads; a.dh = dht; a.scale = 1.f;
+        a.q = w_->tqkv; a.k = w_->tqkv + dt; a.v = w_->tqkv + 2 * dt; a.ldq = a.ldk = a.ldv = 3 * dt;
+        a.out = w_->tatt; a.ldo = dt; a.T = T; a.n_head = D.tf_heads; a.dh = dht; a.scale = 1.f;
         launch_sf_attention(c, a);
-        sf_linear(c, m->tatt, dt, w.out_w, w.out_b, m->ty, dt, T, dt, dt, kGemmResidual, m->tx, dt, "sf_tf_out");
-        launch_layernorm(c, m->ty, dt, w.ln1_w, w.ln1_b, m->tx, dt, T, dt, "sf_ln");
-        sf_linear(c, m->tx, dt, w.in_w, w.in_b, m->th, inner, T, inner, dt, kGemmRelu, nullptr, 0, "sf_tf_in");
-        sf_linear(c, m->th, inner, w.outd_w, w.outd_b, m->ty, dt, T, dt, inner, kGemmResidual, m->tx, dt, "sf_tf_outd");
-        launch_layernorm(c, m->ty, dt, w.ln2_w, w.ln2_b, m->tx, dt, T, dt, "sf_ln");
+        sf_linear(c, w_->tatt, dt, w.out_w, w.out_b, w_->ty, dt, T, dt, dt, kGemmResidual, w_->tx, dt, "sf_tf_out");
+        launch_layernorm(c, w_->ty, dt, w.ln1_w, w.ln1_b, w_->tx, dt, T, dt, "sf_ln");
+        sf_linear(c, w_->tx, dt, w.in_w, w.in_b, w_->th, inner, T, inner, dt, kGemmRelu, nullptr, 0, "sf_tf_in");
+        sf_linear(c, w_->th, inner, w.outd_w, w.outd_b, w_->ty, dt, T, dt, inner, kGemmResidual, w_->tx, dt, "sf_tf_outd");
+        launch_layernorm(c, w_->ty, dt, w.ln2_w, w.ln2_b, w_->tx, dt, T, dt, "sf_ln");
     }
-    launch_sf_head(c, m->tx, m->P("head.h.w"), m->P("head.h.b"), m->P("head.s.w"), m->P("head.s.b"), m->preds, T, dt,
+    launch_sf_head(c, w_->tx, m->P("head.h.w"), m->P("head.h.b"), m->P("head.s.w"), m->P("head.s.b"), w_->preds, T, dt,
                    D.n_spk);
 }
 }  // namespace wlk
@@ -259,29 +271,42 @@ int wlk_sf_create(const wlk_sf_dims* dims, int device, wlk_sortformer** out) {
         m->device = device;
         m->layout = sf_layout(*dims, &m->arena_floats);
         for (const auto& s : m->layout) m->index[s.name] = &s;
-        WLK_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
         wlk_sortformer* p = m.get();
         m->arena = sf_alloc(p, m->arena_floats);
         memset_sync(m->arena, 0, m->arena_floats * sizeof(float));
         const wlk_sf_dims& D = m->D;
         const size_t L = D.max_frames, d = D.fc_d_model, dt = D.tf_d_model, C = D.sub_channels;
         const size_t T1 = sf_sub_len(D.max_feat_frames), F1 = sf_sub_len(D.n_mels);
-        m->feats = sf_alloc(p, (size_t)D.max_feat_frames * D.n_mels);
-        m->ca = sf_alloc(p, T1 * F1 * C);
-        m->cb = sf_alloc(p, T1 * F1 * C);
-        m->emb_raw = sf_alloc(p, L * d);
-        m->x = sf_alloc(p, L * d);
-        m->xn = sf_alloc(p, L * d);
-        m->wide = sf_alloc(p, L * std::max<size_t>(D.fc_ff, 2 * d));
-        m->qkv = sf_alloc(p, L * 3 * d);
-        m->att = sf_alloc(p, L * d);
         m->pos_full = sf_alloc(p, (size_t)std::max(D.fc_layers, 1) * (2 * L - 1) * d);
-        m->tx = sf_alloc(p, L * dt);
-        m->ty = sf_alloc(p, L * dt);
-        m->tqkv = sf_alloc(p, L * 3 * dt);
-        m->tatt = sf_alloc(p, L * dt);
-        m->th = sf_alloc(p, L * D.tf_inner);
-        m->preds = sf_alloc(p, L * D.n_spk);
+        int n_ws = 4;
+        if (const char* e = std::getenv("WLK_SF_WORKSPACES")) n_ws = std::max(1, std::min(16, std::atoi(e)));
+        // a diarizer step is a chain of small kernels that shares the GPU with ASR sessions' chip-filling encoder kernels
+        // (config 4): WLK_SF_PRIORITY=hi puts its streams ahead of them in the dispatcher.  Measured a loss (ASR -20 %,
+        // diarizer p95 worse: profiles/r05l_ab_sortformer_stream_priority.txt); default: normal priority
+        int prio_lo = 0, prio_hi = 0;
+        WLK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        const char* pe = std::getenv("WLK_SF_PRIORITY");
+        m->ws.resize(n_ws);
+        for (auto& w : m->ws) {
+            if (pe && pe[0] == 'h') WLK_HIP(hipStreamCreateWithPriority(&w.stream, hipStreamNonBlocking, prio_hi));
+            else if (pe && pe[0] == 'l') WLK_HIP(hipStreamCreateWithPriority(&w.stream, hipStreamNonBlocking, prio_lo));
+            else WLK_HIP(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+            w.feats = sf_alloc(p, (size_t)D.max_feat_frames * D.n_mels);
+            w.ca = sf_alloc(p, T1 * F1 * C);
+            w.cb = sf_alloc(p, T1 * F1 * C);
+            w.emb_raw = sf_alloc(p, L * d);
+            w.x = sf_alloc(p, L * d);
+            w.xn = sf_alloc(p, L * d);
+            w.wide = sf_alloc(p, L * std::max<size_t>(D.fc_ff, 2 * d));
+            w.qkv = sf_alloc(p, L * 3 * d);
+            w.att = sf_alloc(p, L * d);
+            w.tx = sf_alloc(p, L * dt);
+            w.ty = sf_alloc(p, L * dt);
+            w.tqkv = sf_alloc(p, L * 3 * dt);
+            w.tatt = sf_alloc(p, L * dt);
+            w.th = sf_alloc(p, L * D.tf_inner);
+            w.preds = sf_alloc(p, L * D.n_spk);
+        }
         *out = m.release();
         return WLK_OK;
     });
@@ -343,12 +368,12 @@ int wlk_sf_finalize(wlk_sortformer* m) {
         }
         // linear_pos(pos_emb) of every block for the longest sequence: a shorter sequence of T frames uses rows
         // [max_frames - T, max_frames + T - 1) of it (RelPositionalEncoding centres its table the same way)
-        LaunchCtx c{m->stream, nullptr};
+        LaunchCtx c{m->ws[0].stream, nullptr};
         const int d = D.fc_d_model, rows = 2 * D.max_frames - 1;
         for (int l = 0; l < D.fc_layers; ++l)
             sf_linear(c, m->P("pos.table"), d, m->fc[l].pos_w, nullptr, m->pos_full + (size_t)l * rows * d, d, rows, d, d, 0,
                       nullptr, 0, "sf_pos");
-        WLK_HIP(hipStreamSynchronize(m->stream));
+        WLK_HIP(hipStreamSynchronize(m->ws[0].stream));
         m->finalized = true;
         return WLK_OK;
     });
@@ -363,7 +388,6 @@ int wlk_sf_step(wlk_sortformer* m, const float* feats_host, int n_feat, const fl
         return sf_fail(WLK_ERR_ARG, "bad step arguments");
     if (n_feat > m->D.max_feat_frames) return sf_fail(WLK_ERR_CAPACITY, "feature chunk longer than max_feat_frames");
     return sf_guarded([&]() {
-        std::lock_guard<std::mutex> lock(m->mu);
         WLK_HIP(hipSetDevice(m->device));
         const wlk_sf_dims& D = m->D;
         const int d = D.fc_d_model, C = D.sub_channels;
@@ -374,28 +398,43 @@ int wlk_sf_step(wlk_sortformer* m, const float* feats_host, int n_feat, const fl
         if (T < 1) return sf_fail(WLK_ERR_ARG, "empty step");
         if (T > D.max_frames) return sf_fail(WLK_ERR_CAPACITY, "sequence longer than max_frames");
         if (Tc > chunk_capacity_rows || T > preds_capacity_rows) return sf_fail(WLK_ERR_CAPACITY, "output buffer too small");
-        LaunchCtx c{m->stream, nullptr};
+        // the lowest free workspace (waits when all are busy); released on every way out
+        wlk_sortformer::Workspace* w_ = nullptr;
+        {
+            std::unique_lock<std::mutex> lock(m->mu);
+            m->ws_free.wait(lock, [&] { for (auto& w : m->ws) if (!w.busy) return true; return false; });
+            for (auto& w : m->ws) if (!w.busy) { w_ = &w; break; }
+            w_->busy = true;
+        }
+        struct Release {
+            wlk_sortformer* m; wlk_sortformer::Workspace* w;
+            ~Release() {
+                { std::lock_guard<std::mutex> lock(m->mu); w->busy = false; m->last_ws = (int)(w - m->ws.data()); }
+                m->ws_free.notify_one();
+            }
+        } release{m, w_};
+        LaunchCtx c{w_->stream, nullptr};
         if (n_ctx > 0)
-            WLK_HIP(hipMemcpyAsync(m->emb_raw, ctx_embs_host, (size_t)n_ctx * d * sizeof(float), hipMemcpyHostToDevice, m->stream));
+            WLK_HIP(hipMemcpyAsync(w_->emb_raw, ctx_embs_host, (size_t)n_ctx * d * sizeof(float), hipMemcpyHostToDevice, w_->stream));
         if (n_feat > 0) {
             // ConvSubsampling.forward (dw_striding): conv0+ReLU, 2 x (depthwise s2, pointwise, ReLU), Linear
-            WLK_HIP(hipMemcpyAsync(m->feats, feats_host, (size_t)n_feat * D.n_mels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+            WLK_HIP(hipMemcpyAsync(w_->feats, feats_host, (size_t)n_feat * D.n_mels * sizeof(float), hipMemcpyHostToDevice, w_->stream));
             const int T1 = sf_sub_len(n_feat), F1 = sf_sub_len(D.n_mels), T2 = sf_sub_len(T1), F2 = sf_sub_len(F1),
                       T3 = sf_sub_len(T2), F3 = sf_sub_len(F2);
-            launch_sf_conv0(c, m->feats, m->P("pre.conv0.w"), m->P("pre.conv0.b"), m->ca, n_feat, D.n_mels, C);
-            launch_sf_dwconv2d(c, m->ca, m->P("pre.dw1.w"), m->P("pre.dw1.b"), m->cb, T1, F1, C);
-            sf_linear(c, m->cb, C, m->P("pre.pw1.w"), m->P("pre.pw1.b"), m->ca, C, T2 * F2, C, C, kGemmRelu, nullptr, 0, "sf_pre_pw");
-            launch_sf_dwconv2d(c, m->ca, m->P("pre.dw2.w"), m->P("pre.dw2.b"), m->cb, T2, F2, C);
-            sf_linear(c, m->cb, C, m->P("pre.pw2.w"), m->P("pre.pw2.b"), m->ca, C, T3 * F3, C, C, kGemmRelu, nullptr, 0, "sf_pre_pw");
-            sf_linear(c, m->ca, (long)F3 * C, m->P("pre.out.w"), m->P("pre.out.b"), m->emb_raw + (size_t)n_ctx * d, d, T3, d,
+            launch_sf_conv0(c, w_->feats, m->P("pre.conv0.w"), m->P("pre.conv0.b"), w_->ca, n_feat, D.n_mels, C);
+            launch_sf_dwconv2d(c, w_->ca, m->P("pre.dw1.w"), m->P("pre.dw1.b"), w_->cb, T1, F1, C);
+            sf_linear(c, w_->cb, C, m->P("pre.pw1.w"), m->P("pre.pw1.b"), w_->ca, C, T2 * F2, C, C, kGemmRelu, nullptr, 0, "sf_pre_pw");
+            launch_sf_dwconv2d(c, w_->ca, m->P("pre.dw2.w"), m->P("pre.dw2.b"), w_->cb, T2, F2, C);
+            sf_linear(c, w_->cb, C, m->P("pre.pw2.w"), m->P("pre.pw2.b"), w_->ca, C, T3 * F3, C, C, kGemmRelu, nullptr, 0, "sf_pre_pw");
+            sf_linear(c, w_->ca, (long)F3 * C, m->P("pre.out.w"), m->P("pre.out.b"), w_->emb_raw + (size_t)n_ctx * d, d, T3, d,
                       F3 * C, 0, nullptr, 0, "sf_pre_out");
-            WLK_HIP(hipMemcpyAsync(chunk_embs_host, m->emb_raw + (size_t)n_ctx * d, (size_t)Tc * d * sizeof(float),
-                                   hipMemcpyDeviceToHost, m->stream));
+            WLK_HIP(hipMemcpyAsync(chunk_embs_host, w_->emb_raw + (size_t)n_ctx * d, (size_t)Tc * d * sizeof(float),
+                                   hipMemcpyDeviceToHost, w_->stream));
         }
-        sf_network(m, c, T);
-        m->last_T = T;
-        WLK_HIP(hipMemcpyAsync(preds_host, m->preds, (size_t)T * D.n_spk * sizeof(float), hipMemcpyDeviceToHost, m->stream));
-        WLK_HIP(hipStreamSynchronize(m->stream));
+        sf_network(m, w_, c, T);
+        w_->last_T = T;
+        WLK_HIP(hipMemcpyAsync(preds_host, w_->preds, (size_t)T * D.n_spk * sizeof(float), hipMemcpyDeviceToHost, w_->stream));
+        WLK_HIP(hipStreamSynchronize(w_->stream));
         return WLK_OK;
     });
 }
@@ -407,8 +446,9 @@ int wlk_sf_export(wlk_sortformer* m, const char* what, float* host, uint64_t cap
         WLK_HIP(hipSetDevice(m->device));
         const float* src = nullptr;
         uint64_t n = 0;
-        if (!strcmp(what, "fc_out")) { src = m->x; n = (uint64_t)m->last_T * m->D.fc_d_model; }
-        else if (!strcmp(what, "tf_out")) { src = m->tx; n = (uint64_t)m->last_T * m->D.tf_d_model; }
+        const wlk_sortformer::Workspace& w = m->ws[m->last_ws];       // the most recent step's
+        if (!strcmp(what, "fc_out")) { src = w.x; n = (uint64_t)w.last_T * m->D.fc_d_model; }
+        else if (!strcmp(what, "tf_out")) { src = w.tx; n = (uint64_t)w.last_T * m->D.tf_d_model; }
         else return sf_fail(WLK_ERR_ARG, std::string("unknown export ") + what);
         if (n > capacity) return sf_fail(WLK_ERR_CAPACITY, "export buffer too small");
         copy_sync(host, src, n * sizeof(float), hipMemcpyDeviceToHost);
@@ -422,7 +462,8 @@ int wlk_sf_destroy(wlk_sortformer* m) {
     (void)hipSetDevice(m->device);
     for (float* p : m->owned)
         if (p) (void)hipFree(p);
-    if (m->stream) (void)hipStreamDestroy(m->stream);
+    for (auto& w : m->ws)
+        if (w.stream) (void)hipStreamDestroy(w.stream);
     delete m;
     return WLK_OK;
 }
