@@ -1,16 +1,18 @@
-// fp32-accurate GEMM on the bf16 matrix cores:  C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N])  with both operands in
-// the X3 format (x3.h: three bf16 planes per fp32 value, six bf16 MFMAs per fp32 product).  gfx950 only.
+// fp32-accurate GEMM on the bf16 matrix cores:  C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N])  with both operands as three
+// bf16 planes per fp32 value (x3.h; six bf16 MFMAs per fp32 product).  gfx950 only.
 //
 // Wide kernel (N >= 1024: the encoder's qkv / fc1 projections and the cross-attention K|V projection of all decoder
-// layers): one 96 x 128 tile per workgroup - 16 x 16 = 256 workgroups on the 1500 x 2048 fc1 problem, one per CU.
-// The four waves split the tile's COLUMNS (wave w owns 96 x 32: three 32 x 32 accumulators), so no cross-wave fold is
-// needed; K is walked in 32-deep slabs (one slab row = 4 chunks x 3 planes x 16 bytes = 192 contiguous bytes of the X3
-// row) that arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB pieces, issued by four LOADER waves) into a ring of three
-// slabs, two slabs in flight beyond the one being multiplied, one workgroup barrier per slab.  The DMA
-// writes lane-linearly, so the bank swizzle lives in the source address: unit u of LDS row r sits at unit u ^ ((r >> 2) & 3)
-// - each 16-lane service group of a fragment ds_read_b128 then touches 16 distinct 16-byte bank groups.
-// Per slab and compute wave: 36 MFMAs (2 k-steps x 3 row blocks x 6 plane products; 1152 cycles of matrix pipe), 24
-// fragment reads; per loader wave 11 DMA pieces.  Algorithmic work = 2 M N K flop at fp32 accuracy; the matrix pipe executes 6x that in bf16.
+// layers): 96 x 128 tiles - 16 x 16 = 256 on the 1500 x 2048 fc1 problem, one per CU - walked by persistent workgroups.
+// Four compute waves split a tile's COLUMNS (wave w owns 96 x 32: three 32 x 32 accumulators, no cross-wave fold); K is
+// walked in 32-deep slabs.  ACTIVATIONS: X3 rows (one slab row = 4 chunks x 3 planes x 16 bytes = 192 contiguous bytes)
+// that arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB pieces, issued by three LOADER waves) into a ring of five slots,
+// four slabs in flight beyond the one being multiplied, one workgroup barrier per slab; the DMA writes lane-linearly, so
+// the bank swizzle lives in the source address (unit u of LDS row r sits at unit u ^ ((r >> 2) & 3): each 16-lane
+// service group of a fragment ds_read_b128 touches 16 distinct 16-byte bank groups).  WEIGHTS: fragment-major (W3F
+// below), read by the wave that multiplies them straight into the MFMA's registers.  Per slab and compute wave: 36
+// MFMAs (2 k-steps x 3 row blocks x 6 plane products; 1152 cycles of matrix pipe), 18 fragment reads, 6 weight loads;
+// per loader wave 6 DMA pieces.  Algorithmic work = 2 M N K flop at fp32 accuracy; the matrix pipe executes 6x that in
+// bf16.  Round 5's measurements behind this shape: DESIGN.md 13, profiles/r05[c-j]_x3_*.
 #include <atomic>
 #include <cstdint>
 #include <cstdlib>
