@@ -188,7 +188,7 @@ __device__ __forceinline__ void xw_read_frags(xf32x4 (&f)[XW_NFA], const unsigne
 // was the loss, not the tile boundary; kept because the deeper ring makes the boundary visible.)
 // ABL (timing probe only, WLK_X3_ABL): 1 = loaders and weight loads run, no MFMAs and fragment reads; 2 = no DMA;
 // 3 = MFMAs only; 4 = no weight loads; 5 = weight loads from one cached address; 6 = weight loads in front of a k-step's MFMAs
-// instead of between them
+// instead of between them; 7 / 8 = s_setprio 1 on the compute / loader waves (6 - 8 compute correct results)
 template <int ABL>
 __global__ __launch_bounds__(XW_THREADS) void gemm_x3_wide_kernel(X3GemmArgs g) {
     asm volatile("" ::"s"(g.A3), "s"(g.lda), "s"(g.W3), "s"(g.bias), "s"(g.C), "s"(g.ldc), "s"(g.R), "s"(g.ldr), "s"(g.M),
@@ -232,6 +232,8 @@ __global__ __launch_bounds__(XW_THREADS) void gemm_x3_wide_kernel(X3GemmArgs g) 
     };
     const int slot0 = advance(first);
     if (slot0 >= limit) return;             // padding workgroup (both roles leave before any barrier)
+    if constexpr (ABL == 7) { if (wave < 4) __builtin_amdgcn_s_setprio(1); }      // probes (correct results): issue priority
+    if constexpr (ABL == 8) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }     // of the compute / of the loader waves
     const int nslab = g.K / 32;             // even (launch_gemm_x3)
     const bool x3_out = g.x3_out;
 
@@ -588,6 +590,8 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
         WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
         WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
         WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
         configured.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const int tiles_m = (g.M + XW_BM - 1) / XW_BM, tiles_n = (g.N + XW_BN - 1) / XW_BN;
@@ -644,6 +648,8 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
     else if (abl == 4) hipLaunchKernelGGL(gemm_x3_wide_kernel<4>, grid, dim3(XW_THREADS), XW_LDS_BYTES, ctx.stream, gg);
     else if (abl == 5) hipLaunchKernelGGL(gemm_x3_wide_kernel<5>, grid, dim3(XW_THREADS), XW_LDS_BYTES, ctx.stream, gg);
     else if (abl == 6) hipLaunchKernelGGL(gemm_x3_wide_kernel<6>, grid, dim3(XW_THREADS), XW_LDS_BYTES, ctx.stream, gg);
+    else if (abl == 7) hipLaunchKernelGGL(gemm_x3_wide_kernel<7>, grid, dim3(XW_THREADS), XW_LDS_BYTES, ctx.stream, gg);
+    else if (abl == 8) hipLaunchKernelGGL(gemm_x3_wide_kernel<8>, grid, dim3(XW_THREADS), XW_LDS_BYTES, ctx.stream, gg);
     else hipLaunchKernelGGL(gemm_x3_wide_kernel<0>, grid, dim3(XW_THREADS), XW_LDS_BYTES, ctx.stream, gg);
     WLK_HIP(hipGetLastError());
 }
