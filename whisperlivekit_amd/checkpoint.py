@@ -165,10 +165,9 @@ def load_tensor_file(path: str) -> Any:
         from safetensors.torch import load_file
         return load_file(path, device="cpu")
     import torch
-    try:
-        return torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:            # a pickled object beyond tensors and containers (older exports): the reference loads those too
-        return torch.load(path, map_location="cpu", weights_only=False)
+    # tensors and plain containers only: a checkpoint file is data, not code (the reference's bare torch.load would also run
+    # whatever a pickle asks for; an export that needs that has to be re-saved as tensors first)
+    return torch.load(path, map_location="cpu", weights_only=True)
 
 
 # ---- LoRA -------------------------------------------------------------------------------------------------------------
