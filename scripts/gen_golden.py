@@ -360,6 +360,10 @@ def gen_streams():
     table["large_v3_2s"] = lambda: run_stream("large-v3", synth.to_pcm16_roundtrip(synth.speech_like(2.0, 5)))
     # config 3 as bench.py times it (`--model large-v3 --seconds 10`): seed 0, 20 x 0.5 s (tens of minutes of CPU)
     table["bench_large-v3_10s_s0"] = lambda: run_stream("large-v3", synth.to_pcm16_roundtrip(synth.speech_like(10.0, 0)))
+    # config 3 at BASELINE.json's own length (30 s, 60 x 0.5 s; round 6): audio seed 8 - of seeds 0..11 the stream on which the
+    # seeded large-v3 weights commit the most words, spread over the most calls, from the first second on (scanned on the
+    # GPU with scripts/lv3_seed_scan.py: 47 words in 9 calls; seed 0 commits 26 words in 4 calls, none in its first 10 s)
+    table["bench_large-v3_30s_s8"] = lambda: run_stream("large-v3", synth.to_pcm16_roundtrip(synth.speech_like(30.0, 8)))
     if REAL_VOCAB:
         # a17 with the REAL vocabulary: word splitting / pending UTF-8 / prompt encoding on real GPT-2 byte sequences.
         #   GOLDEN_REAL_VOCAB=1 python scripts/gen_golden.py streams
