@@ -271,12 +271,15 @@ int wlk_sf_finalize(wlk_sortformer* m);
  * -> pre_encode -> chunk embeddings [n_chunk, fc_d_model] (returned in chunk_embs_host, n_chunk in *n_chunk);
  * ctx_embs_host [n_ctx, fc_d_model] = the caller's valid speaker-cache rows followed by its valid FIFO rows;
  * the network runs over [ctx | chunk] and preds_host receives [n_ctx + n_chunk, n_spk] sigmoid activities.
- * n_feat == 0 runs the network over ctx only; n_ctx == 0 over the chunk only.  Thread-safe (one step at a time
- * per model; sessions keep their state on the host). */
+ * n_feat == 0 runs the network over ctx only; n_ctx == 0 over the chunk only.  Thread-safe; sessions keep their state on
+ * the host.  Calls of several threads that wait for the model at the same time run as ONE stacked launch chain (their rows
+ * one after the other, up to 8 sessions); a session's outputs are bit for bit those of its step alone. */
 int wlk_sf_step(wlk_sortformer* m, const float* feats_host, int n_feat, const float* ctx_embs_host, int n_ctx,
                 float* chunk_embs_host, int chunk_capacity_rows, int* n_chunk, float* preds_host,
                 int preds_capacity_rows);
-/* parity/debug export of the last step: "fc_out" [T, fc_d_model] (Conformer output), "tf_out" [T, tf_d_model] */
+/* stacked launch chains run so far, the session steps inside them, their rows (batching statistics of the benchmark) */
+int wlk_sf_stats(wlk_sortformer* m, uint64_t* stacked_steps, uint64_t* session_steps, uint64_t* rows);
+/* parity/debug export of the last step (its first session): "fc_out" [T, fc_d_model] (Conformer output), "tf_out" [T, tf_d_model] */
 int wlk_sf_export(wlk_sortformer* m, const char* what, float* host, uint64_t capacity, uint64_t* n_written);
 int wlk_sf_destroy(wlk_sortformer* m);
 
@@ -309,7 +312,9 @@ int wlk_diag_env_refresh(void);
 /* c[m,n] = epilogue(a[m,k](row stride lda, a_floats floats in total) . w[n,k]^T + bias); flags:
  * 1 = exact-erf GELU, 2 = add r[m, ldr] after the activation, 4 = scale columns < scale_cols,
  * 8 = ReLU, 16 = Swish.  force_gemv: 0 = shape-based choice among the MFMA kernels, 1 = weight-streaming kernel
- * (m <= 8), 2 = the k-wave MFMA kernel of under-filled grids (four waves split K of one 32x32 tile) */
+ * (m <= 8), 2 = the k-wave MFMA kernel of under-filled grids (four waves split K of one 32x32 tile), 3 = the 64x64
+ * kernel, 4 = the one-tile-per-CU k-pipe kernel, 5 = the "kp" family of the stacked Sortformer steps (k-wave tiles below
+ * 512 rows, k-pipe tiles from there on: one per-element arithmetic, so a row's result does not depend on m) */
 int wlk_diag_linear(const float* a, int64_t lda, int64_t a_floats, const float* w, const float* bias,
                     const float* r, int64_t ldr, int m, int n, int k, int flags, float scale, int scale_cols,
                     int force_gemv, float* c);

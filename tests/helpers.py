@@ -1,6 +1,7 @@
 """Shared plumbing for the parity tests: golden fixtures, seeded inputs, oracle sessions."""
 import json
 import os
+import re
 from functools import lru_cache
 
 import numpy as np
@@ -172,6 +173,9 @@ def stream_audio(case_name):
     }
     if case_name.startswith("bench_base_30s_s"):
         return synth.to_pcm16_roundtrip(synth.speech_like(30.0, int(case_name.rsplit("_s", 1)[1])))
+    m = re.fullmatch(r"bench_large-v3_(\d+)s_s(\d+)", case_name)
+    if m:
+        return synth.to_pcm16_roundtrip(synth.speech_like(float(m.group(1)), int(m.group(2))))
     return table[case_name]()
 
 

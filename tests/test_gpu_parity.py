@@ -408,7 +408,9 @@ def make_hip_processor(model_name, cfg_over, seed=0):
 # GPU-only goldens: the exact workload bench.py times (base.en, 30 s, seeds 0..7) and config 3 at FULL depth
 # (large-v3: 32 + 32 layers, 1280 wide, 128 mels) - generated by the unmodified reference on CPU, too slow for the
 # CPU oracle suite (tests/test_oracle_golden.py replays a prefix of one of them)
-GPU_STREAMS = [f"bench_base_30s_s{i}" for i in range(8)] + ["large_v3_2s"]
+# bench_large-v3_30s_s8 (round 6): config 3 at BASELINE.json's own length, the audio seed on which the seeded large-v3 weights
+# commit 47 words over 9 calls (scripts/lv3_seed_scan.py) - what bench.py's `large_v3` leg times
+GPU_STREAMS = [f"bench_base_30s_s{i}" for i in range(8)] + ["large_v3_2s", "bench_large-v3_30s_s8"]
 
 
 def with_teacher(make, teacher):

@@ -92,10 +92,54 @@ def test_network_matches_oracle_two_blocks(shallow, n_ctx, n_feat):
     assert ref.std() > 0.01
 
 
+def _vp(a):
+    import ctypes as C
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.mark.parametrize("N,K,flags", [(2048, 512, 16), (512, 2048, 2), (1536, 512, 0), (512, 512, 2), (1024, 512, 0), (192, 768, 2),
+                                       (192, 512, 0), (256, 256, 8), (576, 192, 4), (768, 192, 8), (192, 192, 2)])
+def test_kp_family_rows_do_not_depend_on_what_is_stacked_under_them(N, K, flags):
+    """Round 6: every projection of the Sortformer goes through launch_gemm_kp - 32 x 32 k-wave tiles below 512 rows,
+    one-tile-per-CU k-pipe tiles from there on, ONE per-element arithmetic (wave w sums k = 32 t + 8 w .. + 7 of every slab,
+    partials folded in wave order; K = 192: one wave walks K in order) - so the rows of one session come out bit for bit the
+    same alone (M = 291, 401, 37) and stacked with other sessions' rows (M = 2 392: a k-pipe tile).  Also against float64."""
+    lib = _lib.load()
+    rng = np.random.default_rng(N + K)
+    M = 2392
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    r = rng.standard_normal((M, N)).astype(np.float32)
+
+    def run(rows):
+        c = np.empty((rows, N), np.float32)
+        rc = lib.wlk_diag_linear(_vp(a), K, rows * K, _vp(w), _vp(bias), _vp(r) if flags & 2 else None, N, rows, N, K, flags,
+                                 0.5, N // 2, 5, _vp(c))
+        assert rc == 0, lib.wlk_diag_last_error()
+        return c
+
+    big = run(M)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
+    if flags & 4:
+        ref[:, : N // 2] *= 0.5
+    if flags & 8:
+        ref = np.maximum(ref, 0)
+    if flags & 16:
+        ref = ref / (1 + np.exp(-ref))
+    if flags & 2:
+        ref = ref + r
+    assert np.abs(big - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    for rows in (291, 401, 37, 600):
+        assert np.array_equal(run(rows).view(np.uint32), big[:rows].view(np.uint32)), (rows, N, K)
+
+
 def test_concurrent_steps_on_one_model_equal_serial_steps(shallow):
     """Round 5: a step runs in one of the model's workspaces on that workspace's stream, so sessions that share the model
-    (config 4) overlap instead of queueing behind one set of buffers.  Eight threads x five steps of different shapes on one
-    model: every result bit-identical to the same step run alone."""
+    (config 4) overlap instead of queueing behind one set of buffers.  Round 6: steps that wait for the model at the same time
+    run as ONE stacked launch chain (rows of up to eight sessions one after the other, ragged lengths, sessions without a
+    feature chunk among them).  Eight threads x five steps of different shapes on one model: every result bit-identical to
+    the same step run alone, and the steps did get stacked."""
     import threading
     dims, _tsd, m = shallow
     rng = np.random.default_rng(77)
@@ -108,6 +152,7 @@ def test_concurrent_steps_on_one_model_equal_serial_steps(shallow):
             ctx = (0.3 * np.random.default_rng(2000 * t + k).standard_normal((n_ctx, 512))).astype(np.float32) if n_ctx else None
             jobs.append((t, feats, ctx))
     serial = [m.step(f, c) for _t, f, c in jobs]
+    before = m.stats()
     got = [None] * len(jobs)
     errors = []
 
@@ -125,6 +170,43 @@ def test_concurrent_steps_on_one_model_equal_serial_steps(shallow):
     for (chunk_s, preds_s), (chunk_g, preds_g) in zip(serial, got):
         assert np.array_equal(chunk_s.view(np.uint32), chunk_g.view(np.uint32))
         assert np.array_equal(preds_s.view(np.uint32), preds_g.view(np.uint32))
+    after = m.stats()
+    steps, sessions = after["stacked_steps"] - before["stacked_steps"], after["session_steps"] - before["session_steps"]
+    assert sessions == len(jobs) and steps < sessions, (before, after)      # several sessions per launch chain
+
+
+def test_stacked_step_of_eight_sessions_equals_eight_steps_alone(full):
+    """Full depth (17 + 18 blocks), eight sessions released together so that they land in one or two stacked chains of
+    M ~ 2 400 rows (the k-pipe tiles), each with its own context length: activities and chunk embeddings bit-identical to
+    the sessions' steps alone, and <= 1e-4 from the torch oracle for one of them."""
+    import threading
+    dims, tsd, m = full
+    rng = np.random.default_rng(5)
+    jobs = []
+    for t in range(8):
+        n_ctx = int(rng.integers(200, 377))
+        jobs.append((logmel_like(np.random.default_rng(300 + t), 200), (0.3 * rng.standard_normal((n_ctx, 512))).astype(np.float32)))
+    serial = [m.step(f, c) for f, c in jobs]
+    before = m.stats()
+    gate = threading.Barrier(8)
+    got = [None] * 8
+
+    def worker(t):
+        gate.wait()
+        got[t] = m.step(*jobs[t])
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    [th.start() for th in threads]
+    [th.join() for th in threads]
+    after = m.stats()
+    assert after["stacked_steps"] - before["stacked_steps"] <= 4, (before, after)
+    for (cs, ps), (cg, pg) in zip(serial, got):
+        assert np.array_equal(cs.view(np.uint32), cg.view(np.uint32)) and np.array_equal(ps.view(np.uint32), pg.view(np.uint32))
+    od = oracle_dims(dims)
+    feats, ctx = jobs[3]
+    embs = torch.cat([torch.from_numpy(ctx), so.pre_encode(tsd, od, torch.from_numpy(feats))], 0)
+    with torch.no_grad():
+        ref = so.forward_embeddings(tsd, od, embs).numpy()
+    assert np.abs(got[3][1] - ref).max() <= 1e-4
 
 
 def test_capacity_and_argument_errors(shallow):

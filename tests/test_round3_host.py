@@ -77,6 +77,12 @@ def test_bench_golden_names_and_parity_gate():
     for seed in range(8):
         assert helpers.golden_exists(f"stream_bench_base_30s_s{seed}.json")
     assert helpers.golden_exists("stream_bench_large-v3_10s_s0.json")
+    # config 3 as the default bench line times it (round 6): 30 s, the word-committing audio seed
+    assert bench.golden_stem(ns(model="large-v3", seconds=float(bench.LV3_SECONDS))) == "stream_bench_large-v3_30s"
+    assert helpers.golden_exists(f"stream_bench_large-v3_{bench.LV3_SECONDS}s_s{bench.LV3_SEED}.json")
+    g = helpers.golden_json(f"stream_bench_large-v3_{bench.LV3_SECONDS}s_s{bench.LV3_SEED}.json")
+    words = [len(ev["tokens"]) for ev in g["events"] if ev["kind"] == "chunk"]
+    assert len(words) == 60 and sum(words) >= 40 and sum(words[:bench.LV3_CPU_CHUNKS]) >= 1      # the CPU leg's prefix commits words
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "sys.exit(3)" in src and '"parity_ok": parity_ok' in src
     # the log tally counts swallowed calls as errors

@@ -210,6 +210,9 @@ struct GemmArgs {
         __builtin_amdgcn_sched_barrier(0); /* nothing of the kernel is scheduled between the loads and their one wait */    \
     } while (0)
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag);
+// the "kp" family: one per-element arithmetic (the k-pipe kernel's) for every tile, so stacked rows keep their solo results
+void launch_gemm_kp(const LaunchCtx& ctx, const GemmArgs& g, const char* tag);
+bool gemm_kp_takes_kpipe(int M, int N, int K);
 bool gemm_takes_kwave(int M, int N, int K);
 bool gemm_takes_ksplit(int M, int N, int K);  // ... for the one-tile-per-CU k-split kernel (encoder-sized problems)   // launch_gemm's shape rule for the k-wave kernel (under-filled grids)
 // weight-streaming path for M <= 8 rows (decode steps); same contract as launch_gemm
@@ -445,13 +448,26 @@ void launch_kv_gather(const LaunchCtx& ctx, const float* src, float* dst, const 
 
 // ---- sortformer.hip (a12: streaming Sortformer diarizer network) -----------------------------------
 // sub-sampling stem, channels-last: feats [T][F] -> conv0 (1->C, 3x3 s2 p1, ReLU) -> [T1][F1][C]
-void launch_sf_conv0(const LaunchCtx& ctx, const float* in, const float* w, const float* b, float* out, int T, int F,
-                     int C);
-// depthwise 3x3 s2 p1 over [Ti][Fi][C] -> [To][Fo][C]; w tap-major [9][C]
-void launch_sf_dwconv2d(const LaunchCtx& ctx, const float* in, const float* w, const float* b, float* out, int Ti,
-                        int Fi, int C);
 inline int sf_sub_len(int n) { return (n - 1) / 2 + 1; }   // floor((n + 2 - 3) / 2) + 1
 void launch_sf_scale_copy(const LaunchCtx& ctx, const float* src, float* dst, long n, float scale);
+constexpr int kSfMaxSegments = 8;     // sessions per stacked Sortformer step
+struct SfSegments {                    // by-value table of a stacked step: session s owns rows [start[s], start[s] + len[s])
+    int n = 0;
+    int start[kSfMaxSegments] = {0}, len[kSfMaxSegments] = {0};
+};
+// one stride-2 stage of the sub-sampling stem over stacked sessions: session s reads frames [in_start, in_start + in_len) and
+// writes its sf_sub_len(in_len) output frames from out_start on
+struct SfConvSegs {
+    int n = 0, in_total = 0, out_total = 0;
+    int in_start[kSfMaxSegments] = {0}, in_len[kSfMaxSegments] = {0}, out_start[kSfMaxSegments] = {0};
+};
+SfConvSegs sf_conv_segs_next(const SfConvSegs& prev);
+void launch_sf_conv0(const LaunchCtx& ctx, const float* in, const float* w, const float* b, float* out, const SfConvSegs& sg, int F,
+                     int C);
+void launch_sf_dwconv2d(const LaunchCtx& ctx, const float* in, const float* w, const float* b, float* out, const SfConvSegs& sg,
+                        int Fi, int C);
+void launch_sf_assemble(const LaunchCtx& ctx, const float* ctx_rows, const float* chunk_rows, float* x, const SfSegments& rows,
+                        const SfSegments& chunks, int d, float scale);
 struct SfAttnArgs {
     const float* q = nullptr; const float* k = nullptr; const float* v = nullptr;
     long ldq = 0, ldk = 0, ldv = 0;
@@ -461,13 +477,17 @@ struct SfAttnArgs {
     // relative-position term (Conformer RelPositionMultiHeadAttention): score += (q + v_bias) . pos[pos_row0 - i + j]
     const float* pos = nullptr; long ldp = 0; int pos_row0 = 0;
     const float* bias_u = nullptr; const float* bias_v = nullptr;
+    // stacked sessions (sortformer_api.hip): n_seg > 0 -> rows [seg_start[s], seg_start[s] + seg_T[s]) of q / k / v / out are
+    // session s's sequence (grid.z = n_seg, T above = the longest); attention never crosses a segment
+    int n_seg = 0;
+    int seg_start[kSfMaxSegments] = {0}, seg_T[kSfMaxSegments] = {0};
 };
 constexpr int kSfMaxFrames = 512;      // attention rows the score buffer in LDS is sized for
 void launch_sf_attention(const LaunchCtx& ctx, const SfAttnArgs& a);
 // Conformer convolution module core: GLU over [T][2d] -> depthwise conv1d (k taps, same padding) -> BatchNorm (eval)
 // -> Swish -> [T][d]; w tap-major [k][d]
 void launch_sf_glu_dwconv(const LaunchCtx& ctx, const float* in, const float* w, const float* b, const float* bn_mean,
-                          const float* bn_invstd, const float* bn_w, const float* bn_b, float* out, int T, int d,
+                          const float* bn_invstd, const float* bn_w, const float* bn_b, float* out, const SfSegments& rows, int d,
                           int taps);
 // relu -> Linear(d,d)+relu -> Linear(d,n_spk) -> sigmoid
 void launch_sf_head(const LaunchCtx& ctx, const float* x, const float* w1, const float* b1, const float* w2,

@@ -234,6 +234,13 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
 // run-to-run identical).  4x the waves per output tile, no cross-workgroup reduction, same k-permutation
 // and buffer-load pipeline as the main kernel.
 // -------------------------------------------------------------------------------------------------
+//
+// KP (round 6): the k-PIPE kernel's partition of K instead - wave w multiplies k = 32 t + 8 w .. 8 w + 7 of every 32-deep
+// slab t (chunk pair w of each of the slab's four sub-tiles) in slab order, same in-wave order of the eight values, same
+// wave-order fold, same epilogue expression.  Every output element is then bit for bit what gemm_nt_f32_kpipe_kernel
+// computes for it with ANY tile: a row keeps its arithmetic when other rows are stacked under it and the launch moves
+// from 32 x 32 tiles to one-tile-per-CU tiles (launch_gemm_kp; the Sortformer's stacked sessions).  K % 128 == 0.
+template <bool KP>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kwave_kernel(GemmArgs g) {
     WLK_PIN_GEMM_ARGS(g);
     constexpr int KW = 4, SLAB = BK * KW, SUB = 32 * LDS_LD;
@@ -286,12 +293,12 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kwave_kernel(GemmArgs g) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const int frag = wave * SUB + (lane & 31) * LDS_LD + (lane >> 5) * 4;
+    const int frag = (KP ? wave * 8 : wave * SUB) + (lane & 31) * LDS_LD + (lane >> 5) * 4;
     auto mma = [&](int buf) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][frag + s * 8]);
-            const float4 b4 = *reinterpret_cast<const float4*>(&Ws[buf][frag + s * 8]);
+            const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][frag + s * (KP ? SUB : 8)]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&Ws[buf][frag + s * (KP ? SUB : 8)]);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
@@ -1297,7 +1304,7 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
                 default: throw std::invalid_argument("gemm: fused LayerNorm needs K = 384 / 512 / 768 / 1024 / 1280");
             }
         } else {
-            hipLaunchKernelGGL(gemm_nt_f32_kwave_kernel, dim3((unsigned)tiles32), dim3(256), 0, ctx.stream, g);
+            hipLaunchKernelGGL(gemm_nt_f32_kwave_kernel<false>, dim3((unsigned)tiles32), dim3(256), 0, ctx.stream, g);
         }
     } else if (tiles64 >= 64) {
         const int tiles_m = (g.M + 63) / 64;
@@ -1307,6 +1314,38 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
         const int tiles_m = (g.M + 31) / 32;
         const int blocks = tiles_m >= 8 ? 8 * ((tiles_m + 3) / 4) * ((tiles_n + 1) / 2) : tiles_m * tiles_n;
         hipLaunchKernelGGL((gemm_nt_f32_kernel<32, 64>), dim3(blocks), dim3(128), 0, ctx.stream, g);
+    }
+    WLK_HIP(hipGetLastError());
+}
+
+// The "kp" family (round 6): kernels that share ONE per-element arithmetic - the k-pipe's - whatever their tile, so that
+// the choice may depend on M without a row's result depending on it.  The streaming Sortformer runs one session's step
+// (M <= 401 rows: 32 x 32 tiles, four waves split K) or several sessions' steps stacked (M up to 8 x 401: one tile per CU)
+// through here, and a session's activities are bit for bit those of its step alone (tests/test_gpu_sortformer.py).
+//   K % 128 == 0, K >= 256:  M >= 512 -> gemm_nt_f32_kpipe_kernel with the tile ksplit_tile picks (any N, any K of that form);
+//                            else     -> gemm_nt_f32_kwave_kernel<true>;
+//   other K (the Transformer half's K = 192): the plain tiled kernel - one wave per 32 x 32 tile walks K in order, the
+//                            same for its 64 x 64 and 32 x 64 workgroup shapes.
+bool gemm_kp_takes_kpipe(int M, int N, int K) { return K % 128 == 0 && K >= 256 && M >= 512 && ksplit_tile(M, N, K, true).tm != 0; }
+void launch_gemm_kp(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
+    if (g.M <= 0 || g.N <= 0) return;
+    if (g.K % 4 != 0 || g.lda % 4 != 0) throw std::invalid_argument("gemm: K and lda must be multiples of 4");
+    if (g.batch > 0 || g.kcache || g.ln_gamma) throw std::invalid_argument("gemm (kp family): plain projections only");
+    if (g.K % 128 != 0 || g.K < 256) {
+        GemmArgs p = g;
+        p.force_kernel = 3;
+        launch_gemm(ctx, p, tag);
+        return;
+    }
+    if ((((long)g.M - 1) * g.lda + g.K) * 4 >= (1L << 31) || (long)g.N * g.K * 4 >= (1L << 31))
+        throw std::invalid_argument("gemm: operand larger than 2 GiB");
+    KernelScope ks(ctx, tag, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    if (gemm_kp_takes_kpipe(g.M, g.N, g.K)) {
+        const KSplitTile kt = ksplit_tile(g.M, g.N, g.K, true);
+        if (!dispatch_kpipe(ctx, g, kt.tm, kt.tn, kt.ks)) throw std::logic_error("gemm: k-pipe tile without an instantiation");
+    } else {
+        const long tiles32 = (long)((g.N + 31) / 32) * ((g.M + 31) / 32);
+        hipLaunchKernelGGL(gemm_nt_f32_kwave_kernel<true>, dim3((unsigned)tiles32), dim3(256), 0, ctx.stream, g);
     }
     WLK_HIP(hipGetLastError());
 }

@@ -8,25 +8,50 @@
 //
 // Sequences here are short (<= 188 + 188 + ~26 frames) and the work per chunk is ~20 GFLOP of GEMM, so these
 // helper kernels are written for low launch latency and coalesced channel-last access, not for peak rates.
+#include <atomic>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace wlk {
 
+// ---- stacked sessions -------------------------------------------------------------------------------------------
+// A stacked step (sortformer_api.hip) lays the sessions' rows one after the other; the kernels that look along the time
+// axis find their session in a by-value table.  Constant indices only: a runtime index into kernel arguments would put
+// the whole argument struct into scratch (measured on the GEMMs in round 2), so lookups are select chains over <= 8 slots.
+__device__ __forceinline__ int seg_find(const int (&start)[kSfMaxSegments], int n, int v) {     // largest s < n with start[s] <= v
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < kSfMaxSegments; ++i)
+        if (i < n && v >= start[i]) s = i;
+    return s;
+}
+__device__ __forceinline__ int seg_pick(const int (&a)[kSfMaxSegments], int s) {
+    int v = a[0];
+#pragma unroll
+    for (int i = 1; i < kSfMaxSegments; ++i) v = s == i ? a[i] : v;
+    return v;
+}
+
 // ---- ConvSubsampling('dw_striding') ----------------------------------------------------------------
 // conv0: Conv2d(1, C, 3, stride 2, padding 1) + ReLU.  One workgroup per output position, one thread per
 // channel: the 9 input taps are wave-uniform, the output is channels-last so that the following pointwise
-// convolutions are GEMMs over [positions, C].
+// convolutions are GEMMs over [positions, C].  Session s: input frames [in_start, in_start + in_len), output frames from
+// out_start on.
 __global__ __launch_bounds__(256) void sf_conv0_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                       const float* __restrict__ b, float* __restrict__ out, int T,
+                                                       const float* __restrict__ b, float* __restrict__ out, SfConvSegs sg,
                                                        int F, int F1, int C) {
-    const int pos = blockIdx.x, t1 = pos / F1, f1 = pos - t1 * F1;
+    const int pos = blockIdx.x, tg = pos / F1, f1 = pos - tg * F1;
+    const int s = seg_find(sg.out_start, sg.n, tg);
+    const int t1 = tg - seg_pick(sg.out_start, s), T = seg_pick(sg.in_len, s);
+    const float* src = in + (long)seg_pick(sg.in_start, s) * F;
     float x[9];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int tt = 2 * t1 - 1 + ky, ff = 2 * f1 - 1 + kx;
-            x[ky * 3 + kx] = (tt >= 0 && tt < T && ff >= 0 && ff < F) ? in[(long)tt * F + ff] : 0.f;
+            x[ky * 3 + kx] = (tt >= 0 && tt < T && ff >= 0 && ff < F) ? src[(long)tt * F + ff] : 0.f;
         }
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float acc = 0.f;
@@ -36,19 +61,23 @@ __global__ __launch_bounds__(256) void sf_conv0_kernel(const float* __restrict__
     }
 }
 
-void launch_sf_conv0(const LaunchCtx& ctx, const float* in, const float* w, const float* b, float* out, int T, int F,
-                     int C) {
-    const int T1 = sf_sub_len(T), F1 = sf_sub_len(F);
-    KernelScope ks(ctx, "sf_conv0", 18.0 * T1 * F1 * C, 4.0 * ((double)T * F + (double)T1 * F1 * C));
-    hipLaunchKernelGGL(sf_conv0_kernel, dim3(T1 * F1), dim3(C < 256 ? C : 256), 0, ctx.stream, in, w, b, out, T, F, F1, C);
+void launch_sf_conv0(const LaunchCtx& ctx, const float* in, const float* w, const float* b, float* out, const SfConvSegs& sg,
+                     int F, int C) {
+    const int F1 = sf_sub_len(F);
+    if (sg.out_total <= 0) return;
+    KernelScope ks(ctx, "sf_conv0", 18.0 * sg.out_total * F1 * C, 4.0 * ((double)sg.in_total * F + (double)sg.out_total * F1 * C));
+    hipLaunchKernelGGL(sf_conv0_kernel, dim3(sg.out_total * F1), dim3(C < 256 ? C : 256), 0, ctx.stream, in, w, b, out, sg, F, F1, C);
     WLK_HIP(hipGetLastError());
 }
 
 // depthwise Conv2d(C, C, 3, stride 2, padding 1, groups C) on channels-last data; weights tap-major [9][C]
 __global__ __launch_bounds__(256) void sf_dwconv2d_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                          const float* __restrict__ b, float* __restrict__ out, int Ti,
+                                                          const float* __restrict__ b, float* __restrict__ out, SfConvSegs sg,
                                                           int Fi, int Fo, int C) {
-    const int pos = blockIdx.x, to = pos / Fo, fo = pos - to * Fo;
+    const int pos = blockIdx.x, tg = pos / Fo, fo = pos - tg * Fo;
+    const int s = seg_find(sg.out_start, sg.n, tg);
+    const int to = tg - seg_pick(sg.out_start, s), Ti = seg_pick(sg.in_len, s);
+    const float* src = in + (long)seg_pick(sg.in_start, s) * Fi * C;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float acc = 0.f;
 #pragma unroll
@@ -57,32 +86,64 @@ __global__ __launch_bounds__(256) void sf_dwconv2d_kernel(const float* __restric
             for (int kx = 0; kx < 3; ++kx) {
                 const int tt = 2 * to - 1 + ky, ff = 2 * fo - 1 + kx;
                 const bool ok = tt >= 0 && tt < Ti && ff >= 0 && ff < Fi;
-                const float x = ok ? in[((long)tt * Fi + ff) * C + c] : 0.f;
+                const float x = ok ? src[((long)tt * Fi + ff) * C + c] : 0.f;
                 acc = fmaf(x, w[(ky * 3 + kx) * C + c], acc);
             }
         out[(long)pos * C + c] = acc + b[c];
     }
 }
 
-void launch_sf_dwconv2d(const LaunchCtx& ctx, const float* in, const float* w, const float* b, float* out, int Ti,
+void launch_sf_dwconv2d(const LaunchCtx& ctx, const float* in, const float* w, const float* b, float* out, const SfConvSegs& sg,
                         int Fi, int C) {
-    const int To = sf_sub_len(Ti), Fo = sf_sub_len(Fi);
-    KernelScope ks(ctx, "sf_dwconv2d", 18.0 * To * Fo * C, 4.0 * ((double)Ti * Fi * C + (double)To * Fo * C));
-    hipLaunchKernelGGL(sf_dwconv2d_kernel, dim3(To * Fo), dim3(C < 256 ? C : 256), 0, ctx.stream, in, w, b, out, Ti, Fi,
+    const int Fo = sf_sub_len(Fi);
+    if (sg.out_total <= 0) return;
+    KernelScope ks(ctx, "sf_dwconv2d", 18.0 * sg.out_total * Fo * C, 4.0 * ((double)sg.in_total * Fi * C + (double)sg.out_total * Fo * C));
+    hipLaunchKernelGGL(sf_dwconv2d_kernel, dim3(sg.out_total * Fo), dim3(C < 256 ? C : 256), 0, ctx.stream, in, w, b, out, sg, Fi,
                        Fo, C);
     WLK_HIP(hipGetLastError());
 }
 
-__global__ void sf_scale_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long n, float scale) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        dst[i] = src[i] * scale;
+SfConvSegs sf_conv_segs_next(const SfConvSegs& prev) {      // the table of the next stride-2 stage: its input is prev's output
+    SfConvSegs nx;
+    nx.n = prev.n;
+    int off = 0;
+    for (int s = 0; s < prev.n; ++s) {
+        const int len = (s + 1 < prev.n ? prev.out_start[s + 1] : prev.out_total) - prev.out_start[s];
+        nx.in_start[s] = prev.out_start[s];
+        nx.in_len[s] = len;
+        nx.out_start[s] = off;
+        off += sf_sub_len(len);
+    }
+    nx.in_total = prev.out_total;
+    nx.out_total = off;
+    return nx;
 }
 
-void launch_sf_scale_copy(const LaunchCtx& ctx, const float* src, float* dst, long n, float scale) {
-    if (n <= 0) return;
-    KernelScope ks(ctx, "sf_scale_copy", 0.0, 8.0 * n);
-    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(sf_scale_copy_kernel, dim3(blocks), dim3(256), 0, ctx.stream, src, dst, n, scale);
+// x[row] = (the session's context row | its chunk row) * scale: the encoder input [speaker cache | FIFO | chunk] of every
+// session of the step, assembled from the uploaded context rows (already at their stacked positions) and the stem's
+// output (chunk rows of all sessions one after the other) - ConformerEncoder's xscaling rides along
+__global__ __launch_bounds__(256) void sf_assemble_kernel(const float* __restrict__ ctx_rows, const float* __restrict__ chunk_rows,
+                                                          float* __restrict__ x, SfSegments rows, SfSegments chunks, int d4,
+                                                          float scale) {
+    const int r = blockIdx.x;
+    const int s = seg_find(rows.start, rows.n, r);
+    const int t = r - seg_pick(rows.start, s), n_chunk = seg_pick(chunks.len, s), n_ctx = seg_pick(rows.len, s) - n_chunk;
+    const float4* src = reinterpret_cast<const float4*>(t < n_ctx ? ctx_rows + (long)r * d4 * 4
+                                                                  : chunk_rows + (long)(seg_pick(chunks.start, s) + t - n_ctx) * d4 * 4);
+    float4* dst = reinterpret_cast<float4*>(x + (long)r * d4 * 4);
+    for (int c = threadIdx.x; c < d4; c += blockDim.x) {
+        const float4 v = src[c];
+        dst[c] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+    }
+}
+
+void launch_sf_assemble(const LaunchCtx& ctx, const float* ctx_rows, const float* chunk_rows, float* x, const SfSegments& rows,
+                        const SfSegments& chunks, int d, float scale) {
+    const int R = rows.n > 0 ? rows.start[rows.n - 1] + rows.len[rows.n - 1] : 0;
+    if (R <= 0) return;
+    if (d % 4) throw std::invalid_argument("sortformer: model width must be a multiple of 4");
+    KernelScope ks(ctx, "sf_assemble", 0.0, 8.0 * R * d);
+    hipLaunchKernelGGL(sf_assemble_kernel, dim3(R), dim3(128), 0, ctx.stream, ctx_rows, chunk_rows, x, rows, chunks, d / 4, scale);
     WLK_HIP(hipGetLastError());
 }
 
@@ -180,15 +241,206 @@ __global__ __launch_bounds__(256) void sf_attention_kernel(SfAttnArgs a) {
     if (grp == 0 && live && i_raw < a.T) a.out[(long)i * a.ldo + h * dh + d] = acc * inv;
 }
 
+// ---- the same attention on the matrix cores (round 6) ------------------------------------------------------------
+// The one-wave-per-query kernel above re-reads every key (and position) row once per query row: 2 T^2 dh floats per head
+// out of L2 (T = 291: 350 MB per launch, 33 us of a 4.5 ms chunk x 35 launches = a quarter of the chunk).  Here a workgroup
+// owns (segment, head, 16 queries) and its four waves split the KEY tiles, v_mfma_f32_16x16x4_f32 throughout:
+//   1. G^T[r'][n] = pos[rbase + r'] . (q_n + v)  for r' in [0, T + 15), rbase = pos_row0 - i0 - 15: every relative-position
+//      product the 16 queries can need, ONCE (the rel_shift of matrix_bd is then the index map j - n + 15 into that row);
+//   2. S^T[j][n] = k_j . (q_n + u)  per 16-key tile (each lane owns a query column: acc[r] = key 4 (lane >> 4) + r);
+//   3. softmax over s = (S + G shifted) * scale per query row, exponentials left un-normalised in LDS, 1 / sum aside;
+//   4. O^T[d][n] += V^T[d][j] P^T[j][n] per key tile, the four waves' partial outputs added in wave order through LDS.
+// K / pos / V fragments come straight from global memory (64 contiguous bytes per row and instruction), Q and P from LDS
+// with row strides = 4 mod 32 floats (conflict-free b128 / b32 reads).  The d (and key) values of one MFMA step are
+// {16 c + 4 g + e : g = 0..3} - a permutation of the dot product's terms, the same one in A and B.
+// 291 frames, dh 64: 152 workgroups x ~930 MFMAs.
+template <int DHP>
+__global__ __launch_bounds__(256) void sf_attention_mfma_kernel(SfAttnArgs a) {
+    constexpr int C = DHP / 16;                 // 16-wide d chunks (AC / G products) = 16-row d tiles (P.V)
+    constexpr int QLD = DHP + 4;                // LDS row stride of the query tiles
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    const int seg = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * 16;
+    const int base = a.n_seg > 0 ? a.seg_start[seg] : 0, T = a.n_seg > 0 ? a.seg_T[seg] : a.T;
+    if (i0 >= T) return;
+    const int dh = a.dh;
+    const int n_kt = (T + 15) >> 4, n_rt = (T + 15 + 15) >> 4;
+    const int SP = n_kt * 16 + 4, GP = n_rt * 16 + 4;
+    float* qu = smem;                           // [16][QLD]
+    float* qv = qu + 16 * QLD;                  // [16][QLD]
+    float* inv = qv + 16 * QLD;                 // [16]
+    float* S = inv + 16;                        // [16][SP]
+    float* G = S + 16 * SP;                     // [16][GP] (pos only); later the P.V merge buffer [3][C][4][64]
+    const float* qbase = a.q + (long)base * a.ldq + h * dh;
+    const float* kbase = a.k + (long)base * a.ldk + h * dh;
+    const float* vbase = a.v + (long)base * a.ldv + h * dh;
+    for (int e = threadIdx.x; e < 16 * DHP; e += 256) {
+        const int r = e / DHP, d = e - r * DHP;
+        float q = 0.f, u = 0.f, v = 0.f;
+        if (d < dh) {
+            q = qbase[(long)min(i0 + r, T - 1) * a.ldq + d];
+            if (a.bias_u) u = a.bias_u[h * dh + d];
+            if (a.bias_v) v = a.bias_v[h * dh + d];
+        }
+        qu[r * QLD + d] = q + u;
+        qv[r * QLD + d] = q + v;
+    }
+    __syncthreads();
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    // B fragments of this lane's query: d = 16 c + 4 g + {0..3}
+    float4 bu[C], bv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        bu[c] = *reinterpret_cast<const float4*>(qu + n * QLD + 16 * c + 4 * g);
+        bv[c] = *reinterpret_cast<const float4*>(qv + n * QLD + 16 * c + 4 * g);
+    }
+    const bool dlive[4] = {4 * g < dh, 16 + 4 * g < dh, 32 + 4 * g < dh, 48 + 4 * g < dh};   // whole float4 inside the head
+    // one 16-row tile of `rows` (row index clamped into [0, hi]) times the query fragments -> acc
+    auto tile_dot = [&](const float* rows, long ld, int row, int hi, const float4 (&b)[C]) {
+        const float* p = rows + (long)min(max(row, 0), hi) * ld + 4 * g;
+        float4 x[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) x[c] = dlive[c] ? *reinterpret_cast<const float4*>(p + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[c].x, b[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[c].y, b[c].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[c].z, b[c].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[c].w, b[c].w, acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    if (a.pos) {
+        const int rbase = a.pos_row0 - i0 - 15;
+        const float* pbase = a.pos + h * dh;
+        for (int rt = wave; rt < n_rt; rt += 4) {
+            // A row m = lane & 15 of the tile; rows past the table are clamped (their products are never read)
+            const f32x4 acc = tile_dot(pbase, a.ldp, rbase + rt * 16 + n, 2 * a.pos_row0, bv);
+            *reinterpret_cast<float4*>(G + n * GP + rt * 16 + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+    for (int kt = wave; kt < n_kt; kt += 4) {
+        const f32x4 acc = tile_dot(kbase, a.ldk, kt * 16 + n, T - 1, bu);
+        *reinterpret_cast<float4*>(S + n * SP + kt * 16 + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    __syncthreads();
+    // softmax of the four query rows of this wave
+#pragma unroll 1
+    for (int rq = 0; rq < 4; ++rq) {
+        const int r = 4 * wave + rq;
+        float* srow = S + r * SP;
+        const float* grow = G + r * GP + 15 - r;
+        float mx = -INFINITY;
+        for (int j = lane; j < T; j += 64) {
+            const float s = (a.pos ? srow[j] + grow[j] : srow[j]) * a.scale;
+            srow[j] = s;
+            mx = fmaxf(mx, s);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        float sum = 0.f;
+        for (int j = lane; j < n_kt * 16; j += 64) {
+            const float e = j < T ? expf(srow[j] - mx) : 0.f;
+            srow[j] = e;
+            sum += e;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        if (lane == 0) inv[r] = 1.0f / sum;
+    }
+    __syncthreads();
+    // O^T[d][n]: A = V^T (row m = d, k = key), B = P^T; one MFMA step takes keys {16 kt + 4 g + e}
+    f32x4 o[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = wave; kt < n_kt; kt += 4) {
+        const float4 p4 = *reinterpret_cast<const float4*>(S + n * SP + kt * 16 + 4 * g);
+        const float pe[4] = {p4.x, p4.y, p4.z, p4.w};
+        float vv[4][C];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* vr = vbase + (long)min(kt * 16 + 4 * g + e, T - 1) * a.ldv;
+#pragma unroll
+            for (int c = 0; c < C; ++c) vv[e][c] = 16 * c + n < dh ? vr[16 * c + n] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < C; ++c) o[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[e][c], pe[e], o[c], 0, 0, 0);
+    }
+    float* red = G;                              // [3][C][4][64]: the scores' G is dead by now
+    if (wave > 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(((wave - 1) * C + c) * 4 + r) * 64 + lane] = o[c][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[c][r] += red[((w * C + c) * 4 + r) * 64 + lane];
+    if (i0 + n < T) {
+        const float sc = inv[n];
+        float* orow = a.out + (long)(base + i0 + n) * a.ldo + h * dh;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            if (16 * c + 4 * g < dh)      // dh is a multiple of 4: the whole float4 is inside the head
+                *reinterpret_cast<float4*>(orow + 16 * c + 4 * g) = make_float4(o[c][0] * sc, o[c][1] * sc, o[c][2] * sc, o[c][3] * sc);
+    }
+}
+
+static size_t sf_attention_mfma_lds(int T, int dhp, bool pos) {
+    const int n_kt = (T + 15) / 16, n_rt = (T + 30) / 16;
+    const size_t g_floats = std::max<size_t>(pos ? 16 * (size_t)(n_rt * 16 + 4) : 0, 3 * (size_t)(dhp / 16) * 4 * 64);
+    return (2 * 16 * (size_t)(dhp + 4) + 16 + 16 * (size_t)(n_kt * 16 + 4) + g_floats) * sizeof(float);
+}
+
 void launch_sf_attention(const LaunchCtx& ctx, const SfAttnArgs& a) {
     if (a.T <= 0) return;
     if (a.T > kSfMaxFrames) throw std::invalid_argument("sortformer attention: sequence longer than the LDS score buffer");
     if (a.dh % 4 != 0 || a.dh > 64 || a.dh < 4) throw std::invalid_argument("sortformer attention: unsupported head width");
-    const double per = (a.pos ? 6.0 : 4.0) * a.T * a.T * a.dh * a.n_head;
-    KernelScope ks(ctx, a.pos ? "sf_relpos_attention" : "sf_attention", per, 16.0 * a.T * a.n_head * a.dh);
-    const dim3 grid((a.T + 3) / 4, a.n_head);
-    if (a.dh <= 32) hipLaunchKernelGGL((sf_attention_kernel<32>), grid, dim3(256), 0, ctx.stream, a);
-    else hipLaunchKernelGGL((sf_attention_kernel<64>), grid, dim3(256), 0, ctx.stream, a);
+    if (a.n_seg < 0 || a.n_seg > kSfMaxSegments) throw std::invalid_argument("sortformer attention: too many segments");
+    double tsq = 0.0, tsum = 0.0;
+    if (a.n_seg > 0) {
+        for (int s = 0; s < a.n_seg; ++s) {
+            if (a.seg_T[s] < 1 || a.seg_T[s] > a.T) throw std::invalid_argument("sortformer attention: bad segment length");
+            tsq += (double)a.seg_T[s] * a.seg_T[s];
+            tsum += a.seg_T[s];
+        }
+    } else {
+        tsq = (double)a.T * a.T;
+        tsum = a.T;
+    }
+    const double per = (a.pos ? 6.0 : 4.0) * tsq * a.dh * a.n_head;
+    KernelScope ks(ctx, a.pos ? "sf_relpos_attention" : "sf_attention", per, 16.0 * tsum * a.n_head * a.dh);
+    // WLK_SF_ATTN=valu: the round-1 kernel (one wave per query row) - A/B switch; it does not take stacked sessions
+    static const bool valu = [] { const char* e = getenv("WLK_SF_ATTN"); return e && e[0] == 'v'; }();
+    if (valu && a.n_seg == 0) {
+        const dim3 grid((a.T + 3) / 4, a.n_head);
+        if (a.dh <= 32) hipLaunchKernelGGL((sf_attention_kernel<32>), grid, dim3(256), 0, ctx.stream, a);
+        else hipLaunchKernelGGL((sf_attention_kernel<64>), grid, dim3(256), 0, ctx.stream, a);
+        WLK_HIP(hipGetLastError());
+        return;
+    }
+    const int dhp = a.dh <= 32 ? 32 : 64;
+    const size_t lds = sf_attention_mfma_lds(a.T, dhp, a.pos != nullptr);
+    static std::atomic<uint64_t> configured{0};     // per device: more than 64 KiB of dynamic LDS has to be asked for
+    int dev = 0;
+    WLK_HIP(hipGetDevice(&dev));
+    if (!(configured.load(std::memory_order_acquire) >> (dev & 63) & 1)) {
+        const int cap = (int)sf_attention_mfma_lds(kSfMaxFrames, 64, true);
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_attention_mfma_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_attention_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        configured.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+    const dim3 grid((a.T + 15) / 16, a.n_head, std::max(a.n_seg, 1));
+    if (dhp == 32) hipLaunchKernelGGL((sf_attention_mfma_kernel<32>), grid, dim3(256), lds, ctx.stream, a);
+    else hipLaunchKernelGGL((sf_attention_mfma_kernel<64>), grid, dim3(256), lds, ctx.stream, a);
     WLK_HIP(hipGetLastError());
 }
 
@@ -197,30 +449,34 @@ __global__ __launch_bounds__(256) void sf_glu_dwconv_kernel(const float* __restr
                                                             const float* __restrict__ b, const float* __restrict__ bn_mean,
                                                             const float* __restrict__ bn_invstd,
                                                             const float* __restrict__ bn_w, const float* __restrict__ bn_b,
-                                                            float* __restrict__ out, int T, int d, int taps) {
-    const int t = blockIdx.x, c = blockIdx.y * blockDim.x + threadIdx.x;
+                                                            float* __restrict__ out, SfSegments rows, int d, int taps) {
+    const int r = blockIdx.x, c = blockIdx.y * blockDim.x + threadIdx.x;
     if (c >= d) return;
+    const int s = seg_find(rows.start, rows.n, r);
+    const int lo = seg_pick(rows.start, s), T = seg_pick(rows.len, s), t = r - lo;      // the taps stay inside the session
+    const float* src = in + (long)lo * 2 * d;
     const int half = (taps - 1) / 2;
     float acc = 0.f;
     for (int k = 0; k < taps; ++k) {
         const int tt = t + k - half;
         if (tt < 0 || tt >= T) continue;
-        const float x = in[(long)tt * 2 * d + c], gate = in[(long)tt * 2 * d + d + c];
+        const float x = src[(long)tt * 2 * d + c], gate = src[(long)tt * 2 * d + d + c];
         const float glu = x * (1.0f / (1.0f + expf(-gate)));
         acc = fmaf(glu, w[k * d + c], acc);
     }
     acc += b[c];
     const float y = (acc - bn_mean[c]) * bn_invstd[c] * bn_w[c] + bn_b[c];
-    out[(long)t * d + c] = y / (1.0f + expf(-y));
+    out[(long)r * d + c] = y / (1.0f + expf(-y));
 }
 
 void launch_sf_glu_dwconv(const LaunchCtx& ctx, const float* in, const float* w, const float* b, const float* bn_mean,
-                          const float* bn_invstd, const float* bn_w, const float* bn_b, float* out, int T, int d,
+                          const float* bn_invstd, const float* bn_w, const float* bn_b, float* out, const SfSegments& rows, int d,
                           int taps) {
-    if (T <= 0) return;
-    KernelScope ks(ctx, "sf_glu_dwconv", 2.0 * taps * T * d, 12.0 * T * d);
-    hipLaunchKernelGGL(sf_glu_dwconv_kernel, dim3(T, (d + 255) / 256), dim3(256), 0, ctx.stream, in, w, b, bn_mean,
-                       bn_invstd, bn_w, bn_b, out, T, d, taps);
+    const int R = rows.n > 0 ? rows.start[rows.n - 1] + rows.len[rows.n - 1] : 0;
+    if (R <= 0) return;
+    KernelScope ks(ctx, "sf_glu_dwconv", 2.0 * taps * R * d, 12.0 * R * d);
+    hipLaunchKernelGGL(sf_glu_dwconv_kernel, dim3(R, (d + 255) / 256), dim3(256), 0, ctx.stream, in, w, b, bn_mean,
+                       bn_invstd, bn_w, bn_b, out, rows, d, taps);
     WLK_HIP(hipGetLastError());
 }
 

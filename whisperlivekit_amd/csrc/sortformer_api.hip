@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <condition_variable>
@@ -120,6 +121,20 @@ struct SfTfLayer {
 
 using namespace wlk;
 
+// One caller's step on its way through the model: inputs and outputs in PINNED host memory (the caller copies its numpy
+// rows in and out itself, in parallel with other callers; the lane's copies are then truly asynchronous).
+struct SfRequest {
+    float* feats = nullptr;     // [max_feat_frames][n_mels]
+    float* ctx = nullptr;       // [max_frames][d]
+    float* chunk = nullptr;     // [max chunk rows][d]      (out)
+    float* preds = nullptr;     // [max_frames][n_spk]      (out)
+    int n_feat = 0, n_ctx = 0, Tc = 0, T = 0;
+    bool in_use = false, queued = false, done = false;
+    int rc = WLK_OK;
+    std::string err;
+    uint64_t ticket = 0;
+};
+
 struct wlk_sortformer {
     wlk_sf_dims D{};
     int device = 0;
@@ -131,27 +146,47 @@ struct wlk_sortformer {
     std::mutex mu;
     std::vector<SfFcLayer> fc;
     std::vector<SfTfLayer> tf;
-    // Workspaces: one step runs in one of them, on its own stream - sessions that share the model (config 4: eight
-    // diarizer sessions per GPU) no longer queue behind ONE set of buffers (round 5: their p50 per chunk was the queue, not
-    // the GPU).  A step takes the lowest free workspace, so a single caller always lands in workspace 0 (what wlk_sf_export
-    // reads when no other step ran since).  WLK_SF_WORKSPACES=n (default 4, 1 = the round-4 behaviour).
-    struct Workspace {
+    // Lanes (round 6; round 5 called them workspaces): one lane runs one STACKED step at a time on its own stream - the
+    // steps of up to `max_batch` sessions that were waiting when the lane became free, rows one after the other
+    // ([speaker cache | FIFO | chunk] of session 0, then of session 1, ...), ONE launch chain for all of them.  Shared
+    // weights are read once per chain instead of once per session, the GEMMs see M = sum of the sessions' frames (the
+    // one-tile-per-CU kernels' home turf instead of 32 x 32 tiles), attention / depthwise convolution stay inside their
+    // session by a by-value segment table.  Every kernel's per-row arithmetic is independent of what is stacked around
+    // the row (launch_gemm_kp), so a session's result is bit for bit its step alone.  There is no gather window: a free
+    // lane takes whatever is queued (work-conserving, like the ASR engine's encode lane).
+    // WLK_SF_WORKSPACES = lanes (default 2), WLK_SF_BATCH = sessions per stacked step (default 8, 1 = round-5 behaviour).
+    struct Lane {
         hipStream_t stream = nullptr;
-        float *feats = nullptr, *ca = nullptr, *cb = nullptr, *emb_raw = nullptr, *x = nullptr, *xn = nullptr, *wide = nullptr,
-              *qkv = nullptr, *att = nullptr, *tx = nullptr, *ty = nullptr, *tqkv = nullptr, *tatt = nullptr, *th = nullptr,
-              *preds = nullptr;
-        int last_T = 0;
+        float *feats = nullptr, *ca = nullptr, *cb = nullptr, *ctxbuf = nullptr, *chunk_tmp = nullptr, *x = nullptr, *xn = nullptr,
+              *wide = nullptr, *qkv = nullptr, *att = nullptr, *tx = nullptr, *ty = nullptr, *tqkv = nullptr, *tatt = nullptr,
+              *th = nullptr, *preds = nullptr;
+        int last_T = 0;                  // rows of the FIRST session of the lane's most recent step (exports)
         bool busy = false;
     };
-    std::vector<Workspace> ws;
-    std::condition_variable ws_free;
-    int last_ws = 0;                      // the workspace of the most recent step (exports)
+    std::vector<Lane> ws;
+    std::vector<SfRequest> slots;
+    std::deque<int> queue;                // slot indices waiting for a lane, FIFO
+    std::condition_variable cv;
+    uint64_t next_ticket = 0;
+    int max_batch = 8;
+    int last_ws = 0;                      // the lane of the most recent step (exports)
+    uint64_t n_steps = 0, n_sessions = 0, n_rows = 0;     // stacked steps run / session steps in them / rows in them
     float* pos_full = nullptr;            // read-only after finalize
     std::vector<float*> owned;
+    std::vector<float*> pinned;
     const float* P(const std::string& n) const {
         auto it = index.find(n);
         if (it == index.end()) throw std::invalid_argument("unknown packed tensor " + n);
         return arena + it->second->offset;
+    }
+    ~wlk_sortformer() {                  // also the clean-up of a wlk_sf_create that threw half-way
+        (void)hipSetDevice(device);
+        for (float* p : owned)
+            if (p) (void)hipFree(p);
+        for (float* p : pinned)
+            if (p) (void)hipHostFree(p);
+        for (auto& w : ws)
+            if (w.stream) (void)hipStreamDestroy(w.stream);
     }
 };
 
@@ -163,20 +198,31 @@ static float* sf_alloc(wlk_sortformer* m, size_t n) {
     return p;
 }
 
+// every projection of the network: the "kp" kernel family - one per-element arithmetic whatever M is (gemm_f32.hip)
 static void sf_linear(const LaunchCtx& c, const float* A, long lda, const float* W, const float* b, float* C, long ldc,
                       int M, int N, int K, int flags, const float* R, long ldr, const char* tag, float scale = 1.f,
                       int scale_cols = 0) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.bias = b; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.flags = flags; g.R = R; g.ldr = ldr; g.scale = scale; g.scale_cols = scale_cols;
-    launch_linear(c, g, tag);
+    launch_gemm_kp(c, g, tag);
 }
 
-// the network over w_->emb_raw[0:T] -> w_->preds[0:T] of one workspace
-static void sf_network(wlk_sortformer* m, wlk_sortformer::Workspace* w_, const LaunchCtx& c, int T) {
+static void sf_set_segments(SfAttnArgs& a, const SfSegments& rows) {
+    a.n_seg = rows.n;
+    a.T = 0;
+    for (int s = 0; s < rows.n; ++s) {
+        a.seg_start[s] = rows.start[s];
+        a.seg_T[s] = rows.len[s];
+        a.T = std::max(a.T, rows.len[s]);
+    }
+}
+
+// the network over w_->x (already scaled) -> w_->preds, rows = the stacked sessions' [start, len) ranges
+static void sf_network(wlk_sortformer* m, wlk_sortformer::Lane* w_, const LaunchCtx& c, const SfSegments& rows) {
     const wlk_sf_dims& D = m->D;
     const int d = D.fc_d_model, ff = D.fc_ff, dh = d / D.fc_heads, L = D.max_frames;
-    launch_sf_scale_copy(c, w_->emb_raw, w_->x, (long)T * d, D.xscale);
+    const int T = rows.start[rows.n - 1] + rows.len[rows.n - 1];          // stacked rows
     for (int l = 0; l < D.fc_layers; ++l) {
         const SfFcLayer& w = m->fc[l];
         // x += 0.5 * FF1(LN(x))   (the 0.5 is folded into ff1b at pack time: exact, a power of two)
@@ -188,15 +234,16 @@ static void sf_network(wlk_sortformer* m, wlk_sortformer::Workspace* w_, const L
         sf_linear(c, w_->xn, d, w.qkv_w, w.qkv_b, w_->qkv, 3 * d, T, 3 * d, d, 0, nullptr, 0, "sf_qkv");
         SfAttnArgs a;
         a.q = w_->qkv; a.k = w_->qkv + d; a.v = w_->qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
-        a.out = w_->att; a.ldo = d; a.T = T; a.n_head = D.fc_heads; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
+        a.out = w_->att; a.ldo = d; a.n_head = D.fc_heads; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
         a.pos = m->pos_full + (size_t)l * (2 * L - 1) * d; a.ldp = d; a.pos_row0 = L - 1;
         a.bias_u = w.bias_u; a.bias_v = w.bias_v;
+        sf_set_segments(a, rows);
         launch_sf_attention(c, a);
         sf_linear(c, w_->att, d, w.out_w, w.out_b, w_->x, d, T, d, d, kGemmResidual, w_->x, d, "sf_att_out");
         // x += Conv(LN(x))
         launch_layernorm(c, w_->x, d, w.ln_conv_w, w.ln_conv_b, w_->xn, d, T, d, "sf_ln");
         sf_linear(c, w_->xn, d, w.pw1_w, w.pw1_b, w_->wide, 2 * d, T, 2 * d, d, 0, nullptr, 0, "sf_conv_pw1");
-        launch_sf_glu_dwconv(c, w_->wide, w.dw_w, w.dw_b, w.bn_mean, w.bn_invstd, w.bn_w, w.bn_b, w_->att, T, d, D.conv_kernel);
+        launch_sf_glu_dwconv(c, w_->wide, w.dw_w, w.dw_b, w.bn_mean, w.bn_invstd, w.bn_w, w.bn_b, w_->att, rows, d, D.conv_kernel);
         sf_linear(c, w_->att, d, w.pw2_w, w.pw2_b, w_->x, d, T, d, d, kGemmResidual, w_->x, d, "sf_conv_pw2");
         // x += 0.5 * FF2(LN(x)); x = LN_out(x)
         launch_layernorm(c, w_->x, d, w.ln_ff2_w, w.ln_ff2_b, w_->xn, d, T, d, "sf_ln");
@@ -213,7 +260,8 @@ static void sf_network(wlk_sortformer* m, wlk_sortformer::Workspace* w_, const L
                   qk_scale, 2 * dt);
         SfAttnArgs a;
         a.q = w_->tqkv; a.k = w_->tqkv + dt; a.v = w_->tqkv + 2 * dt; a.ldq = a.ldk = a.ldv = 3 * dt;
-        a.out = w_->tatt; a.ldo = dt; a.T = T; a.n_head = D.tf_heads; a.dh = dht; a.scale = 1.f;
+        a.out = w_->tatt; a.ldo = dt; a.n_head = D.tf_heads; a.dh = dht; a.scale = 1.f;
+        sf_set_segments(a, rows);
         launch_sf_attention(c, a);
         sf_linear(c, w_->tatt, dt, w.out_w, w.out_b, w_->ty, dt, T, dt, dt, kGemmResidual, w_->tx, dt, "sf_tf_out");
         launch_layernorm(c, w_->ty, dt, w.ln1_w, w.ln1_b, w_->tx, dt, T, dt, "sf_ln");
@@ -223,6 +271,65 @@ static void sf_network(wlk_sortformer* m, wlk_sortformer::Workspace* w_, const L
     }
     launch_sf_head(c, w_->tx, m->P("head.h.w"), m->P("head.h.b"), m->P("head.s.w"), m->P("head.s.b"), w_->preds, T, dt,
                    D.n_spk);
+}
+
+// One stacked step on lane `w_`: the requests in `batch` (slot indices, <= max_batch).  Everything is enqueued on the
+// lane's stream - uploads from the requests' pinned blocks, the stem over all feature chunks, the network over all rows,
+// the read-backs into the pinned blocks - and the stream is synchronised once.
+static void sf_run_batch(wlk_sortformer* m, wlk_sortformer::Lane* w_, const std::vector<int>& batch) {
+    const wlk_sf_dims& D = m->D;
+    const int d = D.fc_d_model, C = D.sub_channels, nb = (int)batch.size();
+    LaunchCtx c{w_->stream, nullptr};
+    SfSegments rows, chunks;
+    SfConvSegs s0;
+    rows.n = chunks.n = nb;
+    int r0 = 0, c0 = 0, f0 = 0, t0 = 0;
+    for (int b = 0; b < nb; ++b) {
+        SfRequest& q = m->slots[batch[b]];
+        rows.start[b] = r0; rows.len[b] = q.T;
+        chunks.start[b] = c0; chunks.len[b] = q.Tc;
+        if (q.n_ctx > 0)
+            WLK_HIP(hipMemcpyAsync(w_->ctxbuf + (size_t)r0 * d, q.ctx, (size_t)q.n_ctx * d * sizeof(float), hipMemcpyHostToDevice, w_->stream));
+        if (q.n_feat > 0) {
+            WLK_HIP(hipMemcpyAsync(w_->feats + (size_t)f0 * D.n_mels, q.feats, (size_t)q.n_feat * D.n_mels * sizeof(float),
+                                   hipMemcpyHostToDevice, w_->stream));
+            s0.in_start[s0.n] = f0; s0.in_len[s0.n] = q.n_feat; s0.out_start[s0.n] = t0;
+            ++s0.n;
+            f0 += q.n_feat;
+            t0 += sf_sub_len(q.n_feat);
+        }
+        r0 += q.T;
+        c0 += q.Tc;
+    }
+    s0.in_total = f0; s0.out_total = t0;
+    if (s0.n > 0) {
+        // ConvSubsampling.forward (dw_striding): conv0+ReLU, 2 x (depthwise s2, pointwise, ReLU), Linear - the feature
+        // chunks of all sessions one after the other along the time axis (a session without features has no rows here)
+        const int F1 = sf_sub_len(D.n_mels), F2 = sf_sub_len(F1), F3 = sf_sub_len(F2);
+        const SfConvSegs s1 = sf_conv_segs_next(s0), s2 = sf_conv_segs_next(s1);
+        launch_sf_conv0(c, w_->feats, m->P("pre.conv0.w"), m->P("pre.conv0.b"), w_->ca, s0, D.n_mels, C);
+        launch_sf_dwconv2d(c, w_->ca, m->P("pre.dw1.w"), m->P("pre.dw1.b"), w_->cb, s1, F1, C);
+        sf_linear(c, w_->cb, C, m->P("pre.pw1.w"), m->P("pre.pw1.b"), w_->ca, C, s1.out_total * F2, C, C, kGemmRelu, nullptr, 0, "sf_pre_pw");
+        launch_sf_dwconv2d(c, w_->ca, m->P("pre.dw2.w"), m->P("pre.dw2.b"), w_->cb, s2, F2, C);
+        sf_linear(c, w_->cb, C, m->P("pre.pw2.w"), m->P("pre.pw2.b"), w_->ca, C, s2.out_total * F3, C, C, kGemmRelu, nullptr, 0, "sf_pre_pw");
+        if (s2.out_total != c0) throw std::logic_error("sortformer: chunk row count out of step with the stem");
+        sf_linear(c, w_->ca, (long)F3 * C, m->P("pre.out.w"), m->P("pre.out.b"), w_->chunk_tmp, d, c0, d, F3 * C, 0, nullptr, 0, "sf_pre_out");
+        for (int b = 0; b < nb; ++b) {
+            SfRequest& q = m->slots[batch[b]];
+            if (q.Tc > 0)
+                WLK_HIP(hipMemcpyAsync(q.chunk, w_->chunk_tmp + (size_t)chunks.start[b] * d, (size_t)q.Tc * d * sizeof(float),
+                                       hipMemcpyDeviceToHost, w_->stream));
+        }
+    }
+    launch_sf_assemble(c, w_->ctxbuf, w_->chunk_tmp, w_->x, rows, chunks, d, D.xscale);
+    sf_network(m, w_, c, rows);
+    w_->last_T = rows.len[0];
+    for (int b = 0; b < nb; ++b) {
+        SfRequest& q = m->slots[batch[b]];
+        WLK_HIP(hipMemcpyAsync(q.preds, w_->preds + (size_t)rows.start[b] * D.n_spk, (size_t)q.T * D.n_spk * sizeof(float),
+                               hipMemcpyDeviceToHost, w_->stream));
+    }
+    WLK_HIP(hipStreamSynchronize(w_->stream));
 }
 }  // namespace wlk
 
@@ -278,8 +385,10 @@ int wlk_sf_create(const wlk_sf_dims* dims, int device, wlk_sortformer** out) {
         const size_t L = D.max_frames, d = D.fc_d_model, dt = D.tf_d_model, C = D.sub_channels;
         const size_t T1 = sf_sub_len(D.max_feat_frames), F1 = sf_sub_len(D.n_mels);
         m->pos_full = sf_alloc(p, (size_t)std::max(D.fc_layers, 1) * (2 * L - 1) * d);
-        int n_ws = 4;
-        if (const char* e = std::getenv("WLK_SF_WORKSPACES")) n_ws = std::max(1, std::min(16, std::atoi(e)));
+        int n_ws = 2;
+        if (const char* e = std::getenv("WLK_SF_WORKSPACES")) n_ws = std::max(1, std::min(8, std::atoi(e)));
+        if (const char* e = std::getenv("WLK_SF_BATCH")) m->max_batch = std::max(1, std::min(kSfMaxSegments, std::atoi(e)));
+        const size_t B = m->max_batch, R = B * L;          // sessions / rows of a stacked step
         // a diarizer step is a chain of small kernels that shares the GPU with ASR sessions' chip-filling encoder kernels
         // (config 4): WLK_SF_PRIORITY=hi puts its streams ahead of them in the dispatcher.  Measured a loss (ASR -20 %,
         // diarizer p95 worse: profiles/r05l_ab_sortformer_stream_priority.txt); default: normal priority
@@ -291,21 +400,36 @@ int wlk_sf_create(const wlk_sf_dims* dims, int device, wlk_sortformer** out) {
             if (pe && pe[0] == 'h') WLK_HIP(hipStreamCreateWithPriority(&w.stream, hipStreamNonBlocking, prio_hi));
             else if (pe && pe[0] == 'l') WLK_HIP(hipStreamCreateWithPriority(&w.stream, hipStreamNonBlocking, prio_lo));
             else WLK_HIP(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
-            w.feats = sf_alloc(p, (size_t)D.max_feat_frames * D.n_mels);
-            w.ca = sf_alloc(p, T1 * F1 * C);
-            w.cb = sf_alloc(p, T1 * F1 * C);
-            w.emb_raw = sf_alloc(p, L * d);
-            w.x = sf_alloc(p, L * d);
-            w.xn = sf_alloc(p, L * d);
-            w.wide = sf_alloc(p, L * std::max<size_t>(D.fc_ff, 2 * d));
-            w.qkv = sf_alloc(p, L * 3 * d);
-            w.att = sf_alloc(p, L * d);
-            w.tx = sf_alloc(p, L * dt);
-            w.ty = sf_alloc(p, L * dt);
-            w.tqkv = sf_alloc(p, L * 3 * dt);
-            w.tatt = sf_alloc(p, L * dt);
-            w.th = sf_alloc(p, L * D.tf_inner);
-            w.preds = sf_alloc(p, L * D.n_spk);
+            w.feats = sf_alloc(p, B * (size_t)D.max_feat_frames * D.n_mels);
+            w.ca = sf_alloc(p, B * T1 * F1 * C);
+            w.cb = sf_alloc(p, B * T1 * F1 * C);
+            w.ctxbuf = sf_alloc(p, R * d);
+            w.chunk_tmp = sf_alloc(p, B * (T1 / 4 + 2) * d);
+            w.x = sf_alloc(p, R * d);
+            w.xn = sf_alloc(p, R * d);
+            w.wide = sf_alloc(p, R * std::max<size_t>(D.fc_ff, 2 * d));
+            w.qkv = sf_alloc(p, R * 3 * d);
+            w.att = sf_alloc(p, R * d);
+            w.tx = sf_alloc(p, R * dt);
+            w.ty = sf_alloc(p, R * dt);
+            w.tqkv = sf_alloc(p, R * 3 * dt);
+            w.tatt = sf_alloc(p, R * dt);
+            w.th = sf_alloc(p, R * D.tf_inner);
+            w.preds = sf_alloc(p, R * D.n_spk);
+        }
+        // request slots: pinned blocks the callers fill and drain themselves (enough for every lane's batch plus the next one's)
+        auto pin = [&](size_t n) {
+            float* h = nullptr;
+            WLK_HIP(hipHostMalloc(reinterpret_cast<void**>(&h), n * sizeof(float), hipHostMallocDefault));
+            p->pinned.push_back(h);
+            return h;
+        };
+        m->slots.resize((size_t)(n_ws + 1) * B);
+        for (auto& q : m->slots) {
+            q.feats = pin((size_t)D.max_feat_frames * D.n_mels);
+            q.ctx = pin(L * d);
+            q.chunk = pin((T1 / 4 + 2) * d);
+            q.preds = pin(L * D.n_spk);
         }
         *out = m.release();
         return WLK_OK;
@@ -370,9 +494,12 @@ int wlk_sf_finalize(wlk_sortformer* m) {
         // [max_frames - T, max_frames + T - 1) of it (RelPositionalEncoding centres its table the same way)
         LaunchCtx c{m->ws[0].stream, nullptr};
         const int d = D.fc_d_model, rows = 2 * D.max_frames - 1;
-        for (int l = 0; l < D.fc_layers; ++l)
-            sf_linear(c, m->P("pos.table"), d, m->fc[l].pos_w, nullptr, m->pos_full + (size_t)l * rows * d, d, rows, d, d, 0,
-                      nullptr, 0, "sf_pos");
+        for (int l = 0; l < D.fc_layers; ++l) {
+            GemmArgs g;
+            g.A = m->P("pos.table"); g.lda = d; g.W = m->fc[l].pos_w; g.C = m->pos_full + (size_t)l * rows * d; g.ldc = d;
+            g.M = rows; g.N = d; g.K = d;
+            launch_linear(c, g, "sf_pos");
+        }
         WLK_HIP(hipStreamSynchronize(m->ws[0].stream));
         m->finalized = true;
         return WLK_OK;
@@ -388,9 +515,8 @@ int wlk_sf_step(wlk_sortformer* m, const float* feats_host, int n_feat, const fl
         return sf_fail(WLK_ERR_ARG, "bad step arguments");
     if (n_feat > m->D.max_feat_frames) return sf_fail(WLK_ERR_CAPACITY, "feature chunk longer than max_feat_frames");
     return sf_guarded([&]() {
-        WLK_HIP(hipSetDevice(m->device));
         const wlk_sf_dims& D = m->D;
-        const int d = D.fc_d_model, C = D.sub_channels;
+        const int d = D.fc_d_model;
         int Tc = 0;
         if (n_feat > 0) Tc = sf_sub_len(sf_sub_len(sf_sub_len(n_feat)));
         const int T = n_ctx + Tc;
@@ -398,55 +524,114 @@ int wlk_sf_step(wlk_sortformer* m, const float* feats_host, int n_feat, const fl
         if (T < 1) return sf_fail(WLK_ERR_ARG, "empty step");
         if (T > D.max_frames) return sf_fail(WLK_ERR_CAPACITY, "sequence longer than max_frames");
         if (Tc > chunk_capacity_rows || T > preds_capacity_rows) return sf_fail(WLK_ERR_CAPACITY, "output buffer too small");
-        // the lowest free workspace (waits when all are busy); released on every way out
-        wlk_sortformer::Workspace* w_ = nullptr;
+        // 1. a request slot; the inputs go into its pinned blocks (this thread's own memcpy, outside the lock)
+        int me = -1;
         {
             std::unique_lock<std::mutex> lock(m->mu);
-            m->ws_free.wait(lock, [&] { for (auto& w : m->ws) if (!w.busy) return true; return false; });
-            for (auto& w : m->ws) if (!w.busy) { w_ = &w; break; }
-            w_->busy = true;
+            m->cv.wait(lock, [&] { for (auto& q : m->slots) if (!q.in_use) return true; return false; });
+            for (size_t i = 0; i < m->slots.size(); ++i)
+                if (!m->slots[i].in_use) { me = (int)i; break; }
+            m->slots[me].in_use = true;
         }
-        struct Release {
-            wlk_sortformer* m; wlk_sortformer::Workspace* w;
-            ~Release() {
-                { std::lock_guard<std::mutex> lock(m->mu); w->busy = false; m->last_ws = (int)(w - m->ws.data()); }
-                m->ws_free.notify_one();
+        SfRequest& mine = m->slots[me];
+        mine.n_feat = n_feat; mine.n_ctx = n_ctx; mine.Tc = Tc; mine.T = T;
+        mine.done = false; mine.rc = WLK_OK; mine.err.clear();
+        if (n_feat > 0) memcpy(mine.feats, feats_host, (size_t)n_feat * D.n_mels * sizeof(float));
+        if (n_ctx > 0) memcpy(mine.ctx, ctx_embs_host, (size_t)n_ctx * d * sizeof(float));
+        // 2. queue; whoever finds a free lane while requests wait runs the oldest ones as ONE stacked step (its own may or
+        //    may not be among them) - no dispatcher thread, no gather window
+        std::unique_lock<std::mutex> lock(m->mu);
+        mine.ticket = m->next_ticket++;
+        mine.queued = true;
+        m->queue.push_back(me);
+        while (!mine.done) {
+            wlk_sortformer::Lane* lane = nullptr;
+            if (!m->queue.empty())
+                for (auto& w : m->ws)
+                    if (!w.busy) { lane = &w; break; }
+            if (!lane) {
+                m->cv.wait(lock);
+                continue;
             }
-        } release{m, w_};
-        LaunchCtx c{w_->stream, nullptr};
-        if (n_ctx > 0)
-            WLK_HIP(hipMemcpyAsync(w_->emb_raw, ctx_embs_host, (size_t)n_ctx * d * sizeof(float), hipMemcpyHostToDevice, w_->stream));
-        if (n_feat > 0) {
-            // ConvSubsampling.forward (dw_striding): conv0+ReLU, 2 x (depthwise s2, pointwise, ReLU), Linear
-            WLK_HIP(hipMemcpyAsync(w_->feats, feats_host, (size_t)n_feat * D.n_mels * sizeof(float), hipMemcpyHostToDevice, w_->stream));
-            const int T1 = sf_sub_len(n_feat), F1 = sf_sub_len(D.n_mels), T2 = sf_sub_len(T1), F2 = sf_sub_len(F1),
-                      T3 = sf_sub_len(T2), F3 = sf_sub_len(F2);
-            launch_sf_conv0(c, w_->feats, m->P("pre.conv0.w"), m->P("pre.conv0.b"), w_->ca, n_feat, D.n_mels, C);
-            launch_sf_dwconv2d(c, w_->ca, m->P("pre.dw1.w"), m->P("pre.dw1.b"), w_->cb, T1, F1, C);
-            sf_linear(c, w_->cb, C, m->P("pre.pw1.w"), m->P("pre.pw1.b"), w_->ca, C, T2 * F2, C, C, kGemmRelu, nullptr, 0, "sf_pre_pw");
-            launch_sf_dwconv2d(c, w_->ca, m->P("pre.dw2.w"), m->P("pre.dw2.b"), w_->cb, T2, F2, C);
-            sf_linear(c, w_->cb, C, m->P("pre.pw2.w"), m->P("pre.pw2.b"), w_->ca, C, T3 * F3, C, C, kGemmRelu, nullptr, 0, "sf_pre_pw");
-            sf_linear(c, w_->ca, (long)F3 * C, m->P("pre.out.w"), m->P("pre.out.b"), w_->emb_raw + (size_t)n_ctx * d, d, T3, d,
-                      F3 * C, 0, nullptr, 0, "sf_pre_out");
-            WLK_HIP(hipMemcpyAsync(chunk_embs_host, w_->emb_raw + (size_t)n_ctx * d, (size_t)Tc * d * sizeof(float),
-                                   hipMemcpyDeviceToHost, w_->stream));
+            std::vector<int> batch;
+            while (!m->queue.empty() && (int)batch.size() < m->max_batch) {
+                batch.push_back(m->queue.front());
+                m->queue.pop_front();
+            }
+            for (int i : batch) m->slots[i].queued = false;
+            lane->busy = true;
+            lock.unlock();
+            int rc = WLK_OK;
+            std::string err;
+            try {
+                WLK_HIP(hipSetDevice(m->device));
+                sf_run_batch(m, lane, batch);
+            } catch (const HipError& e) {
+                rc = WLK_ERR_HIP; err = e.what();
+                (void)hipStreamSynchronize(lane->stream);        // nothing of the failed chain may still write a slot
+            } catch (const std::invalid_argument& e) {
+                rc = WLK_ERR_ARG; err = e.what();
+                (void)hipStreamSynchronize(lane->stream);
+            } catch (const std::exception& e) {
+                rc = WLK_ERR_STATE; err = e.what();
+                (void)hipStreamSynchronize(lane->stream);
+            }
+            lock.lock();
+            lane->busy = false;
+            m->last_ws = (int)(lane - m->ws.data());
+            m->n_steps += 1;
+            m->n_sessions += batch.size();
+            for (int i : batch) {
+                m->n_rows += m->slots[i].T;
+                m->slots[i].rc = rc;
+                m->slots[i].err = err;
+                m->slots[i].done = true;
+            }
+            m->cv.notify_all();
         }
-        sf_network(m, w_, c, T);
-        w_->last_T = T;
-        WLK_HIP(hipMemcpyAsync(preds_host, w_->preds, (size_t)T * D.n_spk * sizeof(float), hipMemcpyDeviceToHost, w_->stream));
-        WLK_HIP(hipStreamSynchronize(w_->stream));
-        return WLK_OK;
+        lock.unlock();
+        // 3. results out of the pinned blocks, slot back
+        const int rc = mine.rc;
+        const std::string err = mine.err;
+        if (rc == WLK_OK) {
+            if (Tc > 0) memcpy(chunk_embs_host, mine.chunk, (size_t)Tc * d * sizeof(float));
+            memcpy(preds_host, mine.preds, (size_t)T * D.n_spk * sizeof(float));
+        }
+        {
+            std::lock_guard<std::mutex> g(m->mu);
+            mine.in_use = false;
+        }
+        m->cv.notify_all();
+        return rc == WLK_OK ? WLK_OK : sf_fail(rc, err);
     });
+}
+
+int wlk_sf_stats(wlk_sortformer* m, uint64_t* stacked_steps, uint64_t* session_steps, uint64_t* rows) {
+    if (!m) return sf_fail(WLK_ERR_ARG, "model is NULL");
+    std::lock_guard<std::mutex> lock(m->mu);
+    if (stacked_steps) *stacked_steps = m->n_steps;
+    if (session_steps) *session_steps = m->n_sessions;
+    if (rows) *rows = m->n_rows;
+    return WLK_OK;
 }
 
 int wlk_sf_export(wlk_sortformer* m, const char* what, float* host, uint64_t capacity, uint64_t* n_written) {
     if (!m || !what || !host) return sf_fail(WLK_ERR_ARG, "NULL argument");
     return sf_guarded([&]() {
-        std::lock_guard<std::mutex> lock(m->mu);
+        // the FIRST session's rows of the most recent step, read while no step runs on that lane (the lane is held for
+        // the duration of the copy: a concurrent caller's step waits or takes another lane)
+        std::unique_lock<std::mutex> lock(m->mu);
+        wlk_sortformer::Lane& w = m->ws[m->last_ws];
+        m->cv.wait(lock, [&] { return !w.busy; });
+        w.busy = true;
+        lock.unlock();
+        struct Release {
+            wlk_sortformer* m; wlk_sortformer::Lane* w;
+            ~Release() { { std::lock_guard<std::mutex> g(m->mu); w->busy = false; } m->cv.notify_all(); }
+        } release{m, &w};
         WLK_HIP(hipSetDevice(m->device));
         const float* src = nullptr;
         uint64_t n = 0;
-        const wlk_sortformer::Workspace& w = m->ws[m->last_ws];       // the most recent step's
         if (!strcmp(what, "fc_out")) { src = w.x; n = (uint64_t)w.last_T * m->D.fc_d_model; }
         else if (!strcmp(what, "tf_out")) { src = w.tx; n = (uint64_t)w.last_T * m->D.tf_d_model; }
         else return sf_fail(WLK_ERR_ARG, std::string("unknown export ") + what);
@@ -458,13 +643,7 @@ int wlk_sf_export(wlk_sortformer* m, const char* what, float* host, uint64_t cap
 }
 
 int wlk_sf_destroy(wlk_sortformer* m) {
-    if (!m) return WLK_OK;
-    (void)hipSetDevice(m->device);
-    for (float* p : m->owned)
-        if (p) (void)hipFree(p);
-    for (auto& w : m->ws)
-        if (w.stream) (void)hipStreamDestroy(w.stream);
-    delete m;
+    delete m;          // ~wlk_sortformer frees the arena, the lanes' buffers and streams, the pinned request blocks
     return WLK_OK;
 }
 

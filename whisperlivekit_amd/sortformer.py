@@ -370,8 +370,9 @@ def streaming_update(sp: SpkCacheParams, st: SortformerState, chunk: np.ndarray,
 # ---- the model handle --------------------------------------------------------------------------------------
 class HipSortformerModel:
     """Shared (per GPU) Sortformer network + feature extractor; implements ``diarization.SortformerBackend``.
-    Sessions keep their ``SortformerState`` on the host, so any number of streams share one handle; steps are
-    serialised inside the library (one workspace)."""
+    Sessions keep their ``SortformerState`` on the host, so any number of streams share one handle; steps of sessions
+    that wait for the model at the same time run as one stacked launch chain inside the library (bit-identical per
+    session to a step alone)."""
 
     def __init__(self, dims: SortformerDims, state_dict: Dict[str, np.ndarray], device: int = 0,
                  params: SortformerStreamingParams = SortformerStreamingParams(),
@@ -445,6 +446,13 @@ class HipSortformerModel:
         chunk, preds = self.step(features, ctx if ctx.shape[0] else None)
         sf = self.cache.subsampling_factor
         return streaming_update(self.cache, state, chunk, preds, round(left_offset / sf), math.ceil(right_offset / sf))
+
+    def stats(self) -> Dict[str, float]:
+        """Batching statistics of the model's lanes: stacked launch chains run, session steps inside them, mean sessions per chain."""
+        a, b, r = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _lib.check(self.lib.wlk_sf_stats(self._h, C.byref(a), C.byref(b), C.byref(r)))
+        return dict(stacked_steps=a.value, session_steps=b.value, rows=r.value,
+                    mean_sessions_per_step=round(b.value / a.value, 3) if a.value else None)
 
     def export(self, what: str) -> np.ndarray:
         width = {"fc_out": self.dims.fc_d_model, "tf_out": self.dims.tf_d_model}[what]
