@@ -277,6 +277,15 @@ int wlk_sf_finalize(wlk_sortformer* m);
 int wlk_sf_step(wlk_sortformer* m, const float* feats_host, int n_feat, const float* ctx_embs_host, int n_ctx,
                 float* chunk_embs_host, int chunk_capacity_rows, int* n_chunk, float* preds_host,
                 int preds_capacity_rows);
+/* The same step with its front end inside (what sortformer_backend.py:273-300 does in three calls): pcm_host [n_pcm] is the new
+ * audio chunk; its log-mel rows (n_pcm / hop + 1 of them, rows from valid_frames on zeroed - FilterbankFeatures' seq_len rule -
+ * unless valid_frames < 0) are computed by `mel`'s kernel on the step's own stream, placed behind prev_feats_host [n_prev, n_mels]
+ * (the rows the caller kept from its previous chunk, :279-283) and handed to the stem; feats_out_host receives the new rows
+ * (*n_feats_out of them) so the caller can keep them for its next chunk.  Bit-identical to wlk_melspec_run + wlk_sf_step. */
+int wlk_sf_step_pcm(wlk_sortformer* m, wlk_melspec* mel, const float* pcm_host, int n_pcm, int valid_frames,
+                    const float* prev_feats_host, int n_prev, float* feats_out_host, int feats_capacity_rows, int* n_feats_out,
+                    const float* ctx_embs_host, int n_ctx, float* chunk_embs_host, int chunk_capacity_rows, int* n_chunk,
+                    float* preds_host, int preds_capacity_rows);
 /* stacked launch chains run so far, the session steps inside them, their rows (batching statistics of the benchmark) */
 int wlk_sf_stats(wlk_sortformer* m, uint64_t* stacked_steps, uint64_t* session_steps, uint64_t* rows);
 /* parity/debug export of the last step (its first session): "fc_out" [T, fc_d_model] (Conformer output), "tf_out" [T, tf_d_model] */

@@ -209,6 +209,34 @@ def test_stacked_step_of_eight_sessions_equals_eight_steps_alone(full):
     assert np.abs(got[3][1] - ref).max() <= 1e-4
 
 
+def test_front_end_inside_the_step_equals_the_three_separate_calls(shallow):
+    """Round 6: wlk_sf_step_pcm computes the chunk's log-mel rows on the step's own stream, behind the rows kept from the previous
+    chunk (one launch chain, one synchronisation instead of extractor call + step).  A 6 s stream through
+    HipSortformerDiarizationOnline on the fused path and on the three-call path (features, concatenate, forward_streaming_step):
+    every chunk's activities, the kept feature rows and the streaming state bit-identical; so are the segments."""
+    dims, _tsd, m = shallow
+    audio = speech_like(6.0, 3).astype(np.float32)
+
+    class ThreeCalls:                      # the same model without the fused entry point
+        n_spk, params = m.n_spk, m.params
+        features, new_state, forward_streaming_step = m.features, m.new_state, m.forward_streaming_step
+
+    fused, plain = HipSortformerDiarizationOnline(m), HipSortformerDiarizationOnline(ThreeCalls())
+    for lo in range(0, len(audio) - 15999, 16000):
+        for o in (fused, plain):
+            o.insert_audio_chunk(audio[lo:lo + 16000])
+        sa, sb = fused.diarize_sync(), plain.diarize_sync()
+        assert [(x.speaker, x.start, x.end) for x in sa] == [(x.speaker, x.start, x.end) for x in sb]
+        assert np.array_equal(fused._previous_chunk_features.view(np.uint32), plain._previous_chunk_features.view(np.uint32))
+        assert fused._previous_chunk_features.shape == (101, 128) and not fused._previous_chunk_features[100].any()
+        assert np.array_equal(fused.total_preds.view(np.uint32), plain.total_preds.view(np.uint32))
+        for name in ("spkcache", "spkcache_preds", "fifo", "fifo_preds", "mean_sil_emb"):
+            assert np.array_equal(getattr(fused.streaming_state, name), getattr(plain.streaming_state, name)), name
+    assert fused.total_preds.shape[0] > 50
+    with pytest.raises(_lib.WlkError):      # an audio chunk longer than the step's buffer
+        m.step_pcm(np.zeros(64001, np.float32), None, None)
+
+
 def test_capacity_and_argument_errors(shallow):
     dims, _, m = shallow
     with pytest.raises(_lib.WlkError):
@@ -227,14 +255,15 @@ def test_full_depth_streaming_session_teacher_forced(full):
     dims, tsd, m = full
     od = oracle_dims(dims)
     steps = []
-    orig = m.step
+    orig = m.step_pcm
 
-    def recording_step(feats, ctx):
-        chunk, preds = orig(feats, ctx)
-        steps.append((feats.copy(), None if ctx is None else ctx.copy(), chunk.copy(), preds.copy()))
-        return chunk, preds
+    def recording_step(pcm, prev, ctx):          # the session's fused call: log-mel of the chunk + stem + network
+        feats, chunk, preds = orig(pcm, prev, ctx)
+        total = feats if prev is None else np.concatenate([prev, feats], axis=0)
+        steps.append((total.copy(), None if ctx is None else ctx.copy(), chunk.copy(), preds.copy()))
+        return feats, chunk, preds
 
-    m.step = recording_step
+    m.step_pcm = recording_step
     try:
         online = HipSortformerDiarizationOnline(m)
         audio = speech_like(18.0, seed=5)
@@ -243,7 +272,7 @@ def test_full_depth_streaming_session_teacher_forced(full):
             online.insert_audio_chunk(audio[i: i + 8000])
             segs += online.diarize_sync()
     finally:
-        m.step = orig
+        m.step_pcm = orig
     assert len(steps) == 18
     st = online.streaming_state
     assert st.spkcache_len == 188 and 0 < st.fifo_len <= 188

@@ -152,6 +152,7 @@ def _declare(lib: C.CDLL) -> None:
         "wlk_sf_upload": (cint, [p, C.c_char_p, p, u64]),
         "wlk_sf_finalize": (cint, [p]),
         "wlk_sf_step": (cint, [p, p, cint, p, cint, p, cint, C.POINTER(cint), p, cint]),
+        "wlk_sf_step_pcm": (cint, [p, p, p, cint, cint, p, cint, p, cint, C.POINTER(cint), p, cint, p, cint, C.POINTER(cint), p, cint]),
         "wlk_sf_stats": (cint, [p, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
         "wlk_sf_export": (cint, [p, C.c_char_p, p, u64, C.POINTER(u64)]),
         "wlk_sf_destroy": (cint, [p]),
@@ -229,7 +230,7 @@ EXPORTED_SYMBOLS = (
     "wlk_job_destroy", "wlk_export", "wlk_session_step_stats", "wlk_prof_begin",
     "wlk_prof_end", "wlk_melspec_create", "wlk_melspec_run", "wlk_melspec_destroy",
     "wlk_sf_arena_floats", "wlk_sf_tensor_lookup", "wlk_sf_tensor_name", "wlk_sf_create", "wlk_sf_upload",
-    "wlk_sf_finalize", "wlk_sf_step", "wlk_sf_stats", "wlk_sf_export", "wlk_sf_destroy",
+    "wlk_sf_finalize", "wlk_sf_step", "wlk_sf_step_pcm", "wlk_sf_stats", "wlk_sf_export", "wlk_sf_destroy",
     "wlk_vad_weights_floats", "wlk_vad_tensor_lookup", "wlk_vad_tensor_name", "wlk_vad_create", "wlk_vad_destroy",
     "wlk_vad_stream_create", "wlk_vad_stream_reset", "wlk_vad_stream_run", "wlk_vad_stream_state",
     "wlk_vad_stream_destroy",

@@ -1715,15 +1715,6 @@ int wlk_export(wlk_session* s, const char* what, float* host, uint64_t capacity,
 }
 
 // ---- diarization front end: stand-alone log-mel extractor --------------------------------------
-struct wlk_melspec {
-    int device = 0, n_fft = 0, win_length = 0, hop = 0, n_mels = 0, cap = 0;
-    float preemph = 0.f, log_guard = 0.f;
-    float *window = nullptr, *filters = nullptr, *audio = nullptr, *out = nullptr;
-    double* twiddle = nullptr;
-    int *lo = nullptr, *hi = nullptr;
-    hipStream_t stream = nullptr;
-    std::mutex mu;   // one device audio/out buffer and one stream: runs from different host threads are serialised
-};
 
 int wlk_melspec_create(int device, int n_fft, int win_length, int hop, int n_mels, const float* filters,
                        const float* window, float preemph, float log_guard, int max_samples, wlk_melspec** out) {

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <stdexcept>
+#include <mutex>
 #include <string>
 
 namespace wlk {
@@ -340,6 +341,19 @@ struct MelSpecArgs {
     float preemph, log_guard;
 };
 void launch_melspec(const LaunchCtx& ctx, const MelSpecArgs& a, int n_frames);
+}  // namespace wlk
+// the extractor handle of the C ABI (api.hip: wlk_melspec_*); sortformer_api.hip launches its kernel inside a stacked step
+// with the handle's read-only tables (window, twiddles, filterbank) and its own audio / output rows
+struct wlk_melspec {
+    int device = 0, n_fft = 0, win_length = 0, hop = 0, n_mels = 0, cap = 0;
+    float preemph = 0.f, log_guard = 0.f;
+    float *window = nullptr, *filters = nullptr, *audio = nullptr, *out = nullptr;
+    double* twiddle = nullptr;
+    int *lo = nullptr, *hi = nullptr;
+    hipStream_t stream = nullptr;
+    std::mutex mu;   // one device audio/out buffer and one stream: runs from different host threads are serialised
+};
+namespace wlk {
 
 // ---- attention.hip --------------------------------------------------------------------------
 // flash-style fp32-MFMA attention: q rows [Tq] against k/v rows [Tk], 64-wide heads, no mask

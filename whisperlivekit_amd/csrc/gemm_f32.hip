@@ -1326,6 +1326,27 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
 //                            else     -> gemm_nt_f32_kwave_kernel<true>;
 //   other K (the Transformer half's K = 192): the plain tiled kernel - one wave per 32 x 32 tile walks K in order, the
 //                            same for its 64 x 64 and 32 x 64 workgroup shapes.
+// the k-pipe tile of a kp-family launch (any tile gives the same bits; this is speed only)
+// Measured on MI355X for the Sortformer's shapes at the row counts stacked steps produce (scripts/kp_tile_probe.py,
+// profiles/r06_kp_tile_probe.txt): ksplit_tile's "rounds of 256 workgroups" model is right for M = 1500 and up to 25 % off
+// elsewhere (thin tiles run two or three workgroups per CU), so the shapes that matter carry their measured best tile.
+static KSplitTile kp_tile(int M, int N, int K) {
+    const int band = M < 900 ? 0 : M < 1800 ? 1 : M < 2800 ? 2 : 3;
+    struct Row { int n, k; int t[4][2]; };
+    static const Row rows[] = {
+        {2048, 512, {{3, 2}, {2, 1}, {2, 2}, {2, 1}}},    // feed-forward in
+        {512, 2048, {{2, 1}, {3, 1}, {3, 2}, {2, 4}}},    // feed-forward out
+        {1536, 512, {{3, 2}, {2, 2}, {2, 2}, {2, 2}}},    // q | k | v
+        {512, 512, {{2, 1}, {3, 1}, {3, 2}, {2, 4}}},     // attention out, pointwise conv 2
+        {1024, 512, {{3, 1}, {3, 2}, {2, 1}, {2, 1}}},    // pointwise conv 1
+        {192, 768, {{2, 1}, {2, 1}, {2, 1}, {3, 1}}},     // Transformer dense out
+        {192, 512, {{2, 1}, {2, 1}, {2, 1}, {3, 1}}},     // encoder projection
+    };
+    for (const Row& r : rows)
+        if (r.n == N && r.k == K) return KSplitTile{r.t[band][0], r.t[band][1], 104};
+    if (N == 256 && K == 256) return M < 4000 ? KSplitTile{2, 1, 104} : M < 9000 ? KSplitTile{2, 2, 104} : KSplitTile{2, 1, 104};   // stem pointwise
+    return ksplit_tile(M, N, K, true);
+}
 bool gemm_kp_takes_kpipe(int M, int N, int K) { return K % 128 == 0 && K >= 256 && M >= 512 && ksplit_tile(M, N, K, true).tm != 0; }
 void launch_gemm_kp(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (g.M <= 0 || g.N <= 0) return;
@@ -1341,7 +1362,8 @@ void launch_gemm_kp(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
         throw std::invalid_argument("gemm: operand larger than 2 GiB");
     KernelScope ks(ctx, tag, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
     if (gemm_kp_takes_kpipe(g.M, g.N, g.K)) {
-        const KSplitTile kt = ksplit_tile(g.M, g.N, g.K, true);
+        KSplitTile kt = kp_tile(g.M, g.N, g.K);
+        if (g.force_kernel >= 500) kt = KSplitTile{(g.force_kernel - 500) / 10, (g.force_kernel - 500) % 10, 104};   // tile probe
         if (!dispatch_kpipe(ctx, g, kt.tm, kt.tn, kt.ks)) throw std::logic_error("gemm: k-pipe tile without an instantiation");
     } else {
         const long tiles32 = (long)((g.N + 31) / 32) * ((g.M + 31) / 32);

@@ -124,7 +124,11 @@ using namespace wlk;
 // One caller's step on its way through the model: inputs and outputs in PINNED host memory (the caller copies its numpy
 // rows in and out itself, in parallel with other callers; the lane's copies are then truly asynchronous).
 struct SfRequest {
-    float* feats = nullptr;     // [max_feat_frames][n_mels]
+    float* feats = nullptr;     // [max_feat_frames][n_mels]: the features the stem sees; with a PCM chunk: [n_prev rows the caller
+                                //   kept from its previous chunk | the chunk's own log-mel rows, written back by the step]
+    float* pcm = nullptr;       // [max_pcm] the new audio chunk (wlk_sf_step_pcm), or unused
+    const wlk_melspec* mel = nullptr;
+    int n_pcm = 0, n_prev = 0, zero_from = 0;
     float* ctx = nullptr;       // [max_frames][d]
     float* chunk = nullptr;     // [max chunk rows][d]      (out)
     float* preds = nullptr;     // [max_frames][n_spk]      (out)
@@ -154,9 +158,10 @@ struct wlk_sortformer {
     // session by a by-value segment table.  Every kernel's per-row arithmetic is independent of what is stacked around
     // the row (launch_gemm_kp), so a session's result is bit for bit its step alone.  There is no gather window: a free
     // lane takes whatever is queued (work-conserving, like the ASR engine's encode lane).
-    // WLK_SF_WORKSPACES = lanes (default 2), WLK_SF_BATCH = sessions per stacked step (default 8, 1 = round-5 behaviour).
+    // WLK_SF_WORKSPACES = lanes (default 1), WLK_SF_BATCH = sessions per stacked step (default 8, 1 = round-5 behaviour).
     struct Lane {
         hipStream_t stream = nullptr;
+        float *audio = nullptr;          // [max_batch][max_pcm]: the sessions' new audio chunks (wlk_sf_step_pcm)
         float *feats = nullptr, *ca = nullptr, *cb = nullptr, *ctxbuf = nullptr, *chunk_tmp = nullptr, *x = nullptr, *xn = nullptr,
               *wide = nullptr, *qkv = nullptr, *att = nullptr, *tx = nullptr, *ty = nullptr, *tqkv = nullptr, *tatt = nullptr,
               *th = nullptr, *preds = nullptr;
@@ -169,6 +174,7 @@ struct wlk_sortformer {
     std::condition_variable cv;
     uint64_t next_ticket = 0;
     int max_batch = 8;
+    int max_pcm = 64000;                  // samples of a PCM chunk a request slot holds (4 s)
     int last_ws = 0;                      // the lane of the most recent step (exports)
     uint64_t n_steps = 0, n_sessions = 0, n_rows = 0;     // stacked steps run / session steps in them / rows in them
     float* pos_full = nullptr;            // read-only after finalize
@@ -291,8 +297,32 @@ static void sf_run_batch(wlk_sortformer* m, wlk_sortformer::Lane* w_, const std:
         if (q.n_ctx > 0)
             WLK_HIP(hipMemcpyAsync(w_->ctxbuf + (size_t)r0 * d, q.ctx, (size_t)q.n_ctx * d * sizeof(float), hipMemcpyHostToDevice, w_->stream));
         if (q.n_feat > 0) {
-            WLK_HIP(hipMemcpyAsync(w_->feats + (size_t)f0 * D.n_mels, q.feats, (size_t)q.n_feat * D.n_mels * sizeof(float),
-                                   hipMemcpyHostToDevice, w_->stream));
+            float* frows = w_->feats + (size_t)f0 * D.n_mels;
+            if (q.n_pcm > 0) {
+                // the front end inside the chain (round 6): previous rows up, the chunk's log-mel rows computed behind them on
+                // this stream with the extractor's read-only tables, rows past the valid length zeroed (FilterbankFeatures'
+                // seq_len rule, diarization.HipMelSpectrogram), the new rows back to the caller.  No separate extractor call:
+                // under load that call's three stream operations queued behind whole launch chains of other streams in the
+                // shared hardware queue (7 - 23 ms per chunk with GPU_MAX_HW_QUEUES = 2)
+                const wlk_melspec* me = q.mel;
+                const int n_new = q.n_feat - q.n_prev;
+                float* au = w_->audio + (size_t)b * m->max_pcm;
+                if (q.n_prev > 0)
+                    WLK_HIP(hipMemcpyAsync(frows, q.feats, (size_t)q.n_prev * D.n_mels * sizeof(float), hipMemcpyHostToDevice, w_->stream));
+                WLK_HIP(hipMemcpyAsync(au, q.pcm, (size_t)q.n_pcm * sizeof(float), hipMemcpyHostToDevice, w_->stream));
+                MelSpecArgs a;
+                a.audio = au; a.n_samples = q.n_pcm; a.window = me->window; a.twiddle = me->twiddle; a.filters = me->filters;
+                a.filt_lo = me->lo; a.filt_hi = me->hi; a.out = frows + (size_t)q.n_prev * D.n_mels; a.n_fft = me->n_fft;
+                a.win_length = me->win_length; a.hop = me->hop; a.n_mels = me->n_mels; a.preemph = me->preemph; a.log_guard = me->log_guard;
+                launch_melspec(c, a, n_new);
+                if (q.zero_from < n_new)
+                    WLK_HIP(hipMemsetAsync(frows + (size_t)(q.n_prev + q.zero_from) * D.n_mels, 0,
+                                           (size_t)(n_new - q.zero_from) * D.n_mels * sizeof(float), w_->stream));
+                WLK_HIP(hipMemcpyAsync(q.feats + (size_t)q.n_prev * D.n_mels, frows + (size_t)q.n_prev * D.n_mels,
+                                       (size_t)n_new * D.n_mels * sizeof(float), hipMemcpyDeviceToHost, w_->stream));
+            } else {
+                WLK_HIP(hipMemcpyAsync(frows, q.feats, (size_t)q.n_feat * D.n_mels * sizeof(float), hipMemcpyHostToDevice, w_->stream));
+            }
             s0.in_start[s0.n] = f0; s0.in_len[s0.n] = q.n_feat; s0.out_start[s0.n] = t0;
             ++s0.n;
             f0 += q.n_feat;
@@ -385,7 +415,10 @@ int wlk_sf_create(const wlk_sf_dims* dims, int device, wlk_sortformer** out) {
         const size_t L = D.max_frames, d = D.fc_d_model, dt = D.tf_d_model, C = D.sub_channels;
         const size_t T1 = sf_sub_len(D.max_feat_frames), F1 = sf_sub_len(D.n_mels);
         m->pos_full = sf_alloc(p, (size_t)std::max(D.fc_layers, 1) * (2 * L - 1) * d);
-        int n_ws = 2;
+        // ONE lane by default (measured, scripts/diar_probe8.py, profiles/r06_diar_lanes.txt): with stacked steps a second lane
+        // only splits the waiting sessions over two half-size chains that then share the GPU - 8 diarizer sessions alone
+        // 642 audio-s/s on one lane against 516 on two, and beside 8 ASR streams the ASR side 250 against 216
+        int n_ws = 1;
         if (const char* e = std::getenv("WLK_SF_WORKSPACES")) n_ws = std::max(1, std::min(8, std::atoi(e)));
         if (const char* e = std::getenv("WLK_SF_BATCH")) m->max_batch = std::max(1, std::min(kSfMaxSegments, std::atoi(e)));
         const size_t B = m->max_batch, R = B * L;          // sessions / rows of a stacked step
@@ -400,6 +433,7 @@ int wlk_sf_create(const wlk_sf_dims* dims, int device, wlk_sortformer** out) {
             if (pe && pe[0] == 'h') WLK_HIP(hipStreamCreateWithPriority(&w.stream, hipStreamNonBlocking, prio_hi));
             else if (pe && pe[0] == 'l') WLK_HIP(hipStreamCreateWithPriority(&w.stream, hipStreamNonBlocking, prio_lo));
             else WLK_HIP(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+            w.audio = sf_alloc(p, B * (size_t)m->max_pcm);
             w.feats = sf_alloc(p, B * (size_t)D.max_feat_frames * D.n_mels);
             w.ca = sf_alloc(p, B * T1 * F1 * C);
             w.cb = sf_alloc(p, B * T1 * F1 * C);
@@ -427,6 +461,7 @@ int wlk_sf_create(const wlk_sf_dims* dims, int device, wlk_sortformer** out) {
         m->slots.resize((size_t)(n_ws + 1) * B);
         for (auto& q : m->slots) {
             q.feats = pin((size_t)D.max_feat_frames * D.n_mels);
+            q.pcm = pin((size_t)m->max_pcm);
             q.ctx = pin(L * d);
             q.chunk = pin((T1 / 4 + 2) * d);
             q.preds = pin(L * D.n_spk);
@@ -506,9 +541,17 @@ int wlk_sf_finalize(wlk_sortformer* m) {
     });
 }
 
-int wlk_sf_step(wlk_sortformer* m, const float* feats_host, int n_feat, const float* ctx_embs_host, int n_ctx,
-                float* chunk_embs_host, int chunk_capacity_rows, int* n_chunk, float* preds_host,
-                int preds_capacity_rows) {
+namespace wlk {
+struct SfPcmIn {                 // wlk_sf_step_pcm's front-end arguments (mel == nullptr: the caller brought the features)
+    const wlk_melspec* mel = nullptr;
+    const float* pcm = nullptr;
+    int n_pcm = 0, n_prev = 0, zero_from = 0;
+    float* feats_out = nullptr;
+};
+}  // namespace wlk
+static int sf_step_impl(wlk_sortformer* m, const float* feats_host, int n_feat, const wlk::SfPcmIn& pin, const float* ctx_embs_host,
+                        int n_ctx, float* chunk_embs_host, int chunk_capacity_rows, int* n_chunk, float* preds_host,
+                        int preds_capacity_rows) {
     if (!m || !preds_host) return sf_fail(WLK_ERR_ARG, "NULL argument");
     if (!m->finalized) return sf_fail(WLK_ERR_STATE, "wlk_sf_finalize has not been called");
     if (n_feat < 0 || n_ctx < 0 || (n_feat > 0 && (!feats_host || !chunk_embs_host)) || (n_ctx > 0 && !ctx_embs_host))
@@ -535,8 +578,14 @@ int wlk_sf_step(wlk_sortformer* m, const float* feats_host, int n_feat, const fl
         }
         SfRequest& mine = m->slots[me];
         mine.n_feat = n_feat; mine.n_ctx = n_ctx; mine.Tc = Tc; mine.T = T;
+        mine.mel = pin.mel; mine.n_pcm = pin.mel ? pin.n_pcm : 0; mine.n_prev = pin.n_prev; mine.zero_from = pin.zero_from;
         mine.done = false; mine.rc = WLK_OK; mine.err.clear();
-        if (n_feat > 0) memcpy(mine.feats, feats_host, (size_t)n_feat * D.n_mels * sizeof(float));
+        if (pin.mel) {
+            if (pin.n_prev > 0) memcpy(mine.feats, feats_host, (size_t)pin.n_prev * D.n_mels * sizeof(float));
+            memcpy(mine.pcm, pin.pcm, (size_t)pin.n_pcm * sizeof(float));
+        } else if (n_feat > 0) {
+            memcpy(mine.feats, feats_host, (size_t)n_feat * D.n_mels * sizeof(float));
+        }
         if (n_ctx > 0) memcpy(mine.ctx, ctx_embs_host, (size_t)n_ctx * d * sizeof(float));
         // 2. queue; whoever finds a free lane while requests wait runs the oldest ones as ONE stacked step (its own may or
         //    may not be among them) - no dispatcher thread, no gather window
@@ -596,6 +645,7 @@ int wlk_sf_step(wlk_sortformer* m, const float* feats_host, int n_feat, const fl
         if (rc == WLK_OK) {
             if (Tc > 0) memcpy(chunk_embs_host, mine.chunk, (size_t)Tc * d * sizeof(float));
             memcpy(preds_host, mine.preds, (size_t)T * D.n_spk * sizeof(float));
+            if (pin.mel) memcpy(pin.feats_out, mine.feats + (size_t)pin.n_prev * D.n_mels, (size_t)(n_feat - pin.n_prev) * D.n_mels * sizeof(float));
         }
         {
             std::lock_guard<std::mutex> g(m->mu);
@@ -604,6 +654,32 @@ int wlk_sf_step(wlk_sortformer* m, const float* feats_host, int n_feat, const fl
         m->cv.notify_all();
         return rc == WLK_OK ? WLK_OK : sf_fail(rc, err);
     });
+}
+
+int wlk_sf_step(wlk_sortformer* m, const float* feats_host, int n_feat, const float* ctx_embs_host, int n_ctx,
+                float* chunk_embs_host, int chunk_capacity_rows, int* n_chunk, float* preds_host,
+                int preds_capacity_rows) {
+    return sf_step_impl(m, feats_host, n_feat, wlk::SfPcmIn{}, ctx_embs_host, n_ctx, chunk_embs_host, chunk_capacity_rows, n_chunk,
+                        preds_host, preds_capacity_rows);
+}
+
+int wlk_sf_step_pcm(wlk_sortformer* m, wlk_melspec* mel, const float* pcm_host, int n_pcm, int valid_frames,
+                    const float* prev_feats_host, int n_prev, float* feats_out_host, int feats_capacity_rows, int* n_feats_out,
+                    const float* ctx_embs_host, int n_ctx, float* chunk_embs_host, int chunk_capacity_rows, int* n_chunk,
+                    float* preds_host, int preds_capacity_rows) {
+    if (!m || !mel || !pcm_host || !feats_out_host || !n_feats_out) return sf_fail(WLK_ERR_ARG, "NULL argument");
+    if (n_pcm < 1 || n_pcm > m->max_pcm || n_pcm > mel->cap) return sf_fail(WLK_ERR_CAPACITY, "audio chunk does not fit the step's buffer");
+    if (mel->n_mels != m->D.n_mels || mel->device != m->device) return sf_fail(WLK_ERR_ARG, "the extractor does not match the model (mel bins / device)");
+    if (n_prev < 0 || (n_prev > 0 && !prev_feats_host)) return sf_fail(WLK_ERR_ARG, "bad previous-feature rows");
+    const int n_new = n_pcm / mel->hop + 1;                 // the centred STFT's frame count (wlk_melspec_run)
+    *n_feats_out = n_new;
+    if (n_new > feats_capacity_rows) return sf_fail(WLK_ERR_CAPACITY, "feature output buffer too small");
+    wlk::SfPcmIn pin;
+    pin.mel = mel; pin.pcm = pcm_host; pin.n_pcm = n_pcm; pin.n_prev = n_prev; pin.feats_out = feats_out_host;
+    pin.zero_from = valid_frames < 0 ? n_new : std::min(valid_frames, n_new);
+    // feats_host of the shared path = the previous rows (the new ones are produced by the step itself)
+    return sf_step_impl(m, n_prev > 0 ? prev_feats_host : pcm_host, n_prev + n_new, pin, ctx_embs_host, n_ctx, chunk_embs_host,
+                        chunk_capacity_rows, n_chunk, preds_host, preds_capacity_rows);
 }
 
 int wlk_sf_stats(wlk_sortformer* m, uint64_t* stacked_steps, uint64_t* session_steps, uint64_t* rows) {

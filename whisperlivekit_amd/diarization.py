@@ -182,14 +182,22 @@ class HipSortformerDiarizationOnline:
             return []
         audio = self.buffer_audio[:threshold]
         self.buffer_audio = self.buffer_audio[threshold:]
-        feats = self.model.features(audio)                                # [frames, 128]
-        if self._previous_chunk_features is not None:
-            total = np.concatenate([self._previous_chunk_features[-99:], feats], axis=0)   # :279-283
-        else:
-            total = feats
-        self._previous_chunk_features = feats
         left_offset = 8 if self._chunk_index > 0 else 0                  # :290-291
-        chunk_preds = self.model.forward_streaming_step(total, self.streaming_state, left_offset, 8)
+        fused = getattr(self.model, "forward_streaming_step_pcm", None)
+        if fused is not None:
+            # the HIP model takes the audio itself: log-mel, stem and network in ONE launch chain / ONE synchronisation
+            # (same kernels, same values as the three calls below)
+            prev = self._previous_chunk_features[-99:] if self._previous_chunk_features is not None else None   # :279-283
+            chunk_preds, feats = fused(audio, prev, self.streaming_state, left_offset, 8)
+            self._previous_chunk_features = feats
+        else:
+            feats = self.model.features(audio)                            # [frames, 128]
+            if self._previous_chunk_features is not None:
+                total = np.concatenate([self._previous_chunk_features[-99:], feats], axis=0)   # :279-283
+            else:
+                total = feats
+            self._previous_chunk_features = feats
+            chunk_preds = self.model.forward_streaming_step(total, self.streaming_state, left_offset, 8)
         self.total_preds = np.concatenate([self.total_preds, np.asarray(chunk_preds, np.float32)], axis=0)
         keep = max(1024, 4 * (self._len_prediction or 256))              # :305-307
         if self.total_preds.shape[0] > keep:

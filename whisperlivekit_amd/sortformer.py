@@ -438,6 +438,40 @@ class HipSortformerModel:
             C.byref(n_chunk), preds.ctypes.data_as(C.c_void_p), preds.shape[0]))
         return chunk[: n_chunk.value], preds[: n_ctx + n_chunk.value]
 
+    def step_pcm(self, pcm: np.ndarray, prev_feats: Optional[np.ndarray], ctx_embs: Optional[np.ndarray]):
+        """``step`` with the front end inside the launch chain (wlk_sf_step_pcm): the chunk's log-mel rows are computed behind
+        ``prev_feats`` on the step's own stream.  -> (new feature rows [n, n_mels], chunk embeddings, activities);
+        bit-identical to ``features(pcm)`` + ``step(concat(prev_feats, feats), ctx)``."""
+        if self._mel is None:
+            self._mel = HipMelSpectrogram(device=self.device, n_mels=self.dims.n_mels)
+        mel, d = self._mel, self.dims.fc_d_model
+        a = np.ascontiguousarray(pcm, dtype=np.float32).reshape(-1)
+        n_prev = 0 if prev_feats is None else int(prev_feats.shape[0])
+        pf = np.ascontiguousarray(prev_feats, np.float32) if n_prev else None
+        n_ctx = 0 if ctx_embs is None else int(ctx_embs.shape[0])
+        e = np.ascontiguousarray(ctx_embs, np.float32) if n_ctx else None
+        cap_f = a.shape[0] // mel.hop + 2
+        feats = np.empty((cap_f, self.dims.n_mels), np.float32)
+        cap_c = (n_prev + cap_f) // 8 + 2
+        chunk = np.empty((cap_c, d), np.float32)
+        preds = np.empty((n_ctx + cap_c, self.n_spk), np.float32)
+        n_f, n_chunk = C.c_int(), C.c_int()
+        valid = -1 if mel.seq_len_plus_one else a.shape[0] // mel.hop
+        _lib.check(self.lib.wlk_sf_step_pcm(
+            self._h, mel._h, a.ctypes.data_as(C.c_void_p), a.shape[0], valid, pf.ctypes.data_as(C.c_void_p) if n_prev else None, n_prev,
+            feats.ctypes.data_as(C.c_void_p), cap_f, C.byref(n_f), e.ctypes.data_as(C.c_void_p) if n_ctx else None, n_ctx,
+            chunk.ctypes.data_as(C.c_void_p), cap_c, C.byref(n_chunk), preds.ctypes.data_as(C.c_void_p), preds.shape[0]))
+        return feats[: n_f.value], chunk[: n_chunk.value], preds[: n_ctx + n_chunk.value]
+
+    def forward_streaming_step_pcm(self, pcm: np.ndarray, prev_feats: Optional[np.ndarray], state: SortformerState,
+                                   left_offset: int, right_offset: int):
+        """``features`` + ``forward_streaming_step`` as ONE device call (one launch chain, one synchronisation): -> (the
+        chunk's activities, the chunk's own feature rows for the caller's next call)."""
+        ctx = np.concatenate([state.spkcache[: state.spkcache_len], state.fifo[: state.fifo_len]], axis=0)
+        feats, chunk, preds = self.step_pcm(pcm, prev_feats, ctx if ctx.shape[0] else None)
+        sf = self.cache.subsampling_factor
+        return streaming_update(self.cache, state, chunk, preds, round(left_offset / sf), math.ceil(right_offset / sf)), feats
+
     def forward_streaming_step(self, features: np.ndarray, state: SortformerState, left_offset: int,
                                right_offset: int) -> np.ndarray:
         """SortformerEncLabelModel.forward_streaming_step for one stream: pre-encode the chunk, run the network over
