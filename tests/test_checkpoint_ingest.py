@@ -3,13 +3,16 @@ the first branch of the reference's load_model (whisper/__init__.py:520-560) - t
 `HipSimulStreamingASR(model_path=...)`.  Real checkpoints hold fp16 tensors that the reference loads into fp32 parameters
 ("fp16 checkpoint values are loaded into fp32 nn.Parameters"): the fp16 file must behave exactly like its values
 upcast to fp32."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
 import helpers as H
 from whisperlivekit_amd import backend as B
-from whisperlivekit_amd.dims import MODEL_DIMS
+from whisperlivekit_amd.dims import ALIGNMENT_HEADS, MODEL_DIMS
 from whisperlivekit_amd.engine import pack_state_dict
 
 
@@ -69,7 +72,9 @@ def test_model_path_streams_like_the_reference_and_fp16_values_are_upcast(tmp_pa
     opened = []
 
     def make(model_name, cfg_over, seed=0):
-        asr = B.HipSimulStreamingASR(model_name, model_path=p32, **H.asr_kwargs(cfg_over))
+        # the golden trace was generated with micro.en's named head table set on the reference's model; a path load by itself
+        # takes Whisper.__init__'s default heads (test_model_path_takes_the_reference's_default_alignment_heads)
+        asr = B.HipSimulStreamingASR(model_name, model_path=p32, custom_alignment_heads=ALIGNMENT_HEADS[model_name], **H.asr_kwargs(cfg_over))
         from whisperlivekit_amd import policy as P
 
         class P2(B.HipSimulStreamingOnlineProcessor):
@@ -100,10 +105,77 @@ def test_model_path_streams_like_the_reference_and_fp16_values_are_upcast(tmp_pa
     p16 = str(tmp_path / "micro16.pt")
     _, sd16 = write_checkpoint(p16, "micro.en", torch.float16)
     audio = H.stream_audio(case)
-    a = B.HipSimulStreamingASR("micro.en", model_path=p16)
+    a = B.HipSimulStreamingASR("micro.en", model_path=p16, custom_alignment_heads=ALIGNMENT_HEADS["micro.en"])
     b = B.HipSimulStreamingASR("micro.en", state_dict={k: v.float().numpy() for k, v in sd16.items()})
     try:
         assert _run(a, audio, 12) == _run(b, audio, 12)
     finally:
         a.hip_model.close()
         b.hip_model.close()
+
+
+@pytest.mark.gpu
+def test_model_path_takes_the_references_default_alignment_heads(tmp_path):
+    """A checkpoint loaded from a PATH gets the heads the reference gives it: `load_model(path)` finds no entry in its per-name
+    table and keeps Whisper.__init__'s default - all heads of the upper half of the decoder layers (whisper/__init__.py:546,
+    model.py:353-361) - unless custom heads are given.  Checked against the reference's own load_model when it is importable."""
+    p = str(tmp_path / "micro.pt")
+    write_checkpoint(p, "micro.en", torch.float32)
+    dims = MODEL_DIMS["micro.en"]
+    want = [(l, h) for l in range(dims.n_text_layer // 2, dims.n_text_layer) for h in range(dims.n_text_head)]
+    asr = B.HipSimulStreamingASR("micro.en", model_path=p)
+    try:
+        assert sorted(asr.hip_model.alignment_heads) == want
+    finally:
+        asr.hip_model.close()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import ref_stubs
+    if ref_stubs.reference_available():
+        ref_stubs.install()
+        from whisperlivekit.whisper import load_model
+        ref = load_model(p, device="cpu")
+        assert sorted(map(tuple, ref.alignment_heads.indices().T.tolist())) == want
+
+
+def _bench_on_checkpoint(path, model_name, seconds, chunks):
+    import json
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = os.path.join(tempfile.mkdtemp(prefix="wlk_bench_ckpt_"), "full.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("WLK_SYNTHETIC_VOCAB", "WLK_VOCAB_DIR")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--checkpoint", path, "--model", model_name, "--seconds", str(seconds),
+                        "--steps", "1", "--warmup", "1", "--no-diarization", "--cpu-chunks", str(chunks), "--cpu-seconds", "240",
+                        "--full-out", full], capture_output=True, text=True, timeout=1500, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1]), json.load(open(full))
+
+
+@pytest.mark.gpu
+def test_bench_on_a_checkpoint_file_checks_itself_against_the_references_cpu_path(tmp_path):
+    """`bench.py --checkpoint <file>` (round-5 review, missing #3): weights from a local checkpoint through
+    whisperlivekit_amd.checkpoint, the real vocabulary, and - no golden trace exists for arbitrary weights - parity by running the
+    reference's own load_model + SimulStreamingOnlineProcessor on the same file on the CPU over a prefix of the timed stream.
+    Exercised here on a checkpoint this test writes (openai layout, seeded values)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import ref_stubs
+    if not ref_stubs.reference_available():
+        pytest.skip("no WhisperLiveKit tree for the CPU side")
+    p = str(tmp_path / "micro.pt")
+    write_checkpoint(p, "micro.en", torch.float32)
+    line, full = _bench_on_checkpoint(p, "micro.en", 12, 24)
+    pc = line["parity_checked"]
+    assert line["parity_ok"] is True and pc["chunks"] == 24 and pc["chunks_identical"] == 24 and pc["words"] >= 1, pc
+    assert line["cpu_baseline"]["kind"] == "reference" and line["cpu_baseline"]["validated"] is True
+    assert "micro.pt" in line["config"]["workload"] and "real vocabulary" in line["config"]["workload"]
+    assert line["value"] > 0 and 0 < line["roofline"]["frac"] <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.environ.get("WLK_WHISPER_CKPT"), reason="WLK_WHISPER_CKPT names no real Whisper checkpoint (none exists offline)")
+def test_real_checkpoint_streams_like_the_reference_on_a_prefix():
+    """With real weights at hand (WLK_WHISPER_CKPT = a file or directory whisper.load_model takes; WLK_WHISPER_NAME = its size name,
+    default base.en): the first 8 s of a stream through the HIP backend and through the reference's CPU path commit the same words."""
+    line, _full = _bench_on_checkpoint(os.environ["WLK_WHISPER_CKPT"], os.environ.get("WLK_WHISPER_NAME", "base.en"), 30, 16)
+    pc = line["parity_checked"]
+    assert line["parity_ok"] is True and pc["chunks_identical"] == pc["chunks"] == 16, pc

@@ -214,6 +214,12 @@ def test_bench_checks_its_own_outputs_against_the_reference():
     # decision of every session ends up identical and no call stays unchecked
     assert pc["identical"] == pc["decisions"] and pc["words_identical_sessions"] == pc["sessions"], pc
     assert pc["unchecked_calls"] == 0 and pc["forced_decisions"] == len(pc["tie_divergences"]), pc
+    # forced steps count as identical, so `identical == decisions` alone could hide a regression that flips many near-ties:
+    # bound them.  Today there is ONE tied decision on these streams (seed 5, call 51, frame scores 1.19e-7 apart), met once per
+    # pass over seed 5 (headline warm-up is not checked; the 8-stream leg runs it once): allow a second one, not a drift
+    assert pc["forced_decisions"] <= 2, pc["tie_divergences"]
+    assert all(abs(t[-1]) < 2e-5 for t in pc["tie_divergences"]), pc["tie_divergences"]
+    assert short["parity_checked"]["identical"] - pc["forced_decisions"] >= pc["decisions"] - 2
     assert line["n_gpus"] == 1 and line["eight_streams"]["streams"] == 8
     assert line["eight_streams"]["swallowed_errors"] == 0 and line["swallowed_errors"] == 0
     out = os.path.join(ROOT, "gpurun_out")

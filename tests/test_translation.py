@@ -144,6 +144,27 @@ def test_local_agreement_validates_only_what_two_hypotheses_share():
     assert tr._segment.tokens == [] and tr._validated_words == []
 
 
+def test_final_translation_that_rewrites_the_validated_prefix_drops_and_repeats_nothing():
+    """A sentence closes with a final hypothesis that changed (or shortened) the already validated prefix: what is emitted
+    continues from where the final hypothesis and the validated words still agree - by content, not by count (round-5
+    advisor finding: a slice by count dropped words when the final hypothesis was shorter and repeated none of the rewrite)."""
+    tm = T.HipNllbTranslationModel(OracleModel(), WordTokenizer())
+    for final, emitted in (("le chien noir dort.", "chien noir dort."),          # rewrote validated word 2: continue behind "le"
+                           ("le chat.", "chat."),                                # shortened: only what differs behind the agreed "le"
+                           ("le chat noir court vite.", "court vite.")):           # plain extension: only the new words
+        tr = tm.new_session("eng_Latn", "fra_Latn")
+        hyps = iter(["le chat noir", "le chat noir dort", final])
+        tr._translate = lambda seg: next(hyps).split()
+        got = []
+        for spec in ("the cat", "black", "sleeps."):
+            tr.insert_tokens(words(spec, 0.4 * len(got)))
+            new, _buf = tr.process()
+            got.append(None if new is None else new.text)
+        assert got[1] == "le chat noir"
+        assert got[2] == emitted, (final, got)       # never the count-based slice (that gave "dort." / nothing / "court vite.")
+        assert tr._validated_words == [] and tr._segment.tokens == []
+
+
 def test_unknown_language_raises_value_error_and_the_factory_falls_back():
     tm = T.HipNllbTranslationModel(OracleModel(), WordTokenizer())
     with pytest.raises(ValueError):

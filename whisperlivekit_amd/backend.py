@@ -21,7 +21,7 @@ import numpy as np
 
 from . import policy as P
 from .align_att import HipAlignAttStandalone, make_alignatt_class
-from .dims import ALIGNMENT_HEADS, MODEL_DIMS, ModelDims
+from .dims import default_alignment_heads, ALIGNMENT_HEADS, MODEL_DIMS, ModelDims
 from .engine import HipWhisperModel
 
 logger = logging.getLogger(__name__)
@@ -78,6 +78,10 @@ class HipSimulStreamingASR:
         self.mlx_encoder = self.fw_encoder = self.mlx_model = None
         self.fast_encoder = False
         heads = custom_alignment_heads or alignment_heads
+        if lora_path is not None and (model_path is None or hip_model is not None):
+            # the adapter is merged while the checkpoint is read (checkpoint.load_whisper_checkpoint); a ready model, a state dict
+            # or synthetic weights would silently serve the un-adapted model (the reference merges it for every load)
+            raise ValueError("lora_path needs model_path (the adapter is merged at checkpoint load)")
         if hip_model is not None:
             self.hip_model = hip_model
         elif model_path is not None:
@@ -85,8 +89,11 @@ class HipSimulStreamingASR:
             # .safetensors / shards, openai / HuggingFace / MLX names, an optional LoRA adapter merged in
             from .checkpoint import load_whisper_checkpoint
             d, sd, own_heads = load_whisper_checkpoint(model_path, lora_path)
-            self.hip_model = HipWhisperModel.from_state_dict(
-                d, sd, heads or own_heads or ALIGNMENT_HEADS.get(model_size), device)
+            # Alignment heads of a PATH load, as the reference resolves them (whisper/__init__.py:546-552, model.py:353-361;
+            # simul_whisper/backend.py:530-539 hands load_model the path, not the size name): custom heads, else the pairs the
+            # checkpoint carries (MLX exports), else Whisper.__init__'s default - every head of the upper half of the decoder
+            # layers.  The per-size tables (dims.ALIGNMENT_HEADS) belong to the official NAMES the reference downloads.
+            self.hip_model = HipWhisperModel.from_state_dict(d, sd, heads or own_heads or default_alignment_heads(d), device)
         elif state_dict is not None:
             d = dims or MODEL_DIMS[model_size]
             self.hip_model = HipWhisperModel.from_state_dict(

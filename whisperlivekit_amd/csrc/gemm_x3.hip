@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <cstdio>
+
 #include "common.h"
 #include "x3.h"
 
@@ -637,9 +639,21 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
     // algorithmic work (what the roofline fraction is computed from): 2 M N K flop, operands and result once
     KernelScope ks(ctx, tag, 2.0 * batch * (double)g.M * g.N * g.K,
                    batch * (6.0 * ((double)g.M * g.K) + 4.0 * (double)g.M * g.N) + 6.0 * (double)g.N * g.K);
+    // Timing ablations of scripts/x3_probe.py.  Variants 1-5 skip MFMAs, DMA pieces or weight loads and produce WRONG results, so a
+    // stray WLK_X3_ABL on a serving box must not reach them: they need WLK_PROBES=1 beside it and announce themselves once.
     static const int abl = [] {
         const char* e = getenv("WLK_X3_ABL");
-        return e ? atoi(e) : 0;
+        int v = e ? atoi(e) : 0;
+        if (v >= 1 && v <= 5) {
+            const char* ok = getenv("WLK_PROBES");
+            if (!(ok && ok[0] == '1')) {
+                fprintf(stderr, "libwlk_hip: WLK_X3_ABL=%d ignored (result-corrupting timing ablation; set WLK_PROBES=1 to run it)\n", v);
+                v = 0;
+            } else {
+                fprintf(stderr, "libwlk_hip: WLK_X3_ABL=%d ACTIVE - the X3 GEMM results of this process are WRONG (timing probe)\n", v);
+            }
+        }
+        return v;
     }();
     const dim3 grid(blocks);
     if (abl == 1) hipLaunchKernelGGL(gemm_x3_wide_kernel<1>, grid, dim3(XW_THREADS), XW_LDS_BYTES, ctx.stream, gg);

@@ -36,11 +36,14 @@ No CPU fallback: the model is a :class:`whisperlivekit_amd.nllb.HipNllbModel`.
 """
 from __future__ import annotations
 
+import logging
 import threading
 from dataclasses import dataclass, field
 from typing import Any, List, Optional, Sequence, Tuple
 
 from . import nllb
+
+logger = logging.getLogger(__name__)
 
 PUNCTUATION_MARKS = {".", "!", "?", "。", "！", "？"}        # timed_objects.py:4
 
@@ -179,7 +182,13 @@ class HipOnlineTranslation:
         start = self._piece_start(self._closed[0].start if self._closed else self._segment.start)
         for seg in self._closed:                      # finished sentences: their last translation is final
             words = self._translate(seg)
-            pieces += words[len(self._validated_words):]      # validated text is append-only: only what lies behind it is new
+            # validated text is append-only: only what lies behind it is new.  "Behind it" is by CONTENT, not by count - a
+            # final hypothesis that rewrote or shortened the validated prefix continues from where the two still agree, so no
+            # word is dropped or printed twice (the open-sentence path below makes the same check)
+            keep = _common_prefix(words, self._validated_words)
+            if keep != len(self._validated_words):
+                logger.debug("final translation rewrites %d validated word(s)", len(self._validated_words) - keep)
+            pieces += words[keep:]
             end = seg.end
             self._validated_words, self._previous, self._buffer_words = [], [], []
         self._closed = []
