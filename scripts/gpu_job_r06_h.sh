@@ -1,0 +1,15 @@
+# X3 for the N = d projections of d >= 1024 models: parity (medium / large-v3 numerics + the three large-v3 streams) and the A/B
+O=gpurun_out/r06h; mkdir -p $O
+S=$(date +%s); timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_x3.py -q -m gpu -k "medium or large or x3 or small" 2>&1 | tail -8 > $O/pytest.log; echo "pytest $(( $(date +%s) - S )) s: $(tail -1 $O/pytest.log)"; grep -E "FAILED|^E " $O/pytest.log | head
+B="python bench.py --model large-v3 --seconds 30 --seed 8 --steps 1 --warmup 1 --no-cpu-baseline --no-diarization --no-large-v3"
+for rep in 1 2; do
+  $B --full-out $O/lv3_x3narrow_$rep.json > /dev/null 2> $O/lv3_x3narrow_$rep.log; echo "x3 narrow rc=$?"
+  WLK_X3_NARROW=0 $B --full-out $O/lv3_fp32narrow_$rep.json > /dev/null 2> $O/lv3_fp32narrow_$rep.log; echo "fp32 narrow rc=$?"
+done
+python - <<PY
+import json
+for n in ("x3narrow_1","fp32narrow_1","x3narrow_2","fp32narrow_2"):
+    d=json.load(open("$O/lv3_%s.json"%n)); r=d["roofline"]; pc=d["parity_checked"]
+    print(n, "value", d["value"], "p50 call", d["p50_call_ms"], "encode us", r["encode"]["us"], "enc frac", r["encode"]["frac"], "parity", d["parity_ok"], pc["decisions"], pc["identical"], len(pc["tie_divergences"]),
+          {k.split(" (")[0]: (v["avg_launch_us"], v["launches"]) for k, v in r["mfma_families"].items()})
+PY

@@ -27,3 +27,13 @@ for name, n, k, flags in SHAPES:
         gf = 2.0 * m * n * k / 1e9
         print(f"{name:8s} M {m:5d} N {n:4d} K {k:4d}: rule {rule:6.1f} us ({gf / rule * 1e-3:5.1f} TFLOP/s) | best {best} {per[best]:6.1f} us "
               f"({gf / per[best] * 1e-3:5.1f}) | " + " ".join(f"{kk} {v:.1f}" for kk, v in per.items()), flush=True)
+
+print("--- below 512 rows: 32 x 32 k-wave tiles (force 7) against 16 x 16 tiles (force 6), same bits")
+for name, n, k, flags in SHAPES + [("tf_qkv(K192: plain)", 576, 192, 4)]:
+    if k % 128:
+        continue
+    row = []
+    for m in (50, 100, 200, 291, 401):
+        a, b = t(m, n, k, flags, 7), t(m, n, k, flags, 6)
+        row.append(f"M {m}: {a:5.1f} / {b:5.1f}")
+    print(f"{name:8s} N {n:4d} K {k:4d}: " + " | ".join(row), flush=True)

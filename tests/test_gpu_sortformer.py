@@ -112,10 +112,10 @@ def test_kp_family_rows_do_not_depend_on_what_is_stacked_under_them(N, K, flags)
     bias = (0.1 * rng.standard_normal(N)).astype(np.float32)
     r = rng.standard_normal((M, N)).astype(np.float32)
 
-    def run(rows):
+    def run(rows, force=5):
         c = np.empty((rows, N), np.float32)
         rc = lib.wlk_diag_linear(_vp(a), K, rows * K, _vp(w), _vp(bias), _vp(r) if flags & 2 else None, N, rows, N, K, flags,
-                                 0.5, N // 2, 5, _vp(c))
+                                 0.5, N // 2, force, _vp(c))
         assert rc == 0, lib.wlk_diag_last_error()
         return c
 
@@ -132,6 +132,10 @@ def test_kp_family_rows_do_not_depend_on_what_is_stacked_under_them(N, K, flags)
     assert np.abs(big - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
     for rows in (291, 401, 37, 600):
         assert np.array_equal(run(rows).view(np.uint32), big[:rows].view(np.uint32)), (rows, N, K)
+    if K % 128 == 0:          # below 512 rows the family has two tile shapes (16 x 16: force 6, 32 x 32: force 7): same bits
+        for rows in (291, 37):
+            for force in (6, 7):
+                assert np.array_equal(run(rows, force).view(np.uint32), big[:rows].view(np.uint32)), (rows, N, K, force)
 
 
 def test_concurrent_steps_on_one_model_equal_serial_steps(shallow):

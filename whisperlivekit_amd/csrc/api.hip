@@ -356,15 +356,24 @@ int wlk_model_finalize(wlk_model* m) {
                 ~StreamGuard() { (void)hipStreamDestroy(s); }
             } st_guard{st};
             c.stream = st;
-            auto pack = [&](const float* w, int n_rows) -> unsigned short* {
-                unsigned short* p3 = dev_alloc<unsigned short>(x3_w_elems(n_rows, da));
+            auto pack = [&](const float* w, int n_rows, int k = 0) -> unsigned short* {
+                if (k == 0) k = da;
+                unsigned short* p3 = dev_alloc<unsigned short>(x3_w_elems(n_rows, k));
                 m->x3_owned.push_back(p3);
-                launch_x3_pack_w(c, w, da, p3, n_rows, da);      // fragment-major: the wide kernel's waves load it straight into registers
+                launch_x3_pack_w(c, w, k, p3, n_rows, k);      // fragment-major: the wide kernel's waves load it straight into registers
                 return p3;
             };
+            // Round 6: the N = d projections (attention out, fc2) too where d >= 1024 (medium, large-v3): measured on MI355X
+            // (scripts/x3_probe.py, profiles/r06_x3_narrow_probe.txt) at M = 1500: N = K = 1280 40.3 us against 52.4 for the fp32
+            // k-pipe kernel, N 1280 / K 5120 147 against 187 - and N = 512 (base.en: 64 workgroups of 96 x 128) 18.9 against 11.3,
+            // 53.6 against 33.9: gemm_x3_wide_applicable's N >= 1024 draws exactly that line.  Their A operands (attention
+            // output, GELU output) are fp32 rows, packed into X3 by one elementwise launch each.  WLK_X3_NARROW=0 switches it off.
+            static const bool narrow = [] { const char* e = getenv("WLK_X3_NARROW"); return !(e && e[0] == '0'); }();
             for (auto& L : m->enc_layers) {
                 L.qkvw3 = gemm_x3_wide_applicable(T, 3 * da, da, da) ? pack(L.qkvw, 3 * da) : nullptr;
                 L.fc1w3 = gemm_x3_wide_applicable(T, 4 * da, da, da) ? pack(L.fc1w, 4 * da) : nullptr;
+                L.outw3 = narrow && gemm_x3_wide_applicable(T, da, da, da) ? pack(L.outw, da) : nullptr;
+                L.fc2w3 = narrow && gemm_x3_wide_applicable(T, da, 4 * da, 4 * da) ? pack(L.fc2w, da, 4 * da) : nullptr;
             }
             const int n_xkv = m->D.n_text_layer * 2 * m->D.n_text_state;
             if (gemm_x3_wide_applicable(T, n_xkv, da, da)) m->xkv_all_w3 = pack(m->xkv_all_w, n_xkv);
@@ -434,10 +443,13 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         {   // X3 operand buffers (6 bytes per element) only where this model's encode chain takes the X3 path (the choice is
             // the model's: weights packed by wlk_model_finalize; WLK_X3=0 / WLK_X3_ATTN=0 leave them out)
             bool any_x3 = m->xkv_all_w3 != nullptr, qkv_x3 = false;
+            bool fc2_x3 = false;
             for (const auto& L : m->enc_layers) {
-                any_x3 |= L.qkvw3 || L.fc1w3;
+                any_x3 |= L.qkvw3 || L.fc1w3 || L.outw3;
                 qkv_x3 |= L.qkvw3 != nullptr;
+                fc2_x3 |= L.fc2w3 != nullptr;
             }
+            if (fc2_x3) s->emlp3 = dev_alloc<unsigned short>(T * 3 * 4 * d);
             const bool attn_x3 = qkv_x3 && enc_attention_x3_enabled() && d == (size_t)D.n_audio_head * 64 && T >= 64 && (2 * d) % 128 == 0;
             if (any_x3) s->eh3 = dev_alloc<unsigned short>(T * 3 * d);
             if (attn_x3) s->eqkv3 = dev_alloc_zero<unsigned short>(x3_attn_image_elems((int)T, (int)d), st);
@@ -528,6 +540,7 @@ int wlk_session_destroy(wlk_session* s) {
     if (s->eh3) (void)hipFree(s->eh3);
     if (s->eqkv3) (void)hipFree(s->eqkv3);
     if (s->enc_out3) (void)hipFree(s->enc_out3);
+    if (s->emlp3) (void)hipFree(s->emlp3);
     if (s->wa_buf) (void)hipFree(s->wa_buf);
     if (s->esplit) (void)hipFree(s->esplit);
     if (s->pinned) (void)hipHostFree(s->pinned);
@@ -832,6 +845,12 @@ extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const
                                       [](wlk_session* s) { return reinterpret_cast<float*>(s->eqkv3); }, none);
     const PtrTable z_qkv3_att = table([](wlk_session* s) { return reinterpret_cast<const float*>(s->eqkv3); },
                                       [](wlk_session* s) { return s->eatt; }, none);
+    const PtrTable z_eh3_ex_res = table([](wlk_session* s) { return reinterpret_cast<const float*>(s->eh3); }, [](wlk_session* s) { return s->ex; },
+                                        [](wlk_session* s) { return (const float*)s->ex; });
+    const PtrTable z_eh3_mlp3 = table([](wlk_session* s) { return reinterpret_cast<const float*>(s->eh3); },
+                                      [](wlk_session* s) { return reinterpret_cast<float*>(s->emlp3); }, none);
+    const PtrTable z_mlp3_ex_res = table([](wlk_session* s) { return reinterpret_cast<const float*>(s->emlp3); }, [](wlk_session* s) { return s->ex; },
+                                         [](wlk_session* s) { return (const float*)s->ex; });
     const bool attn_x3 = enc_attention_x3_enabled() && d == D.n_audio_head * 64 && T >= 64 && (2 * d) % 128 == 0;
     auto gemm_x3 = [&](const GemmArgs& g, const unsigned short* w3, const PtrTable& z, const char* tag) {
         X3GemmArgs x;
@@ -870,10 +889,23 @@ extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const
         GemmArgs o;
         o.lda = d; o.W = L.outw; o.bias = L.outb; o.ldc = d; o.M = T; o.N = d; o.K = d;
         o.flags = kGemmResidual; o.ldr = d;
-        gemm(o, z_att_ex, "enc_out");
+        if (L.outw3) {
+            // d >= 1024: the attention output goes through the X3 kernel too - packed into the (dead by now) LayerNorm image
+            for (int i = 0; i < B; ++i) launch_x3_pack(c, group[i]->eatt, d, group[i]->eh3, d, T, d);
+            gemm_x3(o, L.outw3, z_eh3_ex_res, "enc_out_x3");
+        } else {
+            gemm(o, z_att_ex, "enc_out");
+        }
         GemmArgs f1;
         f1.lda = d; f1.W = L.fc1w; f1.bias = L.fc1b; f1.ldc = 4 * d; f1.M = T; f1.N = 4 * d; f1.K = d; f1.flags = kGemmGelu;
-        if (L.fc1w3) {
+        const bool mlp_x3 = L.fc1w3 && L.fc2w3 && (4 * d) % 128 == 0;      // (128 = the X3 kernel's tile width: vt_col0 must be a multiple of it)      // fc1's GELU epilogue writes fc2's X3 operand itself
+        if (mlp_x3) {
+            launch_layernorm_x3_batched(c, z_ex_eh3, B, d, L.ln2w, L.ln2b, d, T, d, "enc_ln2");
+            X3GemmArgs x;
+            x.lda = d; x.W3 = L.fc1w3; x.bias = f1.bias; x.M = T; x.N = 4 * d; x.K = d; x.flags = kGemmGelu; x.batch = B; x.z = z_eh3_mlp3;
+            x.x3_out = true; x.ldc3 = 4 * d; x.vt_col0 = 4 * d; x.vt_off = 0; x.vt_ld = (T + 31) / 32 * 32;
+            launch_gemm_x3(c, x, "enc_fc1_x3");
+        } else if (L.fc1w3) {
             launch_layernorm_x3_batched(c, z_ex_eh3, B, d, L.ln2w, L.ln2b, d, T, d, "enc_ln2");
             gemm_x3(f1, L.fc1w3, z_eh3_mlp, "enc_fc1_x3");
         } else {
@@ -883,7 +915,13 @@ extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const
         GemmArgs f2;
         f2.lda = 4 * d; f2.W = L.fc2w; f2.bias = L.fc2b; f2.ldc = d; f2.M = T; f2.N = d; f2.K = 4 * d;
         f2.flags = kGemmResidual; f2.ldr = d;
-        gemm(f2, z_mlp_ex, "enc_fc2");
+        if (L.fc2w3) {
+            if (!mlp_x3)
+                for (int i = 0; i < B; ++i) launch_x3_pack(c, group[i]->emlp, 4 * d, group[i]->emlp3, 4 * d, T, 4 * d);
+            gemm_x3(f2, L.fc2w3, z_mlp3_ex_res, "enc_fc2_x3");
+        } else {
+            gemm(f2, z_mlp_ex, "enc_fc2");
+        }
     }
     {   // final LayerNorm + cross-attention K (scaled) and V of every decoder layer in ONE GEMM: cross_kv is [T][L][k | v]
         GemmArgs g;

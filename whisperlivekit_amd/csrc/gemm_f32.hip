@@ -390,7 +390,10 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kwave_kernel(GemmArgs g) {
 // the A values are normalised - (x - mean) * rstd * gamma + beta, the same expression - on their way into LDS.  Bit for
 // bit the LayerNorm launch + this kernel (tests/test_gpu_parity.py::test_prefill_gemm_fuses_the_layernorm); 18 launches
 // less per prefill.
-template <int NPL>
+// KP (round 6): the k-pipe kernel's partition of K, as in gemm_nt_f32_kwave_kernel<true> - wave w takes the eight k values
+// 8 w .. 8 w + 7 of each of the slab's four 32-deep sub-tiles (in the same in-group order), so the 16 x 16 tiles join the "kp"
+// family: bit for bit the 32 x 32 k-wave tiles' and every k-pipe tile's result.
+template <int NPL, bool KP = false>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kwave16_kernel(GemmArgs g) {
     WLK_PIN_GEMM_ARGS(g);
     constexpr bool LN = NPL > 0;
@@ -462,13 +465,13 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kwave16_kernel(GemmArgs g) {
     // lane (row / column = lane & 15, k-slot g4 = lane >> 4): of k-group s it supplies k = 8s + 4 (g4 & 1) + (g4 >> 1) to the
     // first MFMA and that + 2 to the second - elements (g4 >> 1) and (g4 >> 1) + 2 of the float4 at 8s + 4 (g4 & 1)
     const int g4 = lane >> 4;
-    const int frag = wave * SUB + (lane & 15) * LDS_LD + (g4 & 1) * 4;
+    const int frag = (KP ? wave * 8 : wave * SUB) + (lane & 15) * LDS_LD + (g4 & 1) * 4;
     const bool odd = (g4 >> 1) != 0;
     auto mma = [&](int buf) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][frag + s * 8]);
-            const float4 b4 = *reinterpret_cast<const float4*>(&Ws[buf][frag + s * 8]);
+            const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][frag + s * (KP ? SUB : 8)]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&Ws[buf][frag + s * (KP ? SUB : 8)]);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(odd ? a4.y : a4.x, odd ? b4.y : b4.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(odd ? a4.w : a4.z, odd ? b4.w : b4.z, acc, 0, 0, 0);
         }
@@ -1330,6 +1333,18 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
 // Measured on MI355X for the Sortformer's shapes at the row counts stacked steps produce (scripts/kp_tile_probe.py,
 // profiles/r06_kp_tile_probe.txt): ksplit_tile's "rounds of 256 workgroups" model is right for M = 1500 and up to 25 % off
 // elsewhere (thin tiles run two or three workgroups per CU), so the shapes that matter carry their measured best tile.
+// Measured (scripts/kp_tile_probe.py, profiles/r06_kp_tile_probe.txt; us per launch, 32 x 32 / 16 x 16 tiles, M = 50 / 100 / 200 /
+// 291 / 401): N 512 K 512: 7.8/4.5 7.8/4.5 7.9/5.6 8.0/6.8 8.0/7.9;  N 192 K 768: 9.3/5.3 ... 9.5/6.7;  N 512 K 2048: 17.6/9.3 17.8/9.5
+// 18.1/13.3 18.5/17.5 18.7/21.3 (the 32 x 32 wave runs 256 dependent MFMAs whatever M is);  N 1536 K 512: 7.6/5.5 7.8/6.9 10.9/9.9
+// 11.2/13.0 16.6/16.7;  N 2048 K 512: 8.7/6.0 8.9/8.2 12.1/12.9 18.9/17.3 22.2/21.9;  N 1024 K 512: 7.5/4.6 7.7/5.6 7.8/7.9 10.7/9.6
+// 10.8/12.2.  16 x 16 tiles win while their four-fold workgroup count still fits the chip a few times over; the crossover
+// moves down with the bytes each workgroup pulls (K).
+static bool kp16_rule(int M, int N, int K, long tiles16) {
+    if (N <= 512 && K <= 1024) return true;                 // narrow outputs: always (M < 512 here)
+    if (K > 1024) return M <= 320;                          // long reductions: the 32 x 32 chain is the cost until the grid is full
+    if (N == 1024) return M <= 320;
+    return tiles16 <= 1300;                                 // wide outputs (q|k|v, feed-forward in)
+}
 static KSplitTile kp_tile(int M, int N, int K) {
     const int band = M < 900 ? 0 : M < 1800 ? 1 : M < 2800 ? 2 : 3;
     struct Row { int n, k; int t[4][2]; };
@@ -1346,6 +1361,16 @@ static KSplitTile kp_tile(int M, int N, int K) {
         if (r.n == N && r.k == K) return KSplitTile{r.t[band][0], r.t[band][1], 104};
     if (N == 256 && K == 256) return M < 4000 ? KSplitTile{2, 1, 104} : M < 9000 ? KSplitTile{2, 2, 104} : KSplitTile{2, 1, 104};   // stem pointwise
     return ksplit_tile(M, N, K, true);
+}
+// below 512 rows: 16 x 16 tiles (four times the workgroups, a quarter of the dependent MFMA chain per wave) or 32 x 32 tiles?
+// force_kernel 6 / 7 (diagnostics): 16 x 16 / 32 x 32 whatever the shape.  WLK_KP16=0 / 1 overrides the rule.
+static bool kp_takes_16(int M, int N, int K, int force) {
+    if (force == 6) return true;
+    if (force == 7) return false;
+    static const int env = [] { const char* e = getenv("WLK_KP16"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    if (env >= 0) return env == 1;
+    const long tiles16 = (long)((N + 15) / 16) * ((M + 15) / 16);
+    return kp16_rule(M, N, K, tiles16);
 }
 bool gemm_kp_takes_kpipe(int M, int N, int K) { return K % 128 == 0 && K >= 256 && M >= 512 && ksplit_tile(M, N, K, true).tm != 0; }
 void launch_gemm_kp(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
@@ -1365,6 +1390,9 @@ void launch_gemm_kp(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
         KSplitTile kt = kp_tile(g.M, g.N, g.K);
         if (g.force_kernel >= 500) kt = KSplitTile{(g.force_kernel - 500) / 10, (g.force_kernel - 500) % 10, 104};   // tile probe
         if (!dispatch_kpipe(ctx, g, kt.tm, kt.tn, kt.ks)) throw std::logic_error("gemm: k-pipe tile without an instantiation");
+    } else if (kp_takes_16(g.M, g.N, g.K, g.force_kernel)) {
+        const long tiles16 = (long)((g.N + 15) / 16) * ((g.M + 15) / 16);
+        hipLaunchKernelGGL((gemm_nt_f32_kwave16_kernel<0, true>), dim3((unsigned)tiles16), dim3(256), 0, ctx.stream, g);
     } else {
         const long tiles32 = (long)((g.N + 31) / 32) * ((g.M + 31) / 32);
         hipLaunchKernelGGL(gemm_nt_f32_kwave_kernel<true>, dim3((unsigned)tiles32), dim3(256), 0, ctx.stream, g);

@@ -504,6 +504,10 @@ __global__ __launch_bounds__(XW_THREADS) void gemm_x3_wide_kernel(X3GemmArgs g) 
                         v[e] = acc[i][4 * j + e] + bias[j][e];
                         if (scaled(col0 + 8 * j + e)) v[e] *= g.scale;
                     }
+                    if (g.flags & kGemmGelu) {       // round 6: fc1 of the d >= 1024 models hands fc2 its X3 operand directly
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    }
                     *reinterpret_cast<xf32x4*>(srow + 8 * j) = v;
                 }
             }
@@ -578,7 +582,7 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
         throw std::invalid_argument("x3 gemm: bias, C and R must be 16-byte aligned");
     if (g.batch > 0 && ((uintptr_t)g.bias & 15)) throw std::invalid_argument("x3 gemm: bias must be 16-byte aligned");
     if (g.flags & ~(kGemmGelu | kGemmResidual | kGemmScaleCols)) throw std::invalid_argument("x3 gemm: unsupported epilogue flag");
-    if (g.x3_out && ((g.flags & (kGemmGelu | kGemmResidual)) || g.vt_col0 % XW_BN != 0 || g.ldc3 % 8 != 0 || g.vt_ld % 32 != 0 ||
+    if (g.x3_out && ((g.flags & kGemmResidual) || g.vt_col0 % XW_BN != 0 || g.ldc3 % 8 != 0 || g.vt_ld % 32 != 0 ||
                      g.vt_ld < g.M))
         throw std::invalid_argument("x3 gemm: unsupported X3 result layout");
     static std::atomic<uint64_t> configured{0};

@@ -79,6 +79,7 @@ struct LayerW {
     // encoder layers: the wide projections' weights in the X3 format (x3.h), packed by wlk_model_finalize; nullptr = the
     // shape stays on the fp32-MFMA kernels
     const unsigned short *qkvw3 = nullptr, *fc1w3 = nullptr;
+    const unsigned short *outw3 = nullptr, *fc2w3 = nullptr;      // round 6: the N = d projections where d >= 1024 (medium, large)
 };
 
 template <typename T>
@@ -197,6 +198,7 @@ struct wlk_session {
     // X3 images (three bf16 planes) of the LayerNorm outputs that feed the bf16-MFMA projections (gemm_x3.hip); enc_out3
     // replaces enc_out when the cross-attention K|V projection takes that path (wlk_export("enc") unpacks it)
     unsigned short *eh3 = nullptr, *enc_out3 = nullptr;
+    unsigned short* emlp3 = nullptr;      // X3 image of the MLP's hidden activations [T][4 d] (operand of an X3 fc2; round 6)
     bool enc_out_is_x3 = false;
     // operand image of the X3 encoder attention (attention_x3.hip): q | k as X3 rows, V^T behind them; written by the qkv
     // projection's epilogue.  Zero-initialised once: the padding keys of V^T are never written and must stay finite.
