@@ -506,7 +506,7 @@ __global__ __launch_bounds__(XW_THREADS) void gemm_x3_wide_kernel(X3GemmArgs g) 
                     }
                     if (g.flags & kGemmGelu) {       // round 6: fc1 of the d >= 1024 models hands fc2 its X3 operand directly
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                        for (int e = 0; e < 4; ++e) v[e] = x3_gelu_erf(v[e]);
                     }
                     *reinterpret_cast<xf32x4*>(srow + 8 * j) = v;
                 }
