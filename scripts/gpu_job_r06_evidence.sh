@@ -45,7 +45,14 @@ timeout 300 rocprofv3 --kernel-trace -d $R/$O/trace8 -o t -- python $R/scripts/e
 cd $R
 ( grep "^pass\|^{" $O/trace8.log; python scripts/trace_busy.py $(find $O/trace8 -name "*.db" | head -1) 900 ) > $O/trace8_busy.txt
 rm -rf $O/trace8
-python scripts/diar_probe8.py 8 30 8 2>&1 | grep rep > $O/cfg4_probe.txt; cat $O/cfg4_probe.txt | cut -c1-420
+( echo "# scripts/diar_probe8.py <diarizer sessions> 30 <ASR streams>: lanes (WLK_SF_WORKSPACES), stacking (WLK_SF_BATCH), front end inside the step or as three calls"
+  for v in "A=0" "WLK_SF_WORKSPACES=2" "WLK_SF_BATCH=1 WLK_SF_WORKSPACES=4" "PROBE_THREE_CALLS=1"; do
+    echo "== $v: 8 diarizer sessions alone"; env $v python scripts/diar_probe8.py 8 30 2>&1 | grep "rep 1"
+    echo "== $v: 8 diarizer sessions beside 8 base.en ASR streams (config 4)"; env $v python scripts/diar_probe8.py 8 30 8 2>&1 | grep "rep 1"
+  done ) > $O/diar_lanes.txt; cut -c1-420 $O/diar_lanes.txt
+python scripts/kp_tile_probe.py > $O/kp_tile_probe.txt 2>&1
+X3_PROBE_NARROW=1 python scripts/x3_probe.py 2>&1 | grep -v amdgpu.ids > $O/x3_narrow_probe.txt
+python scripts/x3_probe.py 2>&1 | grep -v amdgpu.ids > $O/x3_probe.txt
 python - <<PY
 import json
 d=json.loads(open("$O/bench_driver_cmd.json").read().strip().splitlines()[-1]); e=d.get("eight_streams") or {}; l=d.get("large_v3") or {}
