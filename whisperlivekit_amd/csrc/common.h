@@ -503,9 +503,10 @@ void launch_sf_attention(const LaunchCtx& ctx, const SfAttnArgs& a);
 void launch_sf_glu_dwconv(const LaunchCtx& ctx, const float* in, const float* w, const float* b, const float* bn_mean,
                           const float* bn_invstd, const float* bn_w, const float* bn_b, float* out, const SfSegments& rows, int d,
                           int taps);
-// relu -> Linear(d,d)+relu -> Linear(d,n_spk) -> sigmoid
-void launch_sf_head(const LaunchCtx& ctx, const float* x, const float* w1, const float* b1, const float* w2,
+// relu -> Linear(d,d)+relu -> Linear(d,n_spk) -> sigmoid; w1t = the first Linear's weight TRANSPOSED ([in][out])
+void launch_sf_head(const LaunchCtx& ctx, const float* x, const float* w1t, const float* b1, const float* w2,
                     const float* b2, float* out, int T, int d, int n_spk);
+void launch_sf_transpose(const LaunchCtx& ctx, const float* src, float* dst, int rows, int cols);
 
 // ---- select.hip -----------------------------------------------------------------------------
 // adjustments (may be n_adj = 0) are applied to the logits in place before the reduction

@@ -17,7 +17,9 @@ namespace wlk {
 
 constexpr int kMaxFft = 512;
 
-__global__ __launch_bounds__(256) void melspec_frame_kernel(MelSpecArgs a) {
+// 320 threads: n_fft / 2 + 1 = 257 frequency bins in ONE pass (with 256 threads bin 256 was a second 512-step fp64 loop of
+// thread 0 alone - the whole launch waited for it: 51 us per 101 frames; round 6)
+__global__ __launch_bounds__(320) void melspec_frame_kernel(MelSpecArgs a) {
     __shared__ double tw[kMaxFft];
     __shared__ float xw[kMaxFft];
     __shared__ float power[kMaxFft / 2 + 4];
@@ -25,7 +27,7 @@ __global__ __launch_bounds__(256) void melspec_frame_kernel(MelSpecArgs a) {
     const int tid = threadIdx.x;
     const int n_freq = a.n_fft / 2 + 1;
     const int wlo = (a.n_fft - a.win_length) / 2;
-    for (int n = tid; n < a.n_fft; n += 256) {
+    for (int n = tid; n < a.n_fft; n += blockDim.x) {
         tw[n] = a.twiddle[n];
         const int j = a.hop * t - a.n_fft / 2 + n;          // centre=True, constant (zero) padding
         float s = 0.f;
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(256) void melspec_frame_kernel(MelSpecArgs a) {
         xw[n] = (wi >= 0 && wi < a.win_length) ? s * a.window[wi] : 0.f;
     }
     __syncthreads();
-    for (int k = tid; k < n_freq; k += 256) {
+    for (int k = tid; k < n_freq; k += blockDim.x) {
         double re = 0.0, im = 0.0;
         int idx = 0;
         const int quarter3 = (3 * a.n_fft) / 4;
@@ -67,7 +69,7 @@ void launch_melspec(const LaunchCtx& ctx, const MelSpecArgs& a, int n_frames) {
     if (n_frames <= 0) return;
     if (a.n_fft > kMaxFft || a.n_fft % 4 != 0 || a.n_mels > 256) throw std::invalid_argument("melspec: unsupported size");
     KernelScope ks(ctx, "melspec_frames", 0.0, 4.0 * a.n_samples + 4.0 * n_frames * a.n_mels);
-    hipLaunchKernelGGL(melspec_frame_kernel, dim3(n_frames), dim3(256), 0, ctx.stream, a);
+    hipLaunchKernelGGL(melspec_frame_kernel, dim3(n_frames), dim3(320), 0, ctx.stream, a);
     WLK_HIP(hipGetLastError());
 }
 

@@ -481,8 +481,11 @@ void launch_sf_glu_dwconv(const LaunchCtx& ctx, const float* in, const float* w,
 }
 
 // ---- SortformerModules.forward_speaker_sigmoids (eval): relu -> Linear+relu -> Linear -> sigmoid ------------------
-// one workgroup per frame; the two small matrices stay in L2
-__global__ __launch_bounds__(256) void sf_head_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+// One workgroup per frame, one THREAD per hidden unit: w1t is the first Linear's weight transposed at finalize ([k][n]), so the
+// d threads read one coalesced row per k and the frame's relu(x) values come out of LDS as broadcasts - d fma per thread, no
+// cross-lane reduction (round 1 gave every hidden unit a wave and folded it with shuffles: 68 us per launch at 293 frames;
+// this form: the launch floor).  The n_spk outputs: one wave each, lane-strided products folded by shuffles.
+__global__ __launch_bounds__(256) void sf_head_kernel(const float* __restrict__ x, const float* __restrict__ w1t,
                                                       const float* __restrict__ b1, const float* __restrict__ w2,
                                                       const float* __restrict__ b2, float* __restrict__ out, int d,
                                                       int n_spk) {
@@ -492,12 +495,10 @@ __global__ __launch_bounds__(256) void sf_head_kernel(const float* __restrict__ 
     const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = threadIdx.x; c < d; c += blockDim.x) xs[c] = fmaxf(x[(long)t * d + c], 0.f);
     __syncthreads();
-    for (int n = wave; n < d; n += 4) {            // a wave per hidden unit: coalesced weight rows
+    for (int n = threadIdx.x; n < d; n += blockDim.x) {
         float acc = 0.f;
-        for (int c = lane; c < d; c += 64) acc = fmaf(xs[c], w1[(long)n * d + c], acc);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if (lane == 0) hs[n] = fmaxf(acc + b1[n], 0.f);
+        for (int k = 0; k < d; ++k) acc = fmaf(xs[k], w1t[(long)k * d + n], acc);
+        hs[n] = fmaxf(acc + b1[n], 0.f);
     }
     __syncthreads();
     for (int n = wave; n < n_spk; n += 4) {
@@ -509,12 +510,26 @@ __global__ __launch_bounds__(256) void sf_head_kernel(const float* __restrict__ 
     }
 }
 
-void launch_sf_head(const LaunchCtx& ctx, const float* x, const float* w1, const float* b1, const float* w2,
+void launch_sf_head(const LaunchCtx& ctx, const float* x, const float* w1t, const float* b1, const float* w2,
                     const float* b2, float* out, int T, int d, int n_spk) {
     if (T <= 0) return;
     KernelScope ks(ctx, "sf_head", 2.0 * T * d * (d + n_spk), 4.0 * T * (d + n_spk));
-    hipLaunchKernelGGL(sf_head_kernel, dim3(T), dim3(256), 2 * d * sizeof(float), ctx.stream, x, w1, b1, w2, b2, out, d,
+    hipLaunchKernelGGL(sf_head_kernel, dim3(T), dim3(256), 2 * d * sizeof(float), ctx.stream, x, w1t, b1, w2, b2, out, d,
                        n_spk);
+    WLK_HIP(hipGetLastError());
+}
+
+// [rows][cols] -> [cols][rows] (finalize-time weight transposes)
+__global__ void sf_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+    dst[(long)c * rows + r] = src[i];
+}
+void launch_sf_transpose(const LaunchCtx& ctx, const float* src, float* dst, int rows, int cols) {
+    const long n = (long)rows * cols;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(sf_transpose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx.stream, src, dst, rows, cols);
     WLK_HIP(hipGetLastError());
 }
 

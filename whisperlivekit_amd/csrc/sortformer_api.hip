@@ -178,6 +178,7 @@ struct wlk_sortformer {
     int last_ws = 0;                      // the lane of the most recent step (exports)
     uint64_t n_steps = 0, n_sessions = 0, n_rows = 0;     // stacked steps run / session steps in them / rows in them
     float* pos_full = nullptr;            // read-only after finalize
+    float* head_w1t = nullptr;            // head.h.w transposed ([in][out]) at finalize: coalesced rows for sf_head_kernel
     std::vector<float*> owned;
     std::vector<float*> pinned;
     const float* P(const std::string& n) const {
@@ -275,7 +276,7 @@ static void sf_network(wlk_sortformer* m, wlk_sortformer::Lane* w_, const Launch
         sf_linear(c, w_->th, inner, w.outd_w, w.outd_b, w_->ty, dt, T, dt, inner, kGemmResidual, w_->tx, dt, "sf_tf_outd");
         launch_layernorm(c, w_->ty, dt, w.ln2_w, w.ln2_b, w_->tx, dt, T, dt, "sf_ln");
     }
-    launch_sf_head(c, w_->tx, m->P("head.h.w"), m->P("head.h.b"), m->P("head.s.w"), m->P("head.s.b"), w_->preds, T, dt,
+    launch_sf_head(c, w_->tx, m->head_w1t, m->P("head.h.b"), m->P("head.s.w"), m->P("head.s.b"), w_->preds, T, dt,
                    D.n_spk);
 }
 
@@ -415,6 +416,7 @@ int wlk_sf_create(const wlk_sf_dims* dims, int device, wlk_sortformer** out) {
         const size_t L = D.max_frames, d = D.fc_d_model, dt = D.tf_d_model, C = D.sub_channels;
         const size_t T1 = sf_sub_len(D.max_feat_frames), F1 = sf_sub_len(D.n_mels);
         m->pos_full = sf_alloc(p, (size_t)std::max(D.fc_layers, 1) * (2 * L - 1) * d);
+        m->head_w1t = sf_alloc(p, dt * dt);
         // ONE lane by default (measured, scripts/diar_probe8.py, profiles/r06_diar_lanes.txt): with stacked steps a second lane
         // only splits the waiting sessions over two half-size chains that then share the GPU - 8 diarizer sessions alone
         // 642 audio-s/s on one lane against 516 on two, and beside 8 ASR streams the ASR side 250 against 216
@@ -535,6 +537,7 @@ int wlk_sf_finalize(wlk_sortformer* m) {
             g.M = rows; g.N = d; g.K = d;
             launch_linear(c, g, "sf_pos");
         }
+        launch_sf_transpose(c, m->P("head.h.w"), m->head_w1t, D.tf_d_model, D.tf_d_model);
         WLK_HIP(hipStreamSynchronize(m->ws[0].stream));
         m->finalized = true;
         return WLK_OK;
