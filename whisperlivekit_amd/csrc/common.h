@@ -214,6 +214,7 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag);
 // the "kp" family: one per-element arithmetic (the k-pipe kernel's) for every tile, so stacked rows keep their solo results
 void launch_gemm_kp(const LaunchCtx& ctx, const GemmArgs& g, const char* tag);
 bool gemm_kp_takes_kpipe(int M, int N, int K);
+bool gemm_kp_fuses_layernorm(int M, int N, int K);   // launch_gemm_kp takes ln_gamma / ln_beta for this problem (rows < 512, K = 512)
 bool gemm_takes_kwave(int M, int N, int K);
 bool gemm_takes_ksplit(int M, int N, int K);  // ... for the one-tile-per-CU k-split kernel (encoder-sized problems)   // launch_gemm's shape rule for the k-wave kernel (under-filled grids)
 // weight-streaming path for M <= 8 rows (decode steps); same contract as launch_gemm

@@ -1372,11 +1372,31 @@ static bool kp_takes_16(int M, int N, int K, int force) {
     const long tiles16 = (long)((N + 15) / 16) * ((M + 15) / 16);
     return kp16_rule(M, N, K, tiles16);
 }
+// Can launch_gemm_kp take the LayerNorm in front (GemmArgs::ln_gamma / ln_beta, A = the un-normalised rows)?  Opt-in
+// (WLK_SF_LN_FUSE=1): measured a LOSS on the single-session Sortformer step (68 launches less per chunk, bit-identical, but 4.13 ms
+// per chunk against 3.89: hundreds of workgroups re-deriving the statistics of their rows cost more than the 4.5 us launches they
+// replace - the third time this trade was measured, after the encoder's large tiles in round 1 and the prefill in round 4).
+bool gemm_kp_fuses_layernorm(int M, int N, int K) {
+    static const bool on = [] { const char* e = getenv("WLK_SF_LN_FUSE"); return e && e[0] == '1'; }();
+    (void)N;
+    return on && K == 512 && M > 0 && M < 512;
+}
 bool gemm_kp_takes_kpipe(int M, int N, int K) { return K % 128 == 0 && K >= 256 && M >= 512 && ksplit_tile(M, N, K, true).tm != 0; }
 void launch_gemm_kp(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if (g.M <= 0 || g.N <= 0) return;
     if (g.K % 4 != 0 || g.lda % 4 != 0) throw std::invalid_argument("gemm: K and lda must be multiples of 4");
-    if (g.batch > 0 || g.kcache || g.ln_gamma) throw std::invalid_argument("gemm (kp family): plain projections only");
+    if (g.batch > 0 || g.kcache) throw std::invalid_argument("gemm (kp family): plain projections only");
+    if (g.ln_gamma) {
+        // the LayerNorm in front of the projection inside the 16 x 16 kernel (gemm_nt_f32_kwave16_kernel<NPL, true>: every workgroup
+        // derives layernorm_kernel's statistics of its sixteen rows while the first slabs are in flight) - bit for bit the separate
+        // launch, one kernel boundary less.  Rows < 512, K = 512 only (gemm_kp_fuses_layernorm); the stacked steps keep the launch.
+        if (!gemm_kp_fuses_layernorm(g.M, g.N, g.K)) throw std::invalid_argument("gemm (kp family): this shape does not take the LayerNorm");
+        KernelScope ks(ctx, tag, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+        const long tiles16 = (long)((g.N + 15) / 16) * ((g.M + 15) / 16);
+        hipLaunchKernelGGL((gemm_nt_f32_kwave16_kernel<8, true>), dim3((unsigned)tiles16), dim3(256), 0, ctx.stream, g);
+        WLK_HIP(hipGetLastError());
+        return;
+    }
     if (g.K % 128 != 0 || g.K < 256) {
         GemmArgs p = g;
         p.force_kernel = 3;

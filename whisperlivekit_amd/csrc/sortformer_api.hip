@@ -215,6 +215,22 @@ static void sf_linear(const LaunchCtx& c, const float* A, long lda, const float*
     launch_gemm_kp(c, g, tag);
 }
 
+// LayerNorm + projection: ONE launch while the rows are few (a single session's step: the 16 x 16 kernel normalises its A rows
+// itself, bit for bit layernorm_kernel's values), LayerNorm launch + projection from 512 rows on (stacked steps: the k-pipe tiles
+// take their operands by LDS-DMA and cannot normalise them on the way).  Same results either way.
+static void sf_ln_linear(const LaunchCtx& c, const float* x, const float* lnw, const float* lnb, float* xn, const float* W,
+                         const float* b, float* C, long ldc, int M, int N, int K, int flags, const char* tag) {
+    if (gemm_kp_fuses_layernorm(M, N, K)) {
+        GemmArgs g;
+        g.A = x; g.lda = K; g.W = W; g.bias = b; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.flags = flags;
+        g.ln_gamma = lnw; g.ln_beta = lnb;
+        launch_gemm_kp(c, g, tag);
+    } else {
+        launch_layernorm(c, x, K, lnw, lnb, xn, K, M, K, "sf_ln");
+        sf_linear(c, xn, K, W, b, C, ldc, M, N, K, flags, nullptr, 0, tag);
+    }
+}
+
 static void sf_set_segments(SfAttnArgs& a, const SfSegments& rows) {
     a.n_seg = rows.n;
     a.T = 0;
@@ -233,12 +249,10 @@ static void sf_network(wlk_sortformer* m, wlk_sortformer::Lane* w_, const Launch
     for (int l = 0; l < D.fc_layers; ++l) {
         const SfFcLayer& w = m->fc[l];
         // x += 0.5 * FF1(LN(x))   (the 0.5 is folded into ff1b at pack time: exact, a power of two)
-        launch_layernorm(c, w_->x, d, w.ln_ff1_w, w.ln_ff1_b, w_->xn, d, T, d, "sf_ln");
-        sf_linear(c, w_->xn, d, w.ff1a_w, w.ff1a_b, w_->wide, ff, T, ff, d, kGemmSwish, nullptr, 0, "sf_ff_a");
+        sf_ln_linear(c, w_->x, w.ln_ff1_w, w.ln_ff1_b, w_->xn, w.ff1a_w, w.ff1a_b, w_->wide, ff, T, ff, d, kGemmSwish, "sf_ff_a");
         sf_linear(c, w_->wide, ff, w.ff1b_w, w.ff1b_b, w_->x, d, T, d, ff, kGemmResidual, w_->x, d, "sf_ff_b");
         // x += RelPosMHA(LN(x))
-        launch_layernorm(c, w_->x, d, w.ln_att_w, w.ln_att_b, w_->xn, d, T, d, "sf_ln");
-        sf_linear(c, w_->xn, d, w.qkv_w, w.qkv_b, w_->qkv, 3 * d, T, 3 * d, d, 0, nullptr, 0, "sf_qkv");
+        sf_ln_linear(c, w_->x, w.ln_att_w, w.ln_att_b, w_->xn, w.qkv_w, w.qkv_b, w_->qkv, 3 * d, T, 3 * d, d, 0, "sf_qkv");
         SfAttnArgs a;
         a.q = w_->qkv; a.k = w_->qkv + d; a.v = w_->qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
         a.out = w_->att; a.ldo = d; a.n_head = D.fc_heads; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
@@ -248,13 +262,11 @@ static void sf_network(wlk_sortformer* m, wlk_sortformer::Lane* w_, const Launch
         launch_sf_attention(c, a);
         sf_linear(c, w_->att, d, w.out_w, w.out_b, w_->x, d, T, d, d, kGemmResidual, w_->x, d, "sf_att_out");
         // x += Conv(LN(x))
-        launch_layernorm(c, w_->x, d, w.ln_conv_w, w.ln_conv_b, w_->xn, d, T, d, "sf_ln");
-        sf_linear(c, w_->xn, d, w.pw1_w, w.pw1_b, w_->wide, 2 * d, T, 2 * d, d, 0, nullptr, 0, "sf_conv_pw1");
+        sf_ln_linear(c, w_->x, w.ln_conv_w, w.ln_conv_b, w_->xn, w.pw1_w, w.pw1_b, w_->wide, 2 * d, T, 2 * d, d, 0, "sf_conv_pw1");
         launch_sf_glu_dwconv(c, w_->wide, w.dw_w, w.dw_b, w.bn_mean, w.bn_invstd, w.bn_w, w.bn_b, w_->att, rows, d, D.conv_kernel);
         sf_linear(c, w_->att, d, w.pw2_w, w.pw2_b, w_->x, d, T, d, d, kGemmResidual, w_->x, d, "sf_conv_pw2");
         // x += 0.5 * FF2(LN(x)); x = LN_out(x)
-        launch_layernorm(c, w_->x, d, w.ln_ff2_w, w.ln_ff2_b, w_->xn, d, T, d, "sf_ln");
-        sf_linear(c, w_->xn, d, w.ff2a_w, w.ff2a_b, w_->wide, ff, T, ff, d, kGemmSwish, nullptr, 0, "sf_ff_a");
+        sf_ln_linear(c, w_->x, w.ln_ff2_w, w.ln_ff2_b, w_->xn, w.ff2a_w, w.ff2a_b, w_->wide, ff, T, ff, d, kGemmSwish, "sf_ff_a");
         sf_linear(c, w_->wide, ff, w.ff2b_w, w.ff2b_b, w_->x, d, T, d, ff, kGemmResidual, w_->x, d, "sf_ff_b");
         launch_layernorm(c, w_->x, d, w.ln_out_w, w.ln_out_b, w_->x, d, T, d, "sf_ln");
     }
