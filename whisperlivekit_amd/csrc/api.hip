@@ -845,6 +845,8 @@ extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const
                                       [](wlk_session* s) { return reinterpret_cast<float*>(s->eqkv3); }, none);
     const PtrTable z_qkv3_att = table([](wlk_session* s) { return reinterpret_cast<const float*>(s->eqkv3); },
                                       [](wlk_session* s) { return s->eatt; }, none);
+    const PtrTable z_qkv3_eh3 = table([](wlk_session* s) { return reinterpret_cast<const float*>(s->eqkv3); },
+                                      [](wlk_session* s) { return reinterpret_cast<float*>(s->eh3); }, none);
     const PtrTable z_eh3_ex_res = table([](wlk_session* s) { return reinterpret_cast<const float*>(s->eh3); }, [](wlk_session* s) { return s->ex; },
                                         [](wlk_session* s) { return (const float*)s->ex; });
     const PtrTable z_eh3_mlp3 = table([](wlk_session* s) { return reinterpret_cast<const float*>(s->eh3); },
@@ -865,6 +867,7 @@ extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const
         GemmArgs g;
         g.lda = d; g.W = L.qkvw; g.bias = L.qkvb; g.ldc = 3 * d; g.M = T; g.N = 3 * d;
         g.K = d; g.flags = kGemmScaleCols; g.scale = scale; g.scale_cols = 2 * d;
+        bool att_is_x3 = false;
         if (L.qkvw3 && attn_x3) {
             // q | k | v leave the projection as the X3 operand image of the bf16-MFMA attention (V transposed, keys in the
             // order a lane of that kernel holds its probabilities): no fp32 qkv is written at all
@@ -874,8 +877,11 @@ extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const
             x.scale_cols = g.scale_cols; x.batch = B; x.z = z_eh3_qkv3;
             x.x3_out = true; x.ldc3 = 2 * d; x.vt_col0 = 2 * d; x.vt_off = x3_attn_vt_off(T, d); x.vt_ld = x3_attn_vt_ld(T);
             launch_gemm_x3(c, x, "enc_qkv_x3");
+            // (d >= 1024: the out projection runs on the X3 kernel, and the attention writes its rows in that format itself -
+            // into the LayerNorm image, which is dead once the qkv projection has read it)
+            att_is_x3 = L.outw3 != nullptr;
             launch_encoder_attention_x3(c, nullptr, 2L * d, x3_attn_vt_off(T, d), x3_attn_vt_ld(T), nullptr, d, T, d, D.n_audio_head,
-                                        &z_qkv3_att, B);
+                                        att_is_x3 ? &z_qkv3_eh3 : &z_qkv3_att, B, att_is_x3);
         } else {
             if (L.qkvw3) {
                 launch_layernorm_x3_batched(c, z_ex_eh3, B, d, L.ln1w, L.ln1b, d, T, d, "enc_ln1");
@@ -891,7 +897,8 @@ extern "C++" void wlk_encode_group(const std::vector<wlk_session*>& group, const
         o.flags = kGemmResidual; o.ldr = d;
         if (L.outw3) {
             // d >= 1024: the attention output goes through the X3 kernel too - packed into the (dead by now) LayerNorm image
-            for (int i = 0; i < B; ++i) launch_x3_pack(c, group[i]->eatt, d, group[i]->eh3, d, T, d);
+            if (!att_is_x3)
+                for (int i = 0; i < B; ++i) launch_x3_pack(c, group[i]->eatt, d, group[i]->eh3, d, T, d);
             gemm_x3(o, L.outw3, z_eh3_ex_res, "enc_out_x3");
         } else {
             gemm(o, z_att_ex, "enc_out");

@@ -78,6 +78,8 @@ struct AttnX3Args {
     long ldo;
     int T, d, n_head;
     int batch;
+    int x3_out;                  // round 6: != 0 -> `out` (z.out[i]) is an X3 row image [T][ldo] (three bf16 planes, x3.h) instead of
+                                 // fp32 rows: the operand of an X3 out projection (d >= 1024 models), no fp32 copy, no pack launch
     PtrTable z;                  // batched encodes: qk3 = z.in[i], out = z.out[i]
 };
 
@@ -293,7 +295,25 @@ __global__ __launch_bounds__(512) void enc_attention_x3_kernel(AttnX3Args a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    {
+    if (a.x3_out) {
+        // one (query, 8-feature chunk) per thread: 64 queries x 8 chunks = the 512 threads; same merge arithmetic per element
+        const int tid = threadIdx.x;
+        const int q = tid >> 3, ch = tid & 7;
+        const int qrow = q0 + q;
+        const int w0 = q >> 4, w1 = w0 + 4;
+        const float m0 = Ms[w0 * 16 + (q & 15)], m1 = Ms[w1 * 16 + (q & 15)];
+        const float M = fmaxf(m0, m1);
+        const float e0 = m0 == -INFINITY ? 0.f : expf(m0 - M), e1 = m1 == -INFINITY ? 0.f : expf(m1 - M);
+        const float L = e0 * Ls[w0 * 16 + (q & 15)] + e1 * Ls[w1 * 16 + (q & 15)];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int dd = 8 * ch + e;
+            v[e] = (e0 * Os[(w0 * 16 + (q & 15)) * O_LD + dd] + e1 * Os[(w1 * 16 + (q & 15)) * O_LD + dd]) / L;
+        }
+        if (qrow < T)
+            x3_store_chunk(reinterpret_cast<unsigned short*>(aout) + (long)qrow * 3 * a.ldo + (long)(head * 8 + ch) * 24, v);
+    } else {
         const int tid = threadIdx.x;       // 0 .. 511
         const int dd = tid & 63, qg = tid >> 6;
 #pragma unroll
@@ -353,7 +373,7 @@ bool enc_attention_x3_enabled() {
 }
 
 void launch_encoder_attention_x3(const LaunchCtx& ctx, const unsigned short* qk3, long ldqk, long vt_off, long vt_ld, float* out,
-                                 long ldo, int T, int d, int n_head, const PtrTable* z, int batch) {
+                                 long ldo, int T, int d, int n_head, const PtrTable* z, int batch, bool x3_out) {
     if (d != n_head * 64 || ldqk % 8 != 0 || vt_ld % 32 != 0 || vt_ld < ((T + 31) / 32) * 32 || T < 64)
         throw std::invalid_argument("x3 attention: unsupported shape");
     static std::atomic<uint64_t> configured{0};
@@ -369,6 +389,8 @@ void launch_encoder_attention_x3(const LaunchCtx& ctx, const unsigned short* qk3
     AttnX3Args a{};
     a.qk3 = qk3; a.ldqk = ldqk; a.vt_off = vt_off; a.vt_ld = vt_ld; a.out = out; a.ldo = ldo; a.T = T; a.d = d; a.n_head = n_head;
     a.batch = batch;
+    a.x3_out = x3_out ? 1 : 0;
+    if (x3_out && ldo % 8 != 0) throw std::invalid_argument("x3 attention: X3 result rows need ldo % 8 == 0");
     if (batch > 0) a.z = *z;
     const int q_tiles = (T + AX_QT - 1) / AX_QT;
     KernelScope ks(ctx, "enc_attention_x3", (batch > 0 ? batch : 1) * 4.0 * (double)T * T * 64 * n_head, 0.0);

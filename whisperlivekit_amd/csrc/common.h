@@ -281,7 +281,7 @@ inline long x3_attn_vt_off(int T, int d) { return (long)T * 3 * 2 * d; }        
 inline size_t x3_attn_image_elems(int T, int d) { return (size_t)x3_attn_vt_off(T, d) + (size_t)d * 3 * x3_attn_vt_ld(T); }
 bool enc_attention_x3_enabled();
 void launch_encoder_attention_x3(const LaunchCtx& ctx, const unsigned short* qk3, long ldqk, long vt_off, long vt_ld, float* out,
-                                 long ldo, int T, int d, int n_head, const PtrTable* z, int batch);
+                                 long ldo, int T, int d, int n_head, const PtrTable* z, int batch, bool x3_out = false);
 void launch_x3_pack_qkv(const LaunchCtx& ctx, const float* qkv, unsigned short* out, int T, int d, long vt_off, long vt_ld);
 
 // ---- layernorm.hip --------------------------------------------------------------------------
