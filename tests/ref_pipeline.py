@@ -68,7 +68,7 @@ def make_asr(model_name: str, hip_model, **cfg_over):
                            mlx_encoder=None, fw_encoder=None, tokenizer=None, sep=" ")
 
 
-def make_engine(asr, diarization_model=None, vac: bool = False, **cfg):
+def make_engine(asr, diarization_model=None, vac: bool = False, translation_model=None, **cfg):
     """A TranscriptionEngine INSTANCE of the reference's own class without running its loader; ``args`` is what the
     reference derives from its own config dataclass."""
     install()
@@ -86,7 +86,7 @@ def make_engine(asr, diarization_model=None, vac: bool = False, **cfg):
     eng.tokenizer = None
     eng.diarization = None
     eng.diarization_model = diarization_model
-    eng.translation_model = None
+    eng.translation_model = translation_model      # a whisperlivekit_amd.translation.HipNllbTranslationModel (config 5) or None
     eng.vac_session = None
     return eng
 
@@ -112,8 +112,15 @@ def hip_routes(vad_weights=None):
         def online_diarization_factory(args, backend):
             return HipSortformerDiarizationOnline(shared_model=backend, max_speakers=getattr(args, "sortformer_max_speakers", None))
 
+        def online_translation_factory(args, translation_model):
+            # core.py:483-493 builds nllw.OnlineTranslation(model, [source], [target]); the HIP session takes the same two codes
+            # (the test tokenizer spells them as NLLB does: eng_Latn, fra_Latn, ...)
+            from whisperlivekit_amd.translation import online_translation_factory as hip_factory
+            return hip_factory(translation_model, args.lan, args.target_language)
+
         patches = [mock.patch.object(ap, "online_factory", online_factory),
-                   mock.patch.object(ap, "online_diarization_factory", online_diarization_factory)]
+                   mock.patch.object(ap, "online_diarization_factory", online_diarization_factory),
+                   mock.patch.object(ap, "online_translation_factory", online_translation_factory)]
         if vad_weights is not None:
             from whisperlivekit_amd import vad as V
 
@@ -146,6 +153,8 @@ class PipelineRun:
                                              #   word times rounded to 10 ms like the golden streams' comparison
         self.metrics = None                  # the reference's SessionMetrics
         self.front: List = []                # FrontData updates the formatter yielded
+        self.translations: List = []         # validated Translation pieces the translation worker published (state.new_translation)
+        self.translation_calls = 0           # device translations the session ran (HipOnlineTranslation.translations)
         self.diar_frames = 0                 # activity frames the session's diarizer produced
         self.end_attributed_speaker = 0.0    # State.end_attributed_speaker: how far the diarization worker got
         self.wall_s = 0.0
@@ -219,6 +228,9 @@ async def run_session(engine, pcm: bytes, chunk_s: float = 0.5, lockstep: bool =
             await asyncio.sleep(0.005)
         out.final_tokens = [t for t in proc.state.tokens if hasattr(t, "text")]
         out.metrics = proc.metrics
+        if proc.translation is not None:
+            out.translations = list(getattr(proc.tokens_alignment, "all_translation_segments", [])) + list(proc.state.new_translation)
+            out.translation_calls = int(getattr(proc.translation, "translations", 0))
         if proc.diarization is not None:
             out.diar_frames = int(proc.diarization.total_preds.shape[0])
             out.end_attributed_speaker = float(proc.state.end_attributed_speaker)

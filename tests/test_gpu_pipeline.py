@@ -163,3 +163,30 @@ def test_vac_gate_in_the_pipeline(caplog):
     assert abs(m.total_silence_duration_s - (12.0 - speech)) < 0.05, (m.total_silence_duration_s, speech)
     assert m.n_silence_events >= 1 and (m.n_transcription_calls >= 1) == (speech > 0)
     assert run.front
+
+
+def test_session_with_translation(caplog):
+    """Config 5's session shape: ASR tokens flow from the reference's transcription worker through its translation queue
+    (audio_processor.py:258-281, 887-920) into the HIP NLLB session (whisperlivekit_amd.translation.HipOnlineTranslation, the duck type
+    of nllw.OnlineTranslation) on the same GPU.  Seeded micro NLLB weights and the word-level stand-in tokenizer of
+    tests/test_translation.py (no SentencePiece model exists offline): what is checked is the plumbing - the ASR words are still the
+    golden stream's, every committed token reached the translation session, device translations ran, validated pieces (if the
+    hypotheses agreed) are ordered in time, no worker logged an exception."""
+    from test_translation import CFG, WordTokenizer
+    from whisperlivekit_amd import nllb, translation as T
+    model = nllb.HipNllbModel.synthetic(CFG, 0, device=0, max_src=92, max_tgt=64)
+    try:
+        tm = T.HipNllbTranslationModel(model, WordTokenizer(), max_new_tokens=16)
+        audio = H.stream_audio("bench_base_30s_s0")[: 24 * 8000]
+        want = golden_chunks("bench_base_30s_s0")[:24]
+        engine = RP.make_engine(RP.make_asr("base.en", hip_model("base.en")), translation_model=tm, lan="eng_Latn", target_language="fra_Latn")
+        with caplog.at_level(logging.WARNING, logger="whisperlivekit"):
+            run = asyncio.run(RP.run_session(engine, RP.pcm16_bytes(audio)))
+        assert not bad_records(caplog), bad_records(caplog)
+        assert [c[4] for c in run.calls] == want
+        n_words = sum(len(c) for c in want)
+        assert n_words > 0 and run.translation_calls >= 1, (n_words, run.translation_calls)
+        ends = [float(t.end) for t in run.translations if getattr(t, "end", None) is not None]
+        assert ends == sorted(ends)
+    finally:
+        model.close()
