@@ -106,6 +106,22 @@ int wlk_decode(wlk_session* s, const int64_t* tokens, int n_rows, int n_tok, int
 /* a6: AlignAtt._check_no_speech (simul_whisper.py:370-377): softmax(logits[:, sot_index])[token] */
 int wlk_no_speech_prob(wlk_session* s, int no_speech_token, float* probs_host /* [n_rows] */);
 
+/* f4 (batch `transcribe`): the per-step logit rules of whisper's DecodingTask and the greedy pick at temperature 0 for ONE
+ * sequence, on the device - SuppressBlank / SuppressTokens / ApplyTimestampRules (whisper/decoding.py:417-499) and
+ * GreedyDecoder.update (whisper/decoding.py:270-287).  wlk_rules_set uploads the two token lists of a DecodingTask
+ * (decoding.py:609-636 `_get_suppress_tokens`, :424 blank = encode(" ") + [eot]); wlk_pick_greedy applies the rules to the
+ * logits of the last wlk_decode and returns the chosen token and its log-probability (8 bytes instead of the logits row).
+ * The host derives the history-dependent fields from the sampled tokens exactly as ApplyTimestampRules.apply does:
+ *   ts_mode  0: the last sampled token is no timestamp; 1: the last two are timestamps (or only one token was sampled and
+ *            it is one) - timestamps are suppressed; 2: only the last one is - text tokens below eot are suppressed
+ *   ts_bound timestamps in [timestamp_begin, ts_bound) are suppressed (timestamp_begin = none)
+ *   max_initial  first step only: timestamps above timestamp_begin + max_initial are suppressed (-1 = no limit) */
+typedef struct wlk_pick_params {
+    int32_t first_step, without_timestamps, timestamp_begin, eot, no_timestamps /* -1 = none */, ts_mode, ts_bound, max_initial;
+} wlk_pick_params;
+int wlk_rules_set(wlk_session* s, const int32_t* suppressed, int n_suppressed, const int32_t* blank, int n_blank);
+int wlk_pick_greedy(wlk_session* s, const wlk_pick_params* p, int32_t* token_host, float* logprob_host);
+
 /* a6+a7+a8 in one launch group and ONE readback:
  *  - logits[row, ids[i]] += deltas[i] (-inf suppresses: SuppressTokens.apply whisper/decoding.py:427-432,
  *    _suppress_blank_tokens simul_whisper.py:379-381, DRY penalty align_att_base.py:492-537);

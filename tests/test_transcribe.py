@@ -72,15 +72,7 @@ class Replay:
         return torch.tensor(tokens, dtype=torch.int64)
 
 
-def check_case(case, model, monkeypatch):
-    replay = Replay(case["calls"])
-    monkeypatch.setattr(TR, "choose", replay)
-    kwargs = dict(case["kwargs"])
-    if isinstance(kwargs.get("temperature"), list):
-        kwargs["temperature"] = tuple(kwargs["temperature"])
-    got = TR.transcribe(model, make_audio(case["audio"]), **kwargs)
-    want = case["result"]
-    assert replay.at == len(replay.queue), f"{len(replay.queue) - replay.at} recorded greedy steps were not reached"
+def compare_result(got, want):
     assert got["language"] == want["language"]
     assert got["text"] == want["text"]
     assert len(got["segments"]) == len(want["segments"])
@@ -97,6 +89,21 @@ def check_case(case, model, monkeypatch):
             for a, b in zip(g["words"], w["words"]):
                 assert (a["start"], a["end"]) == (b["start"], b["end"]), (w["id"], a, b)
                 assert a["probability"] == pytest.approx(b["probability"], rel=2e-3, abs=1e-7)
+
+
+def check_case(case, model, monkeypatch):
+    replay = Replay(case["calls"])
+    monkeypatch.setattr(TR, "choose", replay)
+    # the replay follows the reference's choices through transcribe.choose, i.e. through the HOST form of the logit rules;
+    # the device form (wlk_pick_greedy) is checked against it in tests/test_gpu_transcribe_rules.py
+    monkeypatch.setenv("WLK_TRANSCRIBE_DEVICE_RULES", "0")
+    kwargs = dict(case["kwargs"])
+    if isinstance(kwargs.get("temperature"), list):
+        kwargs["temperature"] = tuple(kwargs["temperature"])
+    got = TR.transcribe(model, make_audio(case["audio"]), **kwargs)
+    want = case["result"]
+    assert replay.at == len(replay.queue), f"{len(replay.queue) - replay.at} recorded greedy steps were not reached"
+    compare_result(got, want)
     return replay
 
 

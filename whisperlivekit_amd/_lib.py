@@ -120,6 +120,8 @@ def _declare(lib: C.CDLL) -> None:
         "wlk_encode": (cint, [p, C.POINTER(i32)]),
         "wlk_decode": (cint, [p, p, cint, cint, cint, cint]),
         "wlk_no_speech_prob": (cint, [p, cint, p]),
+        "wlk_rules_set": (cint, [p, p, cint, p, cint]),
+        "wlk_pick_greedy": (cint, [p, p, p, p]),
         "wlk_select": (cint, [p, p, p, p, cint, cint, cint, p, p, p]),
         "wlk_kv_reorder": (cint, [p, p, cint]),
         "wlk_sync": (cint, [p]),
@@ -224,7 +226,7 @@ EXPORTED_SYMBOLS = (
     "wlk_model_set_alignment_heads", "wlk_model_finalize", "wlk_model_destroy", "wlk_session_create",
     "wlk_session_destroy", "wlk_session_set_debug", "wlk_audio_append", "wlk_audio_append_pcm16", "wlk_audio_append_zeros",
     "wlk_audio_drop_front", "wlk_audio_clear", "wlk_audio_len", "wlk_encode", "wlk_decode",
-    "wlk_no_speech_prob", "wlk_select", "wlk_kv_reorder", "wlk_sync", "wlk_decode_until_stop", "wlk_engine_attach", "wlk_engine_detach",
+    "wlk_no_speech_prob", "wlk_rules_set", "wlk_pick_greedy", "wlk_select", "wlk_kv_reorder", "wlk_sync", "wlk_decode_until_stop", "wlk_engine_attach", "wlk_engine_detach",
     "wlk_engine_stats", "wlk_engine_encode_stats", "wlk_engine_prefill_stats", "wlk_diag_prefill_stack", "wlk_job_create",
     "wlk_job_begin_step", "wlk_job_no_speech", "wlk_job_adjustments", "wlk_job_consume", "wlk_job_result",
     "wlk_job_destroy", "wlk_export", "wlk_session_step_stats", "wlk_prof_begin",

@@ -546,6 +546,14 @@ int wlk_session_destroy(wlk_session* s) {
     if (s->pinned) (void)hipHostFree(s->pinned);
     if (s->dec_stage) (void)hipHostFree(s->dec_stage);
     if (s->audio_stage) (void)hipHostFree(s->audio_stage);
+    if (s->pf_stream) {
+        (void)hipStreamSynchronize(s->pf_stream);
+        (void)hipStreamDestroy(s->pf_stream);
+    }
+    if (s->rules_mask) (void)hipFree(s->rules_mask);
+    if (s->pick_out) (void)hipFree(s->pick_out);
+    if (s->pf_table) (void)hipFree(s->pf_table);
+    if (s->pf_progress) (void)hipFree(s->pf_progress);
     if (s->audio_stage_ev) (void)hipEventDestroy(s->audio_stage_ev);
     if (s->dec_stage_ev) (void)hipEventDestroy(s->dec_stage_ev);
     if (s->step_host) (void)hipHostFree(s->step_host);
@@ -999,6 +1007,41 @@ int wlk_session::flash_splits() {
 // (tokens, alignment-window row map, cache offset) is read from the pinned staging block through
 // memcpy nodes / device scalars, so the single-token form of this sequence can be captured once
 // into a hipGraph and replayed.
+// The Infinity-Cache prefetcher beside a graph-replayed single-token step (decoder.hip: mall_prefetch_step_kernel).  OPT-IN
+// (WLK_MALL_PREFETCH=1): measured a loss on large-v3 - step 1.49 -> 1.70 ms, 14.9 -> 14.2 audio-s/s, 510 / 510 decisions either
+// way (profiles/r06k_mall_ab_large-v3.txt) - the second reader competes with the chain's own HBM reads instead of getting
+// ahead of them.  WLK_MALL_LEAD = layers the prefetcher may run ahead of the chain's last mark (default 0).
+static bool mall_prefetch_wanted(const wlk_model*) {
+    static const bool on = [] {
+        const char* e = getenv("WLK_MALL_PREFETCH");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+static int mall_prefetch_lead() {
+    static const int lead = [] {
+        const char* e = getenv("WLK_MALL_LEAD");
+        return e ? atoi(e) : 0;
+    }();
+    return lead;
+}
+static void mall_prefetch_prepare(wlk_session* s) {
+    if (!mall_prefetch_wanted(s->m) || s->pf_stream) return;
+    const wlk_model* m = s->m;
+    const int L = m->D.n_text_layer, d = m->D.n_text_state;
+    std::vector<TouchRanges> host((size_t)L);
+    const unsigned dd = (unsigned)((size_t)d * d / 4);
+    for (int i = 0; i < L; ++i) {
+        const LayerW& W = m->dec_layers[i];
+        host[(size_t)i] = TouchRanges{{W.qkvw, W.outw, W.xqw, W.xoutw, W.fc1w, W.fc2w}, {3 * dd, dd, dd, dd, 4 * dd, 4 * dd}};
+    }
+    WLK_HIP(hipStreamCreateWithFlags(&s->pf_stream, hipStreamNonBlocking));
+    s->pf_table = dev_alloc<TouchRanges>((size_t)L);
+    s->pf_progress = dev_alloc_zero<unsigned long long>(1, s->pf_stream);
+    WLK_HIP(hipMemcpyAsync(s->pf_table, host.data(), host.size() * sizeof(TouchRanges), hipMemcpyHostToDevice, s->pf_stream));
+    WLK_HIP(hipStreamSynchronize(s->pf_stream));
+}
+
 static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n_tok, bool first, int sot_index,
                            bool step_block = false) {
     wlk_model* m = s->m;
@@ -1023,6 +1066,7 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
     const float scale = std::pow((float)kHeadDim, -0.25f);
     const size_t cache_layer = (size_t)s->beam * ctx_len * d;
     bool scores_dumped = false;   // prefill: raw alignment-head scores are waiting in the window rows
+    const bool marks = s->pf_marks && s->pf_progress && step_block && fused;
     for (int i = 0; i < D.n_text_layer; ++i) {
         const LayerW& L = m->dec_layers[i];
         float* kc = s->kcache[s->kv_cur] + i * cache_layer;
@@ -1049,7 +1093,8 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
                 launch_kv_append(c, s->dqkv, kc, vc, n_rows, n_tok, s->d_offset, d, ctx_len);
             }
         }
-        launch_decoder_self_attention(c, s->dqkv, kc, vc, s->datt, n_rows, n_tok, s->d_offset, d, H, ctx_len);
+        launch_decoder_self_attention(c, s->dqkv, kc, vc, s->datt, n_rows, n_tok, s->d_offset, d, H, ctx_len,
+                                      marks ? ProgressMark{&s->step_dev->seq, s->pf_progress, i} : ProgressMark{});
         GemmArgs o;
         o.A = s->datt; o.lda = d; o.W = L.outw; o.bias = L.outb; o.C = s->dx; o.ldc = d; o.M = R; o.N = d; o.K = d;
         o.flags = kGemmResidual; o.R = s->dx; o.ldr = d;
@@ -1450,6 +1495,52 @@ int wlk_no_speech_prob(wlk_session* s, int no_speech_token, float* probs_host) {
     });
 }
 
+// ---- whisper's batch-decoder rules on the device (transcribe.py's greedy T = 0 loop; select.hip: rules_pick_kernel) ----------
+int wlk_rules_set(wlk_session* s, const int32_t* suppressed, int n_suppressed, const int32_t* blank, int n_blank) {
+    if (!s || n_suppressed < 0 || n_blank < 0 || (n_suppressed > 0 && !suppressed) || (n_blank > 0 && !blank))
+        return fail(WLK_ERR_ARG, "invalid rule lists");
+    const int V = s->m->D.n_vocab;
+    for (int i = 0; i < n_suppressed; ++i)
+        if (suppressed[i] < 0 || suppressed[i] >= V) return fail(WLK_ERR_ARG, "suppressed token out of range");
+    for (int i = 0; i < n_blank; ++i)
+        if (blank[i] < 0 || blank[i] >= V) return fail(WLK_ERR_ARG, "blank token out of range");
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(s->m->device));
+        std::vector<unsigned char> host((size_t)V, 0);
+        for (int i = 0; i < n_suppressed; ++i) host[(size_t)suppressed[i]] |= 1;
+        for (int i = 0; i < n_blank; ++i) host[(size_t)blank[i]] |= 2;
+        if (!s->rules_mask) {
+            s->rules_mask = dev_alloc<unsigned char>((size_t)V);
+            s->pick_out = dev_alloc<int>(2);
+        }
+        WLK_HIP(hipStreamSynchronize(s->stream));           // a pick of the previous rule set may still be reading the mask
+        copy_sync(s->rules_mask, host.data(), host.size(), hipMemcpyHostToDevice);
+        return WLK_OK;
+    });
+}
+
+int wlk_pick_greedy(wlk_session* s, const wlk_pick_params* p, int32_t* token_host, float* logprob_host) {
+    if (!s || !p || !token_host || !logprob_host) return fail(WLK_ERR_ARG, "NULL argument");
+    if (s->beam != 1) return fail(WLK_ERR_ARG, "wlk_pick_greedy serves sessions of one row");
+    if (s->n_steps == 0) return fail(WLK_ERR_STATE, "wlk_pick_greedy before wlk_decode");
+    if (!s->rules_mask) return fail(WLK_ERR_STATE, "wlk_pick_greedy before wlk_rules_set");
+    const int V = s->m->D.n_vocab;
+    if (p->timestamp_begin < 0 || p->timestamp_begin > V || p->eot < 0 || p->eot >= V || p->ts_mode < 0 || p->ts_mode > 2)
+        return fail(WLK_ERR_ARG, "rule parameters out of range");
+    return guarded([&]() {
+        WLK_HIP(hipSetDevice(s->m->device));
+        const LaunchCtx c = s->ctx();
+        const PickRules r{p->first_step, p->without_timestamps, p->timestamp_begin, p->eot, p->no_timestamps, p->ts_mode,
+                          p->ts_bound, p->max_initial};
+        launch_rules_pick(c, s->logits_last, V, s->rules_mask, r, s->pick_out, reinterpret_cast<float*>(s->pick_out + 1));
+        WLK_HIP(hipMemcpyAsync(s->pinned, s->pick_out, 8, hipMemcpyDeviceToHost, s->stream));
+        WLK_HIP(hipStreamSynchronize(s->stream));
+        std::memcpy(token_host, s->pinned, 4);
+        std::memcpy(logprob_host, static_cast<char*>(s->pinned) + 4, 4);
+        return WLK_OK;
+    });
+}
+
 // wlk_select, optionally with the no-speech probability of the sot row in the same read-back (first step of the
 // library's decode loop: one synchronisation instead of two)
 static int select_impl(wlk_session* s, const int32_t* adj_row, const int32_t* adj_ids, const float* adj_deltas, int n_adj,
@@ -1587,10 +1678,13 @@ extern "C++" int wlk_step_select(wlk_session* s, int64_t token, const int32_t* a
         hipGraphExec_t& exec = s->fstep_exec[s->kv_cur];
         if (!exec) {
             hipGraph_t graph = nullptr;
+            mall_prefetch_prepare(s);
             WLK_HIP(hipStreamSynchronize(s->stream));
             WLK_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
             try {
+                s->pf_marks = true;
                 enqueue_decode(s, c, 1, 1, false, 0, true);
+                s->pf_marks = false;
                 a.rows = &s->step_dev->row;
                 StepHostOut ho;
                 ho.result = s->result_host_dev;
@@ -1600,6 +1694,7 @@ extern "C++" int wlk_step_select(wlk_session* s, int64_t token, const int32_t* a
                                          s->step_dev->adj_row, s->step_dev->adj_ids, s->step_dev->adj_deltas, 0, a, ho))
                     throw std::runtime_error("fused step: read-out not available");
             } catch (...) {
+                s->pf_marks = false;
                 (void)hipStreamEndCapture(s->stream, &graph);
                 if (graph) (void)hipGraphDestroy(graph);
                 throw;
@@ -1609,6 +1704,11 @@ extern "C++" int wlk_step_select(wlk_session* s, int64_t token, const int32_t* a
             (void)hipGraphDestroy(graph);
         }
         WLK_HIP(hipGraphLaunch(exec, s->stream));
+        if (s->pf_progress) {            // beside the replay: next layers' weights into the Infinity Cache, paced by the chain's marks
+            LaunchCtx pc;
+            pc.stream = s->pf_stream;
+            launch_mall_prefetch_step(pc, s->pf_table, D.n_text_layer, seq, s->pf_progress, mall_prefetch_lead(), s->dh);
+        }
 
         // the last kernel stores the two flags after the fields
         volatile StepResult* r = s->result_host;

@@ -114,6 +114,19 @@ struct EngineBlock {
 };
 void launch_embed_rows_step(const LaunchCtx& ctx, const EngineBlock* host_block, EngineBlock* dev_block, const float* tok_emb,
                             const float* pos_emb, float* x, int n_rows, int d);
+// The Infinity-Cache prefetcher beside a single-token decode step (decoder.hip: mall_prefetch_step_kernel): per decoder layer the
+// weight ranges it reads, and the mark the step's chain leaves for it
+struct TouchRanges {
+    const float* p[6];
+    unsigned n16[6];                      // 16-byte units per range
+};
+struct ProgressMark {
+    const unsigned* seq = nullptr;        // device copy of the step's sequence number (StepBlock::seq)
+    unsigned long long* word = nullptr;   // (seq << 32 | layer), stored by the layer's self-attention launch; nullptr = no mark
+    int layer = 0;
+};
+void launch_mall_prefetch_step(const LaunchCtx& ctx, const TouchRanges* table, int n_layer, unsigned seq,
+                               const unsigned long long* progress, int lead, float* sink);
 void launch_embed_step(const LaunchCtx& ctx, const StepBlock* host_block, StepBlock* dev_block, int* tokens_dev,
                        int* ring_row, int* beam_of_row, int* d_offset, const float* tok_emb, const float* pos_emb, float* x,
                        int d);
@@ -421,7 +434,7 @@ void launch_kv_append(const LaunchCtx& ctx, const float* qkv, float* kc, float* 
 void launch_kv_append_rows(const LaunchCtx& ctx, const float* qkv, const StepRow* rows, long layer_off, int n_rows, int d);
 void launch_decoder_self_attention(const LaunchCtx& ctx, const float* qkv, const float* kc, const float* vc,
                                    float* out, int n_rows, int n_tok, const int* offset_dev, int d, int n_head,
-                                   int ctx_len);
+                                   int ctx_len, const ProgressMark& mark = ProgressMark{});
 struct CrossAttnArgs {
     const float* q;        // [rows][d], pre-scaled
     const float* k;        // [T][ldkv] pre-scaled keys of this layer
@@ -516,6 +529,13 @@ void launch_logsoftmax_topk(const LaunchCtx& ctx, float* logits, int n_vocab, in
                             const float* adj_deltas, int n_adj);
 size_t topk_scratch_bytes(int n_rows);
 void launch_token_prob(const LaunchCtx& ctx, const float* logits, int n_vocab, int n_rows, int token, float* probs);
+// whisper's batch-decoder logit rules + the greedy pick of one sequence (select.hip: rules_pick_kernel); the fields mirror
+// wlk_pick_params of include/wlk_hip.h
+struct PickRules {
+    int first_step, without_timestamps, timestamp_begin, eot, no_timestamps, ts_mode, ts_bound, max_initial;
+};
+void launch_rules_pick(const LaunchCtx& ctx, const float* logits, int n_vocab, const unsigned char* mask, const PickRules& p,
+                       int* out_token, float* out_logprob);
 struct AlignArgs {
     const float* ring;   // [n_align][n_beam][ring_rows][T]
     int n_align, n_beam, ring_rows, T;

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(const float
                                                                      const StepRow* __restrict__ step_rows,
                                                                      const int* __restrict__ offset_p, int d,
                                                                      int ctx_len, int n_tok, float* __restrict__ out,
-                                                                     long layer_off) {
+                                                                     long layer_off, ProgressMark mark) {
     // Latency diet (round 4): the query slice comes straight from global memory (16 lanes x float4, no LDS stage and no
     // barrier in front of the keys), and the first 128 keys AND values - a whole decode step's cache in the common case -
     // are requested before anything is waited for; later chunks (long prompts) loop as before.  The key rows of the first
@@ -195,6 +195,11 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(const float
     const int row = blockIdx.x;
     const int head = blockIdx.y;
     const float4 q4 = *reinterpret_cast<const float4*>(qkv + (long)row * 3 * d + head * 64 + sub * 4);
+    // (a step with the Infinity-Cache prefetcher beside it: the step's sequence number, requested here, stored with the layer
+    // index behind the kernel's work - mall_prefetch_step_kernel paces itself on that word)
+    const bool marks = mark.word != nullptr && (blockIdx.x | blockIdx.y) == 0 && tid == 0;
+    unsigned mark_seq = 0;
+    if (marks) mark_seq = *mark.seq;
     int offset, b, p;
     gcf_ptr kc, vc;
     if (step_rows) {             // batched steps: one fed token per row, every row has its own cache
@@ -296,15 +301,17 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(const float
         for (int s = 0; s < 16; ++s) acc += part[s * 64 + tid];
         out[(long)row * d + head * 64 + tid] = acc;
     }
+    if (marks)
+        __hip_atomic_store(mark.word, ((unsigned long long)mark_seq << 32) | (unsigned)mark.layer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 void launch_decoder_self_attention(const LaunchCtx& ctx, const float* qkv, const float* kc, const float* vc,
                                    float* out, int n_rows, int n_tok, const int* offset, int d, int n_head,
-                                   int ctx_len) {
+                                   int ctx_len, const ProgressMark& mark) {
     if (ctx_len > 448 + 64) throw std::invalid_argument("self-attention: context too long");
     KernelScope ks(ctx, "dec_self_attention");
     hipLaunchKernelGGL(decoder_self_attention_kernel, dim3(n_rows * n_tok, n_head), dim3(256), 0, ctx.stream, qkv,
-                       kc, vc, (const StepRow*)nullptr, offset, d, ctx_len, n_tok, out, 0L);
+                       kc, vc, (const StepRow*)nullptr, offset, d, ctx_len, n_tok, out, 0L, mark);
     WLK_HIP(hipGetLastError());
 }
 
@@ -314,7 +321,7 @@ void launch_decoder_self_attention_rows(const LaunchCtx& ctx, const float* qkv, 
     KernelScope ks(ctx, "dec_self_attention");
     hipLaunchKernelGGL(decoder_self_attention_kernel, dim3(n_rows, n_head), dim3(256), 0, ctx.stream, qkv,
                        (const float*)nullptr, (const float*)nullptr, rows, (const int*)nullptr, d, ctx_len, 1, out,
-                       layer_off);
+                       layer_off, ProgressMark{});
     WLK_HIP(hipGetLastError());
 }
 
@@ -741,6 +748,70 @@ bool cross_split_folds_query(int d) {
 }
 size_t cross_split_scratch_floats(int rows, int n_head, int T) {
     return (size_t)rows * n_head * ((size_t)T + kCrossSplit * (2 + 64));
+}
+
+// ---- Infinity-Cache prefetch of the decoder weights beside a single-token step ----------------------------------------------
+// A single-row decode step of a model whose decoder is larger than the 256 MB memory-side cache streams every weight from
+// HBM inside a chain of dependent launches: each GEMV waits for its first bytes at HBM latency and then has 3 - 5 us to
+// move 7 - 26 MB (large-v3: 3.0 - 4.5 TB/s per launch, 0.31 of HBM over the step; the same launches on cache-resident weights
+// run at 6.7 - 8.6 TB/s, scripts/mall_probe.py).  The weights do not depend on the token, so ONE kernel on a side stream
+// reads layer l + 1's matrices while layer l's chain runs; nothing is kept - the point is that the lines are in the
+// Infinity Cache when the GEMVs ask for them.  Pacing: the chain's self-attention launch of layer l stores (step sequence
+// number, l) into a progress word (ProgressMark), the prefetcher's workgroups wait for it before they start on layer
+// l + 1 - further ahead the cache (2.5 layers of large-v3) would lose the lines again before they are used.  A bounded
+// wait: a chain that never comes ends the prefetcher, it cannot hang the GPU.  Reads only: results cannot change.
+// (As a forked branch of the step's hipGraph the same reads made the replay 3 x slower - HIP 7.2 replays a graph with a
+// parallel branch segment by segment - and crashed under GPU_MAX_HW_QUEUES=2: profiles/r06k_mall_ab_large-v3.txt.)
+__global__ __launch_bounds__(256) void mall_prefetch_step_kernel(const TouchRanges* __restrict__ table, int n_layer, unsigned seq,
+                                                                 const unsigned long long* __restrict__ progress, int lead,
+                                                                 float* __restrict__ sink) {
+    __shared__ int go;
+    float acc = 0.f;
+    const unsigned stride = gridDim.x * 256u;
+#pragma unroll 1
+    for (int l = 1; l < n_layer; ++l) {
+        if (threadIdx.x == 0) {
+            int ok = 0;
+#pragma unroll 1
+            for (int polls = 0; polls < 40000; ++polls) {            // ~1 us per poll: 40 ms at most
+                const unsigned long long v = __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(v >> 32) == seq && (int)(unsigned)v + lead >= l - 1) {
+                    ok = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(127);
+            }
+            go = ok;
+        }
+        __syncthreads();
+        const int ok = go;
+        __syncthreads();
+        if (!ok) break;
+        const TouchRanges t = table[l];
+#pragma unroll 1
+        for (int r = 0; r < 6; ++r) {
+            const float4* __restrict__ p = reinterpret_cast<const float4*>(t.p[r]);
+            const unsigned n = t.n16[r];
+            unsigned i = blockIdx.x * 256u + threadIdx.x;
+#pragma unroll 1
+            for (; i + 7u * stride < n; i += 8u * stride) {           // eight independent 16-byte loads per lane in flight
+                const float4 a = p[i], b = p[i + stride], c = p[i + 2u * stride], e = p[i + 3u * stride];
+                const float4 f = p[i + 4u * stride], g = p[i + 5u * stride], h = p[i + 6u * stride], k = p[i + 7u * stride];
+                acc += ((a.x + b.x) + (c.x + e.x)) + ((f.x + g.x) + (h.x + k.x));
+            }
+            for (; i < n; i += stride) acc += p[i].x;
+        }
+    }
+    if (acc == 1.2345678e-38f) *sink = acc;                       // never true in practice; keeps the loads alive
+}
+
+void launch_mall_prefetch_step(const LaunchCtx& ctx, const TouchRanges* table, int n_layer, unsigned seq,
+                               const unsigned long long* progress, int lead, float* sink) {
+    if (n_layer < 2) return;
+    KernelScope ks(ctx, "dec_mall_prefetch");
+    // 256 workgroups x 256 lanes x 4 loads of 16 bytes = 4 MB in flight: ~4 TB/s at 1 us of latency, beside the step's own chain
+    hipLaunchKernelGGL(mall_prefetch_step_kernel, dim3(256), dim3(256), 0, ctx.stream, table, n_layer, seq, progress, lead, sink);
+    WLK_HIP(hipGetLastError());
 }
 
 // beam reorder of the self-attention caches: dst[l][b] = src[l][source_rows[b]]

@@ -562,6 +562,385 @@ __global__ __launch_bounds__(XW_THREADS) void gemm_x3_wide_kernel(X3GemmArgs g) 
     __builtin_amdgcn_s_barrier();              // the loaders' tail fetches have landed: the workgroup may leave
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// the wide kernel with TWO compute waves per SIMD (round 6).  The kernel above keeps ONE wave per SIMD on the matrix pipe, and
+// whatever that wave waits for - the ~100 cycles of issue every weight load costs it, its fragment reads, the slab barrier -
+// the pipe waits for too: 1.1 us per slab against 0.6 for the 36 MFMAs alone.  Here the two k-steps of a slab
+// belong to two waves: wave v multiplies columns 32 (v & 3) .. + 31 of the tile with the slab's elements 16 (v >> 2) .. + 15
+// (18 MFMAs, 9 fragment reads, 3 weight loads per slab - the workgroup's LDS and weight traffic is unchanged), waves v and
+// v + 4 share a SIMD, and one wave's stalls are the other one's issue slots.  Eight compute waves + three loaders = eleven
+// waves, three on a SIMD, i.e. 168 registers each: the fragments of planes mid and lo are read into the registers the MFMAs
+// have just consumed (lo after the first nine MFMAs of a slab, mid after twelve), only plane hi - used by the last six - is
+// double-buffered, which needs slab t + 1 readable while slab t is multiplied: the slab barrier sits in FRONT of a slab's
+// MFMAs (the loaders' protocol is the one above, one slot less of look-ahead).  At the end of a tile the k-step-1 wave hands
+// its accumulators to its partner through the staging region (lane-private addresses: the same lane of the partner wave
+// owns the same elements), one more barrier per tile; the sum of the two halves then takes the epilogues above.  Not
+// bit-identical to the one-wave kernel (a tile's K sum is regrouped into the even and the odd k-steps); rows still do not
+// depend on what is stacked under them, and WLK_X3_KSPLIT=0 selects the kernel above.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int XK_CW = 8;
+constexpr int XK_WAVES = XK_CW + XW_LOADERS;
+constexpr int XK_THREADS = XK_WAVES * 64;
+__device__ __forceinline__ void xk_read3(xf32x4 (&f)[3], unsigned addr) {       // one plane's fragments of the three row blocks
+    asm volatile("ds_read_b128 %0, %1" : "=v"(f[0]) : "v"(addr));
+    asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(f[1]) : "v"(addr));
+    asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(f[2]) : "v"(addr));
+}
+static_assert(32 * XW_ROW_BYTES == 6144, "row-block stride of the fragment reads");
+__device__ __forceinline__ void xk_wait9(xf32x4 (&a)[3], xf32x4 (&b)[3], xf32x4 (&c)[3]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
+    asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
+}
+}  // namespace
+
+__global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g) {
+    asm volatile("" ::"s"(g.A3), "s"(g.lda), "s"(g.W3), "s"(g.bias), "s"(g.C), "s"(g.ldc), "s"(g.R), "s"(g.ldr), "s"(g.M),
+                 "s"(g.N), "s"(g.K), "s"(g.flags), "s"(g.scale), "s"(g.scale_cols), "s"(g.scale_period), "s"(g.batch));
+    __builtin_amdgcn_sched_barrier(0);
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool batched = g.batch > 0;
+    // ---- the tile walk (as in gemm_x3_wide_kernel) --------------------------------------------------------------------
+    const int tiles_m = (g.M + XW_BM - 1) / XW_BM, tiles_n = (g.N + XW_BN - 1) / XW_BN;
+    const bool banded = g.walk_banded != 0;
+    const int band_m = banded ? (tiles_m + 3) / 4 : tiles_m, band_n = banded ? (tiles_n + 1) / 2 : tiles_n;
+    const int per_session = band_m * band_n;
+    const int xcd = banded ? (int)(blockIdx.x & 7) : 0;
+    const int first = banded ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int stride = banded ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int limit = g.walk_slots;
+    const int band_m0 = banded ? (xcd >> 1) * band_m : 0, band_n0 = banded ? (xcd & 1) * band_n : 0;
+    auto decode = [&](int slot, int& tm, int& tn, int& b) -> bool {
+        b = slot / per_session;
+        const int r = slot - b * per_session;
+        int rm, cn;
+        if (g.walk_colmajor) {
+            cn = r / band_m;
+            rm = r - cn * band_m;
+        } else {
+            rm = r / band_n;
+            cn = r - rm * band_n;
+        }
+        tm = band_m0 + rm;
+        tn = band_n0 + cn;
+        return tm < tiles_m && tn < tiles_n;
+    };
+    auto advance = [&](int slot) {
+        int tm, tn, b;
+        while (slot < limit && !decode(slot, tm, tn, b)) slot += stride;
+        return slot;
+    };
+    const int slot0 = advance(first);
+    if (slot0 >= limit) return;
+    const int nslab = g.K / 32;             // even (launch_gemm_x3)
+    const bool x3_out = g.x3_out;
+
+    // ---- the fp32 epilogue, shared by all eleven waves (item k of the 48 for wave k % 11) ------------------------------------
+    auto shared_epilogue = [&](int m0, int n0, int bz) {
+        float* const gC = batched ? table_at(g.z.out, (unsigned)bz) : g.C;
+        const float* const gR = batched ? table_at(g.z.res, (unsigned)bz) : g.R;
+        const float* const stage = reinterpret_cast<const float*>(lds + XW_STAGE_OFF);
+        const int colq = lane & 7, rsub = lane >> 3;
+        constexpr int ITEMS = 4 * (XW_BM / 8);
+        auto bias_of_item = [&](int k) -> xf32x4 {
+            const int c = min(n0 + 32 * (min(k, ITEMS - 1) / (XW_BM / 8)) + 4 * colq, g.N - 4);
+            return g.bias ? *reinterpret_cast<const xf32x4*>(g.bias + c) : xf32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        xf32x4 bq = bias_of_item(wave);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool gelu = (g.flags & kGemmGelu) != 0, has_res = (g.flags & kGemmResidual) != 0;
+#pragma unroll 1
+        for (int k = wave; k < ITEMS; k += XK_WAVES) {
+            const xf32x4 bq_next = bias_of_item(k + XK_WAVES);
+            const int wp = k / (XW_BM / 8), it = k - wp * (XW_BM / 8);
+            const int row_t = 8 * it + rsub, row = m0 + row_t;
+            const int col = n0 + 32 * wp + 4 * colq;
+            xf32x4 v = *reinterpret_cast<const xf32x4*>(stage + (wp * XW_BM + row_t) * XW_WPITCH + 4 * colq);
+            const xf32x4 res = has_res ? *reinterpret_cast<const xf32x4*>(gR + (long)min(row, g.M - 1) * g.ldr + min(col, g.N - 4))
+                                       : xf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] += bq[e];
+                if ((g.flags & kGemmScaleCols) && (g.scale_period ? (col + e) % g.scale_period : col + e) < g.scale_cols) v[e] *= g.scale;
+                if (gelu) v[e] = x3_gelu_erf(v[e]);
+                v[e] += res[e];
+            }
+            if (row < g.M && col < g.N) *reinterpret_cast<xf32x4*>(gC + (long)row * g.ldc + col) = v;
+            bq = bq_next;
+        }
+    };
+
+    if (wave >= XK_CW) {
+        // ---- loader (the code of gemm_x3_wide_kernel's loaders; barriers per tile: slabs + fold + epilogue) ----------------
+        const int lw = wave - XK_CW;
+        const char* src[XW_NPW];
+        int row_of[XW_NPW], unit_of[XW_NPW];
+#pragma unroll
+        for (int i = 0; i < XW_NPW; ++i) {
+            const int byte = 1024 * (lw + XW_LOADERS * i) + 16 * lane;
+            row_of[i] = byte / XW_ROW_BYTES;
+            unit_of[i] = (((byte - row_of[i] * XW_ROW_BYTES) >> 4) ^ ((row_of[i] >> 2) & 3)) * 16;
+        }
+        auto set_src = [&](int slot) {
+            int tm, tn, b;
+            decode(slot, tm, tn, b);
+            const int m0 = tm * XW_BM;
+            const char* const gA = reinterpret_cast<const char*>(batched ? reinterpret_cast<const unsigned short*>(table_at(g.z.in, (unsigned)b)) : g.A3);
+#pragma unroll
+            for (int i = 0; i < XW_NPW; ++i) src[i] = gA + (long)min(m0 + row_of[i], g.M - 1) * g.lda * 6 + unit_of[i];
+        };
+        int issue_slot = slot0, s_next = 0, ring = 0;
+        bool more = true;
+        set_src(issue_slot);
+        auto issue_one = [&]() {
+            const long adv = (long)s_next * XW_ROW_BYTES;
+            unsigned char* const dst = lds + ring * XW_SLAB_BYTES + lw * 1024;
+            x3_static_for<XW_NPW>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + adv),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * XW_LOADERS * 1024), 16, 0, 0);
+            });
+            ring = ring == XW_NB - 1 ? 0 : ring + 1;
+            if (more && ++s_next == nslab) {
+                const int ns = advance(issue_slot + stride);
+                if (ns < limit) {
+                    issue_slot = ns;
+                    set_src(ns);
+                    s_next = 0;
+                } else {
+                    more = false;
+                    s_next = nslab - 1;
+                }
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < XW_DT; ++i) issue_one();
+        xw_wait_landed();
+        __builtin_amdgcn_s_barrier();
+        for (int slot = slot0; slot < limit; slot = advance(slot + stride)) {
+            for (int tt = 0; tt < nslab; ++tt) {
+                issue_one();
+                xw_wait_landed();
+                __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_s_barrier();          // the fold: the k-step-1 waves' accumulators are in the staging region
+            if (x3_out) {
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
+            } else {
+                int tm, tn, bz;
+                decode(slot, tm, tn, bz);
+                shared_epilogue(tm * XW_BM, tn * XW_BN, bz);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+
+    // ---- compute waves ------------------------------------------------------------------------------------------------
+    const int cb = wave & 3, half = wave >> 2;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int r = lane & 31, hi = lane >> 5, swz = (r >> 2) & 3;
+    unsigned fa[3];                        // plane p's fragment of row block 0 in ring slot 0: lane (r, hi) reads row r, chunk 2 half + hi
+#pragma unroll
+    for (int p = 0; p < 3; ++p) fa[p] = lds_base + (unsigned)(r * XW_ROW_BYTES) + (unsigned)((((2 * half + hi) * 3 + p) ^ swz) * 16);
+    xf32x16 acc[3];
+    auto mfma3 = [&](const xf32x4& w, const xf32x4 (&f)[3]) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, f[i]), acc[i], 0, 0, 0);
+    };
+    const int n_blocks = (g.N + 31) / 32;
+    typedef const __attribute__((address_space(1))) xf32x4* wptr_t;
+    auto w_base = [&](int slot) -> const char* {       // this wave's half of slab 0 of its weight block
+        int tm, tn, bz;
+        decode(slot, tm, tn, bz);
+        return reinterpret_cast<const char*>(g.W3) + (long)min(4 * tn + cb, n_blocks - 1) * nslab * XW_WSLAB_BYTES + half * (XW_WSLAB_BYTES / 2) + 16 * lane;
+    };
+    const int col_in_tile = 32 * cb + 4 * hi;
+    auto load_bias = [&](int slot, xf32x4 (&b)[4]) {
+        int tm, tn, bz;
+        decode(slot, tm, tn, bz);
+        if (x3_out && half == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = min(tn * XW_BN + col_in_tile + 8 * j, g.N - 4);
+                b[j] = g.bias ? *reinterpret_cast<const xf32x4*>(g.bias + c) : xf32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    xf32x4 wa[3], wb[3];                       // weight planes of the even / of the odd slabs (two slabs ahead of their MFMAs)
+    const char* w_cur = w_base(slot0);
+#pragma unroll
+    for (int x = 0; x < 3; ++x) wa[x] = *(wptr_t)(w_cur + 1024 * x);
+#pragma unroll
+    for (int x = 0; x < 3; ++x) wb[x] = *(wptr_t)(w_cur + XW_WSLAB_BYTES + 1024 * x);
+    xf32x4 bias_next[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias_next[j] = xf32x4{0.f, 0.f, 0.f, 0.f};
+    load_bias(slot0, bias_next);
+
+    __builtin_amdgcn_s_barrier();              // slab 0 has landed
+    xf32x4 f0a[3], f0b[3], f1[3], f2[3];       // plane hi (two buffers), mid, lo
+    xk_read3(f0a, fa[0]);
+    xk_read3(f1, fa[1]);
+    xk_read3(f2, fa[2]);
+    xk_wait9(f0a, f1, f2);
+    unsigned ring_off = XW_SLAB_BYTES;         // byte offset of the ring slot of the slab being READ (one ahead of the MFMAs)
+    // one slab: the barrier behind which the next slab is readable, then the six plane products grouped by WEIGHT plane -
+    // (hi, hi) (mid, hi) (lo, hi) | (mid, mid) (hi, mid) | (hi, lo), activation plane first - so that a weight plane is dead as
+    // early as possible: the plane of slab t + 2 is loaded into the registers of slab t's as soon as its last MFMA has
+    // issued (two buffers, 1.5 - 1.8 slabs between a load and its first use; one slab ahead the MFMAs waited for weights
+    // that queue behind the loaders' pieces in the CU's in-order vector memory path).  Fragments: plane lo after the third
+    // product, plane mid after the fourth, plane hi (last use: the sixth) into its second buffer at the top.
+    auto slab = [&](const xf32x4 (&F0c)[3], xf32x4 (&F0n)[3], xf32x4 (&W)[3], const char* p2) {
+        __builtin_amdgcn_s_barrier();
+        xk_read3(F0n, fa[0] + ring_off);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(W[0], F0c);
+        mfma3(W[0], f1);
+        mfma3(W[0], f2);
+        __builtin_amdgcn_sched_barrier(0);
+        xk_read3(f2, fa[2] + ring_off);
+        W[0] = *(wptr_t)(p2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(W[1], f1);
+        __builtin_amdgcn_sched_barrier(0);
+        xk_read3(f1, fa[1] + ring_off);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(W[1], F0c);
+        __builtin_amdgcn_sched_barrier(0);
+        W[1] = *(wptr_t)(p2 + 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(W[2], F0c);
+        __builtin_amdgcn_sched_barrier(0);
+        W[2] = *(wptr_t)(p2 + 2048);
+        __builtin_amdgcn_sched_barrier(0);
+        xk_wait9(F0n, f1, f2);
+        ring_off = ring_off == (unsigned)((XW_NB - 1) * XW_SLAB_BYTES) ? 0u : ring_off + (unsigned)XW_SLAB_BYTES;
+    };
+    for (int slot = slot0; slot < limit;) {
+        int tile_m, tile_n, bz;
+        decode(slot, tile_m, tile_n, bz);
+        const int next_slot = advance(slot + stride);
+        const int m0 = tile_m * XW_BM, n0 = tile_n * XW_BN;
+        const int col0 = n0 + col_in_tile;
+        const char* const w_next = next_slot < limit ? w_base(next_slot) : w_cur;
+        xf32x4 bias[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias[j] = bias_next[j];
+        if (next_slot < limit) load_bias(next_slot, bias_next);
+        auto scaled = [&](int col) { return (g.flags & kGemmScaleCols) && (g.scale_period ? col % g.scale_period : col) < g.scale_cols; };
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+        for (int tt = 0; tt < nslab; tt += 2) {           // (behind the tile's last slabs: the next tile's first two)
+            const bool wrap = tt + 2 >= nslab;
+            const char* const p2 = wrap ? w_next : w_cur + (long)(tt + 2) * XW_WSLAB_BYTES;
+            slab(f0a, f0b, wa, p2);
+            slab(f0b, f0a, wb, p2 + XW_WSLAB_BYTES);
+        }
+        w_cur = w_next;
+        float* const gC = batched ? table_at(g.z.out, (unsigned)bz) : g.C;
+        if (x3_out) {
+            constexpr int PITCH = XW_STAGE_PITCH;
+            float* const stage = reinterpret_cast<float*>(lds + XW_STAGE_OFF);
+            if (half == 1) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<xf32x4*>(stage + (32 * i + r) * PITCH + col_in_tile + 8 * j) =
+                            xf32x4{acc[i][4 * j], acc[i][4 * j + 1], acc[i][4 * j + 2], acc[i][4 * j + 3]};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // fold
+            if (half == 0) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    float* const srow = stage + (32 * i + r) * PITCH + col_in_tile;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        xf32x4 v = *reinterpret_cast<const xf32x4*>(srow + 8 * j);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = (acc[i][4 * j + e] + v[e]) + bias[j][e];
+                            if (scaled(col0 + 8 * j + e)) v[e] *= g.scale;
+                        }
+                        if (g.flags & kGemmGelu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = x3_gelu_erf(v[e]);
+                        }
+                        *reinterpret_cast<xf32x4*>(srow + 8 * j) = v;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            unsigned short* const c3 = batched ? reinterpret_cast<unsigned short*>(gC) : g.C3;
+            const int tid = threadIdx.x;           // 0 .. 511: the compute waves
+            if (n0 < g.vt_col0) {
+                for (int item = tid; item < XW_BM * (XW_BN / 8); item += XK_CW * 64) {
+                    const int row = item >> 4, c = item & 15;
+                    if (m0 + row < g.M && n0 + 8 * c < g.N) {
+                        const float4 a = *reinterpret_cast<const float4*>(stage + row * PITCH + 8 * c);
+                        const float4 b = *reinterpret_cast<const float4*>(stage + row * PITCH + 8 * c + 4);
+                        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                        x3_store_chunk(c3 + (long)(m0 + row) * 3 * g.ldc3 + (long)((n0 >> 3) + c) * 24, v);
+                    }
+                }
+            } else {
+                unsigned short* const vt = c3 + g.vt_off;
+                for (int item = tid; item < XW_BN * (XW_BM / 8); item += XK_CW * 64) {
+                    const int dcol = item / (XW_BM / 8), u = item - dcol * (XW_BM / 8);
+                    const int r0 = 32 * (u >> 2) + 4 * (u & 3);
+                    if (n0 + dcol < g.N && m0 + 32 * (u >> 2) < g.vt_ld) {
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int row = r0 + (e & 3) + 16 * (e >> 2);
+                            v[e] = m0 + row < g.M ? stage[row * PITCH + dcol] : 0.f;
+                        }
+                        x3_store_chunk(vt + (long)(n0 + dcol - g.vt_col0) * 3 * g.vt_ld + (long)((m0 >> 3) + u) * 24, v);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // the staging region may be written again
+        } else {
+            float* const wst = reinterpret_cast<float*>(lds + XW_STAGE_OFF) + cb * (XW_BM * XW_WPITCH);
+            if (half == 1) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<xf32x4*>(wst + (32 * i + r) * XW_WPITCH + 8 * j + 4 * hi) =
+                            xf32x4{acc[i][4 * j], acc[i][4 * j + 1], acc[i][4 * j + 2], acc[i][4 * j + 3]};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // fold
+            if (half == 0) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float* const p = wst + (32 * i + r) * XW_WPITCH + 8 * j + 4 * hi;
+                        const xf32x4 o = *reinterpret_cast<const xf32x4*>(p);
+                        *reinterpret_cast<xf32x4*>(p) = xf32x4{acc[i][4 * j] + o[0], acc[i][4 * j + 1] + o[1], acc[i][4 * j + 2] + o[2], acc[i][4 * j + 3] + o[3]};
+                    }
+            }
+            shared_epilogue(m0, n0, bz);
+        }
+        slot = next_slot;
+    }
+    __builtin_amdgcn_s_barrier();              // the loaders' tail fetches have landed: the workgroup may leave
+}
+
 bool gemm_x3_wide_applicable(int M, int N, int K, long lda) {
     static const bool on = [] {
         const char* e = getenv("WLK_X3");
@@ -571,7 +950,11 @@ bool gemm_x3_wide_applicable(int M, int N, int K, long lda) {
 }
 
 static std::atomic<int> g_x3_persist{-1};                // -1: WLK_X3_PERSIST not read yet
-void x3_refresh_env_switches() { g_x3_persist.store(-1, std::memory_order_relaxed); }
+static std::atomic<int> g_x3_ksplit{-1};                 // -1: WLK_X3_KSPLIT not read yet (1: gemm_x3_wide2_kernel, the default)
+void x3_refresh_env_switches() {
+    g_x3_persist.store(-1, std::memory_order_relaxed);
+    g_x3_ksplit.store(-1, std::memory_order_relaxed);
+}
 
 void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) {
     if (g.M <= 0 || g.N <= 0) return;
@@ -598,6 +981,7 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
         WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
         WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
         WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
         configured.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const int tiles_m = (g.M + XW_BM - 1) / XW_BM, tiles_n = (g.N + XW_BN - 1) / XW_BN;
@@ -660,6 +1044,17 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
         return v;
     }();
     const dim3 grid(blocks);
+    int ksplit = g_x3_ksplit.load(std::memory_order_relaxed);
+    if (ksplit < 0) {
+        const char* e = getenv("WLK_X3_KSPLIT");
+        ksplit = !(e && e[0] == '0');
+        g_x3_ksplit.store(ksplit, std::memory_order_relaxed);
+    }
+    if (ksplit && abl == 0) {
+        hipLaunchKernelGGL(gemm_x3_wide2_kernel, grid, dim3(XK_THREADS), XW_LDS_BYTES, ctx.stream, gg);
+        WLK_HIP(hipGetLastError());
+        return;
+    }
     if (abl == 1) hipLaunchKernelGGL(gemm_x3_wide_kernel<1>, grid, dim3(XW_THREADS), XW_LDS_BYTES, ctx.stream, gg);
     else if (abl == 2) hipLaunchKernelGGL(gemm_x3_wide_kernel<2>, grid, dim3(XW_THREADS), XW_LDS_BYTES, ctx.stream, gg);
     else if (abl == 3) hipLaunchKernelGGL(gemm_x3_wide_kernel<3>, grid, dim3(XW_THREADS), XW_LDS_BYTES, ctx.stream, gg);

@@ -248,6 +248,15 @@ struct wlk_session {
     // still in flight, the next append waits for it before reusing the block
     void* audio_stage = nullptr;
     hipEvent_t audio_stage_ev = nullptr;
+    // whisper's batch-decoder rules on the device (wlk_rules_set / wlk_pick_greedy): bit 0 = always suppressed, bit 1 = blank
+    unsigned char* rules_mask = nullptr;
+    int* pick_out = nullptr;                            // [token | log-probability]
+    // Infinity-Cache prefetcher beside a graph-replayed single-token step (wlk_step_select; decoder.hip): its stream, the
+    // per-layer range table and the progress word the step's chain marks
+    hipStream_t pf_stream = nullptr;
+    wlk::TouchRanges* pf_table = nullptr;
+    unsigned long long* pf_progress = nullptr;
+    bool pf_marks = false;                              // set around the capture of a step graph: the chain stores its marks
     bool audio_stage_used = false;
     // single-token steps as one graph replay (wlk_step_select): host-coherent blocks the step's first / last kernel
     // read / write directly, their device-side addresses, the device copy of the input block, one graph per KV set

@@ -614,6 +614,121 @@ bool launch_select_fused(const LaunchCtx& ctx, float* logits, int n_vocab, int n
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The per-step logit rules of whisper's batch decoder (whisper/decoding.py:417-499: SuppressBlank, SuppressTokens,
+// ApplyTimestampRules) and the greedy pick at temperature 0 (GreedyDecoder.update, :270-287) for ONE sequence, on the device:
+// the host keeps what the rules need of the token history (three flags and a bound) and reads back the token and its
+// log-probability - 8 bytes per step instead of the 207 KB logits row, and no 52k-element log_softmax on the host.
+//   allowed(v) = not suppressed, not a blank at the first step, and (with timestamps) none of: <|notimestamps|>; a timestamp
+//   behind a closed pair (mode 1); a text token behind an opening timestamp (mode 2); a timestamp below the monotonic bound;
+//   at the first step a text token or a timestamp beyond max_initial.
+//   Then, as the reference: if logsumexp(logprobs[timestamps]) > max(logprobs[text]) the text tokens go too.
+//   token = argmax over what is left (lowest index on ties), log-probability = log_softmax over what is left at that
+//   token = -log(sum exp(x - max)).
+// One workgroup of 1024 threads, two strided passes over the row (51 elements per thread).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct PickBest {
+    float v;
+    int i;
+};
+__device__ __forceinline__ PickBest pick_better(PickBest a, PickBest b) {      // larger value, lower index on ties
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ PickBest pick_wave_best(PickBest x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        PickBest o;
+        o.v = __shfl_xor(x.v, off);
+        o.i = __shfl_xor(x.i, off);
+        x = pick_better(x, o);
+    }
+    return x;
+}
+}  // namespace
+
+__global__ __launch_bounds__(1024) void rules_pick_kernel(const float* __restrict__ logits, int n_vocab,
+                                                          const unsigned char* __restrict__ mask, PickRules p,
+                                                          int* __restrict__ out_token, float* __restrict__ out_logprob) {
+    __shared__ PickBest s_all[16], s_ts[16];
+    __shared__ float s_text[16], s_sum_all[16], s_sum_ts[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tb = p.timestamp_begin;
+    auto allowed = [&](int v) -> bool {
+        const unsigned char m = mask[v];
+        if ((m & 1) || (p.first_step && (m & 2))) return false;
+        if (p.without_timestamps) return true;
+        if (v == p.no_timestamps) return false;
+        if (p.ts_mode == 1 && v >= tb) return false;
+        if (p.ts_mode == 2 && v < p.eot) return false;
+        if (v >= tb && v < p.ts_bound) return false;
+        if (p.first_step && (v < tb || (p.max_initial >= 0 && v >= tb + p.max_initial + 1))) return false;
+        return true;
+    };
+    PickBest all{-INFINITY, 0x7fffffff}, ts{-INFINITY, 0x7fffffff};
+    float text = -INFINITY;
+    for (int v = tid; v < n_vocab; v += 1024) {
+        if (!allowed(v)) continue;
+        const float x = logits[v];
+        all = pick_better(all, PickBest{x, v});
+        if (v >= tb) ts = pick_better(ts, PickBest{x, v});
+        else text = fmaxf(text, x);
+    }
+    all = pick_wave_best(all);
+    ts = pick_wave_best(ts);
+    text = wave_max(text);
+    if (lane == 0) {
+        s_all[wave] = all;
+        s_ts[wave] = ts;
+        s_text[wave] = text;
+    }
+    __syncthreads();
+    all = s_all[0];
+    ts = s_ts[0];
+    text = s_text[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) {
+        all = pick_better(all, s_all[w]);
+        ts = pick_better(ts, s_ts[w]);
+        text = fmaxf(text, s_text[w]);
+    }
+    float sum_all = 0.f, sum_ts = 0.f;
+    for (int v = tid; v < n_vocab; v += 1024) {
+        if (!allowed(v)) continue;
+        const float x = logits[v];
+        sum_all += expf(x - all.v);
+        if (v >= tb) sum_ts += expf(x - ts.v);
+    }
+    sum_all = wave_sum(sum_all);
+    sum_ts = wave_sum(sum_ts);
+    if (lane == 0) {
+        s_sum_all[wave] = sum_all;
+        s_sum_ts[wave] = sum_ts;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        sum_all = 0.f;
+        sum_ts = 0.f;
+        for (int w = 0; w < 16; ++w) {
+            sum_all += s_sum_all[w];
+            sum_ts += s_sum_ts[w];
+        }
+        const float lse_all = all.v + logf(sum_all);
+        // logsumexp(logprobs[tb:]) > logprobs[:tb].max(), both relative to the same log_softmax
+        const bool ts_wins = !p.without_timestamps && ts.i != 0x7fffffff && (ts.v + logf(sum_ts)) - lse_all > text - lse_all;
+        const PickBest pick = ts_wins ? ts : all;
+        out_token[0] = pick.i == 0x7fffffff ? 0 : pick.i;
+        out_logprob[0] = -logf(ts_wins ? sum_ts : sum_all);
+    }
+}
+
+void launch_rules_pick(const LaunchCtx& ctx, const float* logits, int n_vocab, const unsigned char* mask, const PickRules& p,
+                       int* out_token, float* out_logprob) {
+    KernelScope ks(ctx, "rules_pick", 0.0, 8.0 * n_vocab);
+    hipLaunchKernelGGL(rules_pick_kernel, dim3(1), dim3(1024), 0, ctx.stream, logits, n_vocab, mask, p, out_token, out_logprob);
+    WLK_HIP(hipGetLastError());
+}
+
 void launch_alignatt_rows(const LaunchCtx& ctx, const AlignArgs& a0, const StepRow* rows) {
     AlignArgs a = a0;
     a.rows = rows;

@@ -328,6 +328,23 @@ class HipSession:
         _lib.check(self.lib.wlk_no_speech_prob(self._h, int(token), out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def set_rules(self, suppressed: Sequence[int], blank: Sequence[int]) -> None:
+        """The token lists of whisper's SuppressTokens / SuppressBlank for wlk_pick_greedy (decoding.py:417-432)."""
+        a = np.ascontiguousarray(suppressed, dtype=np.int32).reshape(-1)
+        b = np.ascontiguousarray(blank, dtype=np.int32).reshape(-1)
+        _lib.check(self.lib.wlk_rules_set(self._h, a.ctypes.data_as(C.c_void_p), a.size, b.ctypes.data_as(C.c_void_p), b.size))
+
+    def pick_greedy(self, *, first_step: bool, without_timestamps: bool, timestamp_begin: int, eot: int, no_timestamps: int,
+                    ts_mode: int, ts_bound: int, max_initial: int) -> Tuple[int, float]:
+        """Logit rules + argmax + log-probability of the last decode's row on the device (decoding.py:270-287, 417-499)."""
+        prm = np.asarray([int(first_step), int(without_timestamps), timestamp_begin, eot, no_timestamps, ts_mode, ts_bound,
+                          max_initial], dtype=np.int32)
+        tok = np.empty(1, np.int32)
+        lp = np.empty(1, np.float32)
+        _lib.check(self.lib.wlk_pick_greedy(self._h, prm.ctypes.data_as(C.c_void_p), tok.ctypes.data_as(C.c_void_p),
+                                            lp.ctypes.data_as(C.c_void_p)))
+        return int(tok[0]), float(lp[0])
+
     def select(self, adj_rows: Sequence[int], adj_ids: Sequence[int], adj_deltas: Sequence[float], k: int,
                content_mel_len: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         n = len(adj_ids)

@@ -15,6 +15,7 @@ in fp32, as the reference does on its CPU).  Decoding a file name (ffmpeg) is ou
 """
 from __future__ import annotations
 
+import os
 import threading
 import warnings
 import zlib
@@ -304,6 +305,23 @@ class _WindowDecoder:
                 changed = True
         return _log_softmax(logits) if changed else logprobs
 
+    def _pick_state(self, tokens: np.ndarray) -> dict:
+        """What ApplyTimestampRules (decoding.py:441-499) reads from the sampled tokens of the one sequence, as the fields of
+        wlk_pick_params: the device applies the rules to the logits row, the history stays here."""
+        tb = self.tok.timestamp_begin
+        sampled = tokens[0, self.sample_begin:]
+        last_ts = len(sampled) >= 1 and sampled[-1] >= tb
+        before_last_ts = len(sampled) < 2 or sampled[-2] >= tb
+        stamps = sampled[sampled >= tb]
+        bound = tb
+        if len(stamps) > 0:
+            bound = int(stamps[-1]) if (last_ts and not before_last_ts) else int(stamps[-1]) + 1
+        return dict(first_step=tokens.shape[1] == self.sample_begin, without_timestamps=bool(self.o.without_timestamps),
+                    timestamp_begin=tb, eot=self.tok.eot,
+                    no_timestamps=-1 if self.tok.no_timestamps is None else int(self.tok.no_timestamps),
+                    ts_mode=0 if not last_ts else (1 if before_last_ts else 2), ts_bound=bound,
+                    max_initial=-1 if self.max_initial_ts is None else int(self.max_initial_ts))
+
     # -- the loop ------------------------------------------------------------------------------------------------------
     def run(self, mel_segment: Optional[np.ndarray], session: Optional[HipSession] = None) -> DecodingResult:
         o, tok, V = self.o, self.tok, self.model.dims.n_vocab
@@ -327,10 +345,26 @@ class _WindowDecoder:
         beam = BeamUpdate(o.beam_size, tok.eot, o.patience or 1.0) if o.beam_size is not None else None
         if beam is not None and beam.max_candidates <= 0:
             raise ValueError(f"Invalid beam size ({o.beam_size}) or patience ({o.patience})")
+        # greedy decoding of one sequence at temperature 0: rules, argmax and log-probability on the device, 8 bytes back per
+        # step (WLK_TRANSCRIBE_DEVICE_RULES=0: the host path below, which sampling and beam search always take)
+        device_rules = (beam is None and rows == 1 and o.temperature == 0 and hasattr(s, "pick_greedy")
+                        and os.environ.get("WLK_TRANSCRIBE_DEVICE_RULES", "1") != "0")
+        if device_rules:
+            s.set_rules(self.suppressed or [], self.blank_ids or [])
         for i in range(self.sample_len):
             s.decode(tokens if i == 0 else tokens[:, -1:], first=(i == 0), sot_index=self.sot_index)
             if i == 0 and tok.no_speech is not None:
                 no_speech = float(s.no_speech_prob(tok.no_speech)[0])
+            if device_rules:
+                nxt_id, picked = s.pick_greedy(**self._pick_state(tokens))
+                if tokens[0, -1] != tok.eot:
+                    sum_logprobs[0] += np.float32(picked)
+                else:
+                    nxt_id = tok.eot
+                tokens = np.concatenate([tokens, np.asarray([[nxt_id]], np.int64)], axis=1)
+                if nxt_id == tok.eot or tokens.shape[-1] > self.n_ctx:
+                    break
+                continue
             logits = _logits(s, rows, V)
             logprobs = self._apply_rules(logits, tokens)
             if beam is not None:
