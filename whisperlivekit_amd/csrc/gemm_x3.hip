@@ -570,7 +570,7 @@ __global__ __launch_bounds__(XW_THREADS) void gemm_x3_wide_kernel(X3GemmArgs g) 
 // (18 MFMAs, 9 fragment reads, 3 weight loads per slab - the workgroup's LDS and weight traffic is unchanged), waves v and
 // v + 4 share a SIMD, and one wave's stalls are the other one's issue slots.  Eight compute waves + three loaders = eleven
 // waves, three on a SIMD, i.e. 168 registers each: the fragments of planes mid and lo are read into the registers the MFMAs
-// have just consumed (lo after the first nine MFMAs of a slab, mid after twelve), only plane hi - used by the last six - is
+// have just consumed (lo after the first three MFMAs of a slab, mid after twelve), only plane hi - used by the last six - is
 // double-buffered, which needs slab t + 1 readable while slab t is multiplied: the slab barrier sits in FRONT of a slab's
 // MFMAs (the loaders' protocol is the one above, one slot less of look-ahead).  At the end of a tile the k-step-1 wave hands
 // its accumulators to its partner through the staging region (lane-private addresses: the same lane of the partner wave
@@ -773,12 +773,12 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
             }
         }
     };
-    xf32x4 wa[3], wb[3];                       // weight planes of the even / of the odd slabs (two slabs ahead of their MFMAs)
+    xf32x4 wa[3], wb[3];                       // weight planes of the slab being multiplied / of the next one
+#pragma unroll
+    for (int x = 0; x < 3; ++x) wb[x] = xf32x4{0.f, 0.f, 0.f, 0.f};
     const char* w_cur = w_base(slot0);
 #pragma unroll
     for (int x = 0; x < 3; ++x) wa[x] = *(wptr_t)(w_cur + 1024 * x);
-#pragma unroll
-    for (int x = 0; x < 3; ++x) wb[x] = *(wptr_t)(w_cur + XW_WSLAB_BYTES + 1024 * x);
     xf32x4 bias_next[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) bias_next[j] = xf32x4{0.f, 0.f, 0.f, 0.f};
@@ -791,34 +791,35 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
     xk_read3(f2, fa[2]);
     xk_wait9(f0a, f1, f2);
     unsigned ring_off = XW_SLAB_BYTES;         // byte offset of the ring slot of the slab being READ (one ahead of the MFMAs)
-    // one slab: the barrier behind which the next slab is readable, then the six plane products grouped by WEIGHT plane -
-    // (hi, hi) (mid, hi) (lo, hi) | (mid, mid) (hi, mid) | (hi, lo), activation plane first - so that a weight plane is dead as
-    // early as possible: the plane of slab t + 2 is loaded into the registers of slab t's as soon as its last MFMA has
-    // issued (two buffers, 1.5 - 1.8 slabs between a load and its first use; one slab ahead the MFMAs waited for weights
-    // that queue behind the loaders' pieces in the CU's in-order vector memory path).  Fragments: plane lo after the third
-    // product, plane mid after the fourth, plane hi (last use: the sixth) into its second buffer at the top.
-    auto slab = [&](const xf32x4 (&F0c)[3], xf32x4 (&F0n)[3], xf32x4 (&W)[3], const char* p2) {
+    // one slab: the barrier behind which the next slab is readable, then the six plane products in the one-wave kernel's order
+    // (small terms first: (lo, hi) (hi, lo) (mid, mid) (mid, hi) (hi, mid) (hi, hi), activation plane first) with the next
+    // slab's fragment reads and weight loads between them.  The weights are requested one slab ahead, in the order of their
+    // use and all in the first half of the slab: a whole slab of MFMAs lies between a load and its first use.  (Two slabs
+    // ahead, with the products regrouped by weight plane so that a plane's registers are free early, measured SLOWER:
+    // profiles/r06k_x3_ksplit_regrouped_probe.txt - weight latency is not what the loop waits for.)
+    auto slab = [&](const xf32x4 (&F0c)[3], xf32x4 (&F0n)[3], const xf32x4 (&Wc)[3], xf32x4 (&Wn)[3], const char* pn) {
         __builtin_amdgcn_s_barrier();
         xk_read3(F0n, fa[0] + ring_off);
         __builtin_amdgcn_sched_barrier(0);
-        mfma3(W[0], F0c);
-        mfma3(W[0], f1);
-        mfma3(W[0], f2);
+        mfma3(Wc[0], f2);
         __builtin_amdgcn_sched_barrier(0);
         xk_read3(f2, fa[2] + ring_off);
-        W[0] = *(wptr_t)(p2);
+        Wn[0] = *(wptr_t)(pn);
         __builtin_amdgcn_sched_barrier(0);
-        mfma3(W[1], f1);
+        mfma3(Wc[2], F0c);
+        __builtin_amdgcn_sched_barrier(0);
+        Wn[2] = *(wptr_t)(pn + 2048);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(Wc[1], f1);
+        __builtin_amdgcn_sched_barrier(0);
+        Wn[1] = *(wptr_t)(pn + 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(Wc[0], f1);
         __builtin_amdgcn_sched_barrier(0);
         xk_read3(f1, fa[1] + ring_off);
         __builtin_amdgcn_sched_barrier(0);
-        mfma3(W[1], F0c);
-        __builtin_amdgcn_sched_barrier(0);
-        W[1] = *(wptr_t)(p2 + 1024);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma3(W[2], F0c);
-        __builtin_amdgcn_sched_barrier(0);
-        W[2] = *(wptr_t)(p2 + 2048);
+        mfma3(Wc[1], F0c);
+        mfma3(Wc[0], F0c);
         __builtin_amdgcn_sched_barrier(0);
         xk_wait9(F0n, f1, f2);
         ring_off = ring_off == (unsigned)((XW_NB - 1) * XW_SLAB_BYTES) ? 0u : ring_off + (unsigned)XW_SLAB_BYTES;
@@ -839,11 +840,9 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
-        for (int tt = 0; tt < nslab; tt += 2) {           // (behind the tile's last slabs: the next tile's first two)
-            const bool wrap = tt + 2 >= nslab;
-            const char* const p2 = wrap ? w_next : w_cur + (long)(tt + 2) * XW_WSLAB_BYTES;
-            slab(f0a, f0b, wa, p2);
-            slab(f0b, f0a, wb, p2 + XW_WSLAB_BYTES);
+        for (int tt = 0; tt < nslab; tt += 2) {
+            slab(f0a, f0b, wa, wb, w_cur + (long)(tt + 1) * XW_WSLAB_BYTES);
+            slab(f0b, f0a, wb, wa, tt + 2 < nslab ? w_cur + (long)(tt + 2) * XW_WSLAB_BYTES : w_next);
         }
         w_cur = w_next;
         float* const gC = batched ? table_at(g.z.out, (unsigned)bz) : g.C;
