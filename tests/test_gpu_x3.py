@@ -21,7 +21,8 @@ def _err(x, ref):
 
 
 @pytest.mark.parametrize("M,N,K,flags", [(1500, 2048, 512, 1), (1500, 1536, 512, 4), (1500, 6144, 512, 4), (333, 1152, 384, 0),
-                                          (1500, 1280 * 3, 1280, 4), (257, 1024, 64, 1)])
+                                          (1500, 1280 * 3, 1280, 4), (257, 1024, 64, 1),
+                                          (1500, 1280, 1280, 0), (700, 1024, 256, 1)])     # (64-row tiles by the launch rule)
 def test_x3_gemm_is_as_close_to_float64_as_the_fp32_mfma_gemm(M, N, K, flags):
     lib = _lib.load()
     rng = np.random.default_rng(M + N + K)
@@ -137,3 +138,34 @@ def test_persistent_walk_is_bit_identical_to_one_workgroup_per_tile(M, N, K, fla
     if not flags & 1:
         ref[:, :N // 2] *= 0.5 if flags & 4 else 1.0
         assert float(np.abs(out["1"] - ref).max()) < 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("M,N,K,flags", [(1500, 1280, 1280, 0), (1500, 1280, 5120, 4), (1500, 2048, 512, 1), (333, 1152, 384, 0),
+                                         (2999, 1536, 384, 5), (64, 1024, 128, 0)])
+def test_tile_height_and_wave_split_do_not_change_an_element(M, N, K, flags, monkeypatch):
+    """Round 6: the two-wave kernel (a slab's k-steps split between the two compute waves of a SIMD) takes 64-row tiles where
+    96-row tiles leave CUs idle (WLK_X3_BM forces either).  An element's arithmetic does not depend on the tile height: both
+    heights give bit-identical results; against the one-wave kernel of round 5 (WLK_X3_KSPLIT=0), which groups a tile's K sum
+    differently, the difference stays at rounding level."""
+    lib = _lib.load()
+    rng = np.random.default_rng(M + N + K)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    out = {}
+    for name, env in (("bm96", {"WLK_X3_BM": "96"}), ("bm64", {"WLK_X3_BM": "64"}), ("one_wave", {"WLK_X3_KSPLIT": "0"})):
+        for k in ("WLK_X3_BM", "WLK_X3_KSPLIT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert lib.wlk_diag_env_refresh() == 0
+        c = np.full((M, N), np.nan, np.float32)
+        assert lib.wlk_diag_linear_x3(vp(a), vp(w), vp(bias), M, N, K, flags, 0.5, N // 2, vp(c)) == 0, lib.wlk_diag_last_error()
+        out[name] = c
+    for k in ("WLK_X3_BM", "WLK_X3_KSPLIT"):
+        monkeypatch.delenv(k, raising=False)
+    assert lib.wlk_diag_env_refresh() == 0
+    assert np.isfinite(out["bm96"]).all()
+    assert np.array_equal(out["bm96"].view(np.uint32), out["bm64"].view(np.uint32)), float(np.abs(out["bm96"] - out["bm64"]).max())
+    scale = float(np.abs(out["one_wave"]).max())
+    assert float(np.abs(out["bm96"] - out["one_wave"]).max()) <= 4e-6 * max(1.0, scale)

@@ -582,19 +582,38 @@ namespace {
 constexpr int XK_CW = 8;
 constexpr int XK_WAVES = XK_CW + XW_LOADERS;
 constexpr int XK_THREADS = XK_WAVES * 64;
-__device__ __forceinline__ void xk_read3(xf32x4 (&f)[3], unsigned addr) {       // one plane's fragments of the three row blocks
+template <int NRB>
+__device__ __forceinline__ void xk_read(xf32x4 (&f)[NRB], unsigned addr) {       // one plane's fragments of the tile's row blocks
     asm volatile("ds_read_b128 %0, %1" : "=v"(f[0]) : "v"(addr));
     asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(f[1]) : "v"(addr));
-    asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(f[2]) : "v"(addr));
+    if constexpr (NRB == 3) asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(f[2]) : "v"(addr));
 }
 static_assert(32 * XW_ROW_BYTES == 6144, "row-block stride of the fragment reads");
-__device__ __forceinline__ void xk_wait9(xf32x4 (&a)[3], xf32x4 (&b)[3], xf32x4 (&c)[3]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
-    asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
+template <int NRB>
+__device__ __forceinline__ void xk_wait(xf32x4 (&a)[NRB], xf32x4 (&b)[NRB], xf32x4 (&c)[NRB]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(c[0]), "+v"(c[1]));
+    if constexpr (NRB == 3) asm volatile("" : "+v"(a[2]), "+v"(b[2]), "+v"(c[2]));
 }
+// all but the newest (ring depth - 2) slabs of this loader have landed
+template <int NPW>
+__device__ __forceinline__ void xk_wait_landed() {
+    static_assert(NPW == 6 || NPW == 4, "update the vmcnt literals");
+    if constexpr (NPW == 6) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+static_assert(XW_DT - 1 == 3, "xk_wait_landed's literals are 3 slabs of NPW pieces");
 }  // namespace
 
+// BM = 96 (three 32-row blocks per wave: the shapes above) or 64 (two: the N = d projections of the d >= 1024 models, whose 96-row
+// tiles are 160 workgroups on 256 CUs - 24 x 10 = 240 tiles of 64 rows fill the chip with two thirds of the work each).  Per-element
+// arithmetic does not depend on BM.
+template <int BM>
 __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g) {
+    constexpr int NRB = BM / 32;                              // row blocks of a wave's part of the tile
+    constexpr int SLAB_BYTES = BM * XW_ROW_BYTES;             // activation rows of a slab: 18 432 / 12 288
+    constexpr int NPW = SLAB_BYTES / 1024 / XW_LOADERS;       // DMA pieces per loader wave and slab: 6 / 4
+    constexpr int STAGE_OFF = XW_NB * SLAB_BYTES;             // the staging region behind the ring
+    static_assert(NPW * XW_LOADERS * 1024 == SLAB_BYTES, "a slab is a whole number of 1 KiB pieces per loader");
     asm volatile("" ::"s"(g.A3), "s"(g.lda), "s"(g.W3), "s"(g.bias), "s"(g.C), "s"(g.ldc), "s"(g.R), "s"(g.ldr), "s"(g.M),
                  "s"(g.N), "s"(g.K), "s"(g.flags), "s"(g.scale), "s"(g.scale_cols), "s"(g.scale_period), "s"(g.batch));
     __builtin_amdgcn_sched_barrier(0);
@@ -603,7 +622,7 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool batched = g.batch > 0;
     // ---- the tile walk (as in gemm_x3_wide_kernel) --------------------------------------------------------------------
-    const int tiles_m = (g.M + XW_BM - 1) / XW_BM, tiles_n = (g.N + XW_BN - 1) / XW_BN;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + XW_BN - 1) / XW_BN;
     const bool banded = g.walk_banded != 0;
     const int band_m = banded ? (tiles_m + 3) / 4 : tiles_m, band_n = banded ? (tiles_n + 1) / 2 : tiles_n;
     const int per_session = band_m * band_n;
@@ -641,11 +660,11 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
     auto shared_epilogue = [&](int m0, int n0, int bz) {
         float* const gC = batched ? table_at(g.z.out, (unsigned)bz) : g.C;
         const float* const gR = batched ? table_at(g.z.res, (unsigned)bz) : g.R;
-        const float* const stage = reinterpret_cast<const float*>(lds + XW_STAGE_OFF);
+        const float* const stage = reinterpret_cast<const float*>(lds + STAGE_OFF);
         const int colq = lane & 7, rsub = lane >> 3;
-        constexpr int ITEMS = 4 * (XW_BM / 8);
+        constexpr int ITEMS = 4 * (BM / 8);
         auto bias_of_item = [&](int k) -> xf32x4 {
-            const int c = min(n0 + 32 * (min(k, ITEMS - 1) / (XW_BM / 8)) + 4 * colq, g.N - 4);
+            const int c = min(n0 + 32 * (min(k, ITEMS - 1) / (BM / 8)) + 4 * colq, g.N - 4);
             return g.bias ? *reinterpret_cast<const xf32x4*>(g.bias + c) : xf32x4{0.f, 0.f, 0.f, 0.f};
         };
         xf32x4 bq = bias_of_item(wave);
@@ -655,10 +674,10 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
 #pragma unroll 1
         for (int k = wave; k < ITEMS; k += XK_WAVES) {
             const xf32x4 bq_next = bias_of_item(k + XK_WAVES);
-            const int wp = k / (XW_BM / 8), it = k - wp * (XW_BM / 8);
+            const int wp = k / (BM / 8), it = k - wp * (BM / 8);
             const int row_t = 8 * it + rsub, row = m0 + row_t;
             const int col = n0 + 32 * wp + 4 * colq;
-            xf32x4 v = *reinterpret_cast<const xf32x4*>(stage + (wp * XW_BM + row_t) * XW_WPITCH + 4 * colq);
+            xf32x4 v = *reinterpret_cast<const xf32x4*>(stage + (wp * BM + row_t) * XW_WPITCH + 4 * colq);
             const xf32x4 res = has_res ? *reinterpret_cast<const xf32x4*>(gR + (long)min(row, g.M - 1) * g.ldr + min(col, g.N - 4))
                                        : xf32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -676,10 +695,10 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
     if (wave >= XK_CW) {
         // ---- loader (the code of gemm_x3_wide_kernel's loaders; barriers per tile: slabs + fold + epilogue) ----------------
         const int lw = wave - XK_CW;
-        const char* src[XW_NPW];
-        int row_of[XW_NPW], unit_of[XW_NPW];
+        const char* src[NPW];
+        int row_of[NPW], unit_of[NPW];
 #pragma unroll
-        for (int i = 0; i < XW_NPW; ++i) {
+        for (int i = 0; i < NPW; ++i) {
             const int byte = 1024 * (lw + XW_LOADERS * i) + 16 * lane;
             row_of[i] = byte / XW_ROW_BYTES;
             unit_of[i] = (((byte - row_of[i] * XW_ROW_BYTES) >> 4) ^ ((row_of[i] >> 2) & 3)) * 16;
@@ -687,18 +706,18 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
         auto set_src = [&](int slot) {
             int tm, tn, b;
             decode(slot, tm, tn, b);
-            const int m0 = tm * XW_BM;
+            const int m0 = tm * BM;
             const char* const gA = reinterpret_cast<const char*>(batched ? reinterpret_cast<const unsigned short*>(table_at(g.z.in, (unsigned)b)) : g.A3);
 #pragma unroll
-            for (int i = 0; i < XW_NPW; ++i) src[i] = gA + (long)min(m0 + row_of[i], g.M - 1) * g.lda * 6 + unit_of[i];
+            for (int i = 0; i < NPW; ++i) src[i] = gA + (long)min(m0 + row_of[i], g.M - 1) * g.lda * 6 + unit_of[i];
         };
         int issue_slot = slot0, s_next = 0, ring = 0;
         bool more = true;
         set_src(issue_slot);
         auto issue_one = [&]() {
             const long adv = (long)s_next * XW_ROW_BYTES;
-            unsigned char* const dst = lds + ring * XW_SLAB_BYTES + lw * 1024;
-            x3_static_for<XW_NPW>([&](auto I) {
+            unsigned char* const dst = lds + ring * SLAB_BYTES + lw * 1024;
+            x3_static_for<NPW>([&](auto I) {
                 constexpr int i = decltype(I)::value;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + adv),
                                                  (__attribute__((address_space(3))) void*)(dst + i * XW_LOADERS * 1024), 16, 0, 0);
@@ -718,12 +737,12 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
         };
 #pragma unroll
         for (int i = 0; i < XW_DT; ++i) issue_one();
-        xw_wait_landed();
+        xk_wait_landed<NPW>();
         __builtin_amdgcn_s_barrier();
         for (int slot = slot0; slot < limit; slot = advance(slot + stride)) {
             for (int tt = 0; tt < nslab; ++tt) {
                 issue_one();
-                xw_wait_landed();
+                xk_wait_landed<NPW>();
                 __builtin_amdgcn_s_barrier();
             }
             __builtin_amdgcn_s_barrier();          // the fold: the k-step-1 waves' accumulators are in the staging region
@@ -733,7 +752,7 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
             } else {
                 int tm, tn, bz;
                 decode(slot, tm, tn, bz);
-                shared_epilogue(tm * XW_BM, tn * XW_BN, bz);
+                shared_epilogue(tm * BM, tn * XW_BN, bz);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -748,10 +767,10 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
     unsigned fa[3];                        // plane p's fragment of row block 0 in ring slot 0: lane (r, hi) reads row r, chunk 2 half + hi
 #pragma unroll
     for (int p = 0; p < 3; ++p) fa[p] = lds_base + (unsigned)(r * XW_ROW_BYTES) + (unsigned)((((2 * half + hi) * 3 + p) ^ swz) * 16);
-    xf32x16 acc[3];
-    auto mfma3 = [&](const xf32x4& w, const xf32x4 (&f)[3]) {
+    xf32x16 acc[NRB];
+    auto mfma3 = [&](const xf32x4& w, const xf32x4 (&f)[NRB]) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < NRB; ++i)
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, f[i]), acc[i], 0, 0, 0);
     };
     const int n_blocks = (g.N + 31) / 32;
@@ -785,25 +804,25 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
     load_bias(slot0, bias_next);
 
     __builtin_amdgcn_s_barrier();              // slab 0 has landed
-    xf32x4 f0a[3], f0b[3], f1[3], f2[3];       // plane hi (two buffers), mid, lo
-    xk_read3(f0a, fa[0]);
-    xk_read3(f1, fa[1]);
-    xk_read3(f2, fa[2]);
-    xk_wait9(f0a, f1, f2);
-    unsigned ring_off = XW_SLAB_BYTES;         // byte offset of the ring slot of the slab being READ (one ahead of the MFMAs)
+    xf32x4 f0a[NRB], f0b[NRB], f1[NRB], f2[NRB];       // plane hi (two buffers), mid, lo
+    xk_read<NRB>(f0a, fa[0]);
+    xk_read<NRB>(f1, fa[1]);
+    xk_read<NRB>(f2, fa[2]);
+    xk_wait<NRB>(f0a, f1, f2);
+    unsigned ring_off = SLAB_BYTES;         // byte offset of the ring slot of the slab being READ (one ahead of the MFMAs)
     // one slab: the barrier behind which the next slab is readable, then the six plane products in the one-wave kernel's order
     // (small terms first: (lo, hi) (hi, lo) (mid, mid) (mid, hi) (hi, mid) (hi, hi), activation plane first) with the next
     // slab's fragment reads and weight loads between them.  The weights are requested one slab ahead, in the order of their
     // use and all in the first half of the slab: a whole slab of MFMAs lies between a load and its first use.  (Two slabs
     // ahead, with the products regrouped by weight plane so that a plane's registers are free early, measured SLOWER:
     // profiles/r06k_x3_ksplit_regrouped_probe.txt - weight latency is not what the loop waits for.)
-    auto slab = [&](const xf32x4 (&F0c)[3], xf32x4 (&F0n)[3], const xf32x4 (&Wc)[3], xf32x4 (&Wn)[3], const char* pn) {
+    auto slab = [&](const xf32x4 (&F0c)[NRB], xf32x4 (&F0n)[NRB], const xf32x4 (&Wc)[3], xf32x4 (&Wn)[3], const char* pn) {
         __builtin_amdgcn_s_barrier();
-        xk_read3(F0n, fa[0] + ring_off);
+        xk_read<NRB>(F0n, fa[0] + ring_off);
         __builtin_amdgcn_sched_barrier(0);
         mfma3(Wc[0], f2);
         __builtin_amdgcn_sched_barrier(0);
-        xk_read3(f2, fa[2] + ring_off);
+        xk_read<NRB>(f2, fa[2] + ring_off);
         Wn[0] = *(wptr_t)(pn);
         __builtin_amdgcn_sched_barrier(0);
         mfma3(Wc[2], F0c);
@@ -816,19 +835,19 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
         __builtin_amdgcn_sched_barrier(0);
         mfma3(Wc[0], f1);
         __builtin_amdgcn_sched_barrier(0);
-        xk_read3(f1, fa[1] + ring_off);
+        xk_read<NRB>(f1, fa[1] + ring_off);
         __builtin_amdgcn_sched_barrier(0);
         mfma3(Wc[1], F0c);
         mfma3(Wc[0], F0c);
         __builtin_amdgcn_sched_barrier(0);
-        xk_wait9(F0n, f1, f2);
-        ring_off = ring_off == (unsigned)((XW_NB - 1) * XW_SLAB_BYTES) ? 0u : ring_off + (unsigned)XW_SLAB_BYTES;
+        xk_wait<NRB>(F0n, f1, f2);
+        ring_off = ring_off == (unsigned)((XW_NB - 1) * SLAB_BYTES) ? 0u : ring_off + (unsigned)SLAB_BYTES;
     };
     for (int slot = slot0; slot < limit;) {
         int tile_m, tile_n, bz;
         decode(slot, tile_m, tile_n, bz);
         const int next_slot = advance(slot + stride);
-        const int m0 = tile_m * XW_BM, n0 = tile_n * XW_BN;
+        const int m0 = tile_m * BM, n0 = tile_n * XW_BN;
         const int col0 = n0 + col_in_tile;
         const char* const w_next = next_slot < limit ? w_base(next_slot) : w_cur;
         xf32x4 bias[4];
@@ -837,7 +856,7 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
         if (next_slot < limit) load_bias(next_slot, bias_next);
         auto scaled = [&](int col) { return (g.flags & kGemmScaleCols) && (g.scale_period ? col % g.scale_period : col) < g.scale_cols; };
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < NRB; ++i)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
         for (int tt = 0; tt < nslab; tt += 2) {
@@ -848,10 +867,10 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
         float* const gC = batched ? table_at(g.z.out, (unsigned)bz) : g.C;
         if (x3_out) {
             constexpr int PITCH = XW_STAGE_PITCH;
-            float* const stage = reinterpret_cast<float*>(lds + XW_STAGE_OFF);
+            float* const stage = reinterpret_cast<float*>(lds + STAGE_OFF);
             if (half == 1) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < NRB; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         *reinterpret_cast<xf32x4*>(stage + (32 * i + r) * PITCH + col_in_tile + 8 * j) =
@@ -861,7 +880,7 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
             __builtin_amdgcn_s_barrier();          // fold
             if (half == 0) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
+                for (int i = 0; i < NRB; ++i) {
                     float* const srow = stage + (32 * i + r) * PITCH + col_in_tile;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -884,7 +903,7 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
             unsigned short* const c3 = batched ? reinterpret_cast<unsigned short*>(gC) : g.C3;
             const int tid = threadIdx.x;           // 0 .. 511: the compute waves
             if (n0 < g.vt_col0) {
-                for (int item = tid; item < XW_BM * (XW_BN / 8); item += XK_CW * 64) {
+                for (int item = tid; item < BM * (XW_BN / 8); item += XK_CW * 64) {
                     const int row = item >> 4, c = item & 15;
                     if (m0 + row < g.M && n0 + 8 * c < g.N) {
                         const float4 a = *reinterpret_cast<const float4*>(stage + row * PITCH + 8 * c);
@@ -895,8 +914,8 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
                 }
             } else {
                 unsigned short* const vt = c3 + g.vt_off;
-                for (int item = tid; item < XW_BN * (XW_BM / 8); item += XK_CW * 64) {
-                    const int dcol = item / (XW_BM / 8), u = item - dcol * (XW_BM / 8);
+                for (int item = tid; item < XW_BN * (BM / 8); item += XK_CW * 64) {
+                    const int dcol = item / (BM / 8), u = item - dcol * (BM / 8);
                     const int r0 = 32 * (u >> 2) + 4 * (u & 3);
                     if (n0 + dcol < g.N && m0 + 32 * (u >> 2) < g.vt_ld) {
                         float v[8];
@@ -912,10 +931,10 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();          // the staging region may be written again
         } else {
-            float* const wst = reinterpret_cast<float*>(lds + XW_STAGE_OFF) + cb * (XW_BM * XW_WPITCH);
+            float* const wst = reinterpret_cast<float*>(lds + STAGE_OFF) + cb * (BM * XW_WPITCH);
             if (half == 1) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < NRB; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         *reinterpret_cast<xf32x4*>(wst + (32 * i + r) * XW_WPITCH + 8 * j + 4 * hi) =
@@ -925,7 +944,7 @@ __global__ __launch_bounds__(XK_THREADS) void gemm_x3_wide2_kernel(X3GemmArgs g)
             __builtin_amdgcn_s_barrier();          // fold
             if (half == 0) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < NRB; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float* const p = wst + (32 * i + r) * XW_WPITCH + 8 * j + 4 * hi;
@@ -950,9 +969,11 @@ bool gemm_x3_wide_applicable(int M, int N, int K, long lda) {
 
 static std::atomic<int> g_x3_persist{-1};                // -1: WLK_X3_PERSIST not read yet
 static std::atomic<int> g_x3_ksplit{-1};                 // -1: WLK_X3_KSPLIT not read yet (1: gemm_x3_wide2_kernel, the default)
+static std::atomic<int> g_x3_bm{-1};                     // -1: WLK_X3_BM not read yet (0: by the rounds x rows rule)
 void x3_refresh_env_switches() {
     g_x3_persist.store(-1, std::memory_order_relaxed);
     g_x3_ksplit.store(-1, std::memory_order_relaxed);
+    g_x3_bm.store(-1, std::memory_order_relaxed);
 }
 
 void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) {
@@ -980,11 +1001,54 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
         WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
         WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
         WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
-        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide2_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
+        WLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_wide2_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
         configured.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
-    const int tiles_m = (g.M + XW_BM - 1) / XW_BM, tiles_n = (g.N + XW_BN - 1) / XW_BN;
     const int batch = g.batch > 0 ? g.batch : 1;
+    // Timing ablations of scripts/x3_probe.py.  Variants 1-5 skip MFMAs, DMA pieces or weight loads and produce WRONG results, so a
+    // stray WLK_X3_ABL on a serving box must not reach them: they need WLK_PROBES=1 beside it and announce themselves once.
+    static const int abl = [] {
+        const char* e = getenv("WLK_X3_ABL");
+        int v = e ? atoi(e) : 0;
+        if (v >= 1 && v <= 5) {
+            const char* ok = getenv("WLK_PROBES");
+            if (!(ok && ok[0] == '1')) {
+                fprintf(stderr, "libwlk_hip: WLK_X3_ABL=%d ignored (result-corrupting timing ablation; set WLK_PROBES=1 to run it)\n", v);
+                v = 0;
+            } else {
+                fprintf(stderr, "libwlk_hip: WLK_X3_ABL=%d ACTIVE - the X3 GEMM results of this process are WRONG (timing probe)\n", v);
+            }
+        }
+        return v;
+    }();
+    int ksplit = g_x3_ksplit.load(std::memory_order_relaxed);
+    if (ksplit < 0) {
+        const char* e = getenv("WLK_X3_KSPLIT");
+        ksplit = !(e && e[0] == '0');
+        g_x3_ksplit.store(ksplit, std::memory_order_relaxed);
+    }
+    const bool wide2 = ksplit && abl == 0;
+    static std::atomic<int> cu_count[64];
+    int cus = cu_count[dev & 63].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        WLK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (cus < 8) cus = 8;
+        cu_count[dev & 63].store(cus, std::memory_order_relaxed);
+    }
+    // tile height (two-wave kernel only): 64-row tiles where they cut the rounds x rows a CU works through by a quarter or more -
+    // the N = d projections of the d >= 1024 models (N = 1280: 160 tiles of 96 rows on 256 CUs, 240 of 64).  WLK_X3_BM=64 / 96 forces.
+    int bm_env = g_x3_bm.load(std::memory_order_relaxed);
+    if (bm_env < 0) {
+        const char* e = getenv("WLK_X3_BM");
+        bm_env = e ? atoi(e) : 0;
+        g_x3_bm.store(bm_env, std::memory_order_relaxed);
+    }
+    const int tiles_n = (g.N + XW_BN - 1) / XW_BN;
+    auto rounds_rows = [&](int bm) { return (long)(((long)((g.M + bm - 1) / bm) * tiles_n * batch + cus - 1) / cus) * bm; };
+    int bm = XW_BM;
+    if (wide2 && (bm_env == 64 || (bm_env == 0 && 4 * rounds_rows(64) <= 3 * rounds_rows(XW_BM)))) bm = 64;
+    const int tiles_m = (g.M + bm - 1) / bm;
     // WLK_X3_MAP=1 (probe): plain row-major tile order instead of the XCD bands; WLK_X3_PERSIST=0: one workgroup per
     // tile (the round-4 launch: same kernel, every list has one entry)
     static const int map_mode = [] {
@@ -996,13 +1060,6 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
         const char* e = getenv("WLK_X3_PERSIST");
         persist = !(e && e[0] == '0');
         g_x3_persist.store(persist, std::memory_order_relaxed);
-    }
-    static std::atomic<int> cu_count[64];
-    int cus = cu_count[dev & 63].load(std::memory_order_relaxed);
-    if (cus == 0) {
-        WLK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        if (cus < 8) cus = 8;
-        cu_count[dev & 63].store(cus, std::memory_order_relaxed);
     }
     // column-major walk inside a band: the workgroups resident at a time share weight blocks 4-fold and a persistent
     // workgroup keeps its activation rows from tile to tile (cross-K|V 71 -> 67 us, large-v3 fc1 154 -> 147); with several
@@ -1026,31 +1083,10 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
     // algorithmic work (what the roofline fraction is computed from): 2 M N K flop, operands and result once
     KernelScope ks(ctx, tag, 2.0 * batch * (double)g.M * g.N * g.K,
                    batch * (6.0 * ((double)g.M * g.K) + 4.0 * (double)g.M * g.N) + 6.0 * (double)g.N * g.K);
-    // Timing ablations of scripts/x3_probe.py.  Variants 1-5 skip MFMAs, DMA pieces or weight loads and produce WRONG results, so a
-    // stray WLK_X3_ABL on a serving box must not reach them: they need WLK_PROBES=1 beside it and announce themselves once.
-    static const int abl = [] {
-        const char* e = getenv("WLK_X3_ABL");
-        int v = e ? atoi(e) : 0;
-        if (v >= 1 && v <= 5) {
-            const char* ok = getenv("WLK_PROBES");
-            if (!(ok && ok[0] == '1')) {
-                fprintf(stderr, "libwlk_hip: WLK_X3_ABL=%d ignored (result-corrupting timing ablation; set WLK_PROBES=1 to run it)\n", v);
-                v = 0;
-            } else {
-                fprintf(stderr, "libwlk_hip: WLK_X3_ABL=%d ACTIVE - the X3 GEMM results of this process are WRONG (timing probe)\n", v);
-            }
-        }
-        return v;
-    }();
     const dim3 grid(blocks);
-    int ksplit = g_x3_ksplit.load(std::memory_order_relaxed);
-    if (ksplit < 0) {
-        const char* e = getenv("WLK_X3_KSPLIT");
-        ksplit = !(e && e[0] == '0');
-        g_x3_ksplit.store(ksplit, std::memory_order_relaxed);
-    }
-    if (ksplit && abl == 0) {
-        hipLaunchKernelGGL(gemm_x3_wide2_kernel, grid, dim3(XK_THREADS), XW_LDS_BYTES, ctx.stream, gg);
+    if (wide2) {
+        if (bm == 64) hipLaunchKernelGGL(gemm_x3_wide2_kernel<64>, grid, dim3(XK_THREADS), XW_LDS_BYTES, ctx.stream, gg);
+        else hipLaunchKernelGGL(gemm_x3_wide2_kernel<96>, grid, dim3(XK_THREADS), XW_LDS_BYTES, ctx.stream, gg);
         WLK_HIP(hipGetLastError());
         return;
     }
