@@ -1036,8 +1036,11 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
         if (cus < 8) cus = 8;
         cu_count[dev & 63].store(cus, std::memory_order_relaxed);
     }
-    // tile height (two-wave kernel only): 64-row tiles where they cut the rounds x rows a CU works through by a quarter or more -
-    // the N = d projections of the d >= 1024 models (N = 1280: 160 tiles of 96 rows on 256 CUs, 240 of 64).  WLK_X3_BM=64 / 96 forces.
+    // tile height (two-wave kernel only): 64-row tiles where they cut the rounds x rows a CU works through by a tenth or more - the
+    // N = d projections of the d >= 1024 models (N = 1280: 160 tiles of 96 rows on 256 CUs, 240 of 64: 40.1 -> 31.7 us at K = 1280,
+    // 140.9 -> 120.0 at K = 5120) and large-v3's fc1 (640 tiles = 3 rounds of 96 rows, 960 = 4 rounds of 64: 137.4 -> 131.4 us); at
+    // equal rounds x rows the 96-row tile's loop wins (18 MFMAs per three weight loads against 12: base fc1 25.7 vs 31.1 us).
+    // profiles/r06l_x3_bm64_probe.txt.  WLK_X3_BM=64 / 96 forces either; an element's arithmetic does not depend on it.
     int bm_env = g_x3_bm.load(std::memory_order_relaxed);
     if (bm_env < 0) {
         const char* e = getenv("WLK_X3_BM");
@@ -1047,7 +1050,7 @@ void launch_gemm_x3(const LaunchCtx& ctx, const X3GemmArgs& g, const char* tag) 
     const int tiles_n = (g.N + XW_BN - 1) / XW_BN;
     auto rounds_rows = [&](int bm) { return (long)(((long)((g.M + bm - 1) / bm) * tiles_n * batch + cus - 1) / cus) * bm; };
     int bm = XW_BM;
-    if (wide2 && (bm_env == 64 || (bm_env == 0 && 4 * rounds_rows(64) <= 3 * rounds_rows(XW_BM)))) bm = 64;
+    if (wide2 && (bm_env == 64 || (bm_env == 0 && 10 * rounds_rows(64) <= 9 * rounds_rows(XW_BM)))) bm = 64;
     const int tiles_m = (g.M + bm - 1) / bm;
     // WLK_X3_MAP=1 (probe): plain row-major tile order instead of the XCD bands; WLK_X3_PERSIST=0: one workgroup per
     // tile (the round-4 launch: same kernel, every list has one entry)
