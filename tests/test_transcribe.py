@@ -280,3 +280,56 @@ def test_sessions_of_ended_threads_are_released(real_vocab):
     assert list(model.__dict__["_batch_rows"]) == [threading.get_ident()]
     TR.release_sessions(model)
     assert closed == created
+
+
+def _allowed_by_pick_params(p, suppressed, blank, n_vocab):
+    """The token set wlk_pick_greedy's kernel keeps (csrc/select.hip: rules_pick_kernel's `allowed`), restated over the
+    wlk_pick_params fields: what the C ABI promises for a given parameter block."""
+    v = np.arange(n_vocab)
+    ok = np.ones(n_vocab, bool)
+    ok[list(suppressed)] = False
+    if p["first_step"]:
+        ok[list(blank)] = False
+    if p["without_timestamps"]:
+        return ok
+    tb = p["timestamp_begin"]
+    if p["no_timestamps"] >= 0:
+        ok[p["no_timestamps"]] = False
+    if p["ts_mode"] == 1:
+        ok &= v < tb
+    if p["ts_mode"] == 2:
+        ok &= v >= p["eot"]
+    ok &= ~((v >= tb) & (v < p["ts_bound"]))
+    if p["first_step"]:
+        ok &= v >= tb
+        if p["max_initial"] >= 0:
+            ok &= v < tb + p["max_initial"] + 1
+    return ok
+
+
+@pytest.mark.parametrize("options", [dict(), dict(without_timestamps=True), dict(suppress_blank=False, suppress_tokens=""),
+                                     dict(max_initial_timestamp=None), dict(prompt="hello there", suppress_tokens="1,2,-1")])
+def test_pick_params_describe_the_mask_of_the_host_rules(options, real_vocab):
+    """The host half of the device rules: for token histories on every branch of ApplyTimestampRules, the parameter block
+    `_pick_state` hands to wlk_pick_greedy describes exactly the set of tokens `_apply_rules` (the form followed against the
+    reference's recorded choices above) leaves finite - before the data-dependent "timestamps outweigh text" rule, which the
+    kernel applies to the logits itself."""
+    from oracle_session import OracleModel
+    model = OracleModel("micro", 0)
+    dec = TR._WindowDecoder(model, TR.DecodingOptions(language="en", temperature=0.0, **options))
+    V = model.dims.n_vocab
+    tb, eot = dec.tok.timestamp_begin, dec.tok.eot
+    rng = np.random.default_rng(5)
+    text = lambda n: [int(t) for t in rng.integers(300, 20000, n)]
+    histories = [[], [tb], [tb + 3], [tb, *text(3)], [tb, *text(2), tb + 40], [tb, *text(2), tb + 40, tb + 40],
+                 [tb, *text(1), tb + 40, tb + 40, *text(2)], [tb, *text(4), tb + 1499], [tb, *text(2), tb + 700, tb + 700, eot],
+                 text(5), [tb + 1500], [tb, *text(2), tb + 1500, tb + 1500]]
+    for hist in histories:
+        tokens = np.asarray([list(dec.initial) + hist], np.int64)
+        # logits under which the data-dependent rule stays silent: text far above the timestamps
+        logits = np.zeros((1, V), np.float32)
+        logits[0, :tb] = 50.0
+        dec._apply_rules(logits, tokens)
+        want = np.isfinite(logits[0])
+        got = _allowed_by_pick_params(dec._pick_state(tokens), dec.suppressed or [], dec.blank_ids or [], V)
+        assert np.array_equal(got, want), (options, hist, np.flatnonzero(got != want)[:8])
