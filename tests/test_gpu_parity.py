@@ -518,6 +518,27 @@ def test_stream_through_library_decode_loop(case):
             p.close()
 
 
+@pytest.mark.parametrize("case", ["micro_12s", "base_4s", "bench_base_30s_s0"])
+def test_early_zscore_beside_the_vocabulary_projection_changes_nothing(case, monkeypatch):
+    """A graph-replayed step runs the AlignAtt z-score as side workgroups of the vocabulary projection's launch, the medians /
+    arg-max beside the top-k slice pass, and ends in the 64-thread fold alone (select.hip: select_stage1_early_kernel).  Same
+    device functions in other launches: every token, attended frame and summed log-probability of a stream must be the bits
+    of the two-launch read-out behind the logits (WLK_EARLY_Z=0, read when a session captures its step graph)."""
+    if not H.golden_exists(f"stream_{case}.json"):
+        pytest.skip(f"golden stream {case} not generated")
+    runs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("WLK_EARLY_Z", flag)
+        g, proc, got = replay_stream(case, make_hip_loop_processor)
+        try:
+            words = [[(t.start, t.end, t.text) for t in toks] for ev, toks, _ in got if ev["kind"] == "chunk"]
+            runs.append((proc.model.decision_log, words))
+            assert sum(len(d[1]) for d in proc.model.decision_log) > 0
+        finally:
+            proc.close()
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]
+
+
 def test_barrier_free_single_row_gemv_is_bit_identical_to_the_staged_kernel(tmp_path):
     """gemv1_f32_kernel (beam-1 decode steps: no LDS, no barrier) keeps the staged kernel's reduction and fmaf
     order, so switching it off (WLK_NO_GEMV1, read once per process) must not change a single bit."""

@@ -484,7 +484,7 @@ int wlk_session_create(wlk_model* m, int beam, int max_audio_samples, wlk_sessio
         s->fsplit = dev_alloc<float>(flash_split_scratch_floats(s->max_rows, D.n_text_head, wlk_session::kFlashSplitsMax));
         // partial softmax states of the encoder attention's key splits (<= 8 per (query, head))
         s->esplit = dev_alloc<float>(flash_split_scratch_floats(D.n_audio_ctx, D.n_audio_head, 8));
-        s->z = dev_alloc<float>((size_t)beam * std::max(m->n_align, 1) * T);
+        s->z = dev_alloc<float>((size_t)beam * std::max(m->n_align, 1) * T + (size_t)beam * 128);   // + the read-out's per-block (value, frame) pairs
         s->attn_last = dev_alloc_zero<float>((size_t)beam * T, st);
         s->adj_row = dev_alloc<int>(3 * wlk_session::kAdjCap);   // [rows n | ids n | deltas n] packed per call
         s->src_rows = dev_alloc<int>(8);
@@ -558,6 +558,7 @@ int wlk_session_destroy(wlk_session* s) {
     if (s->dec_stage_ev) (void)hipEventDestroy(s->dec_stage_ev);
     if (s->step_host) (void)hipHostFree(s->step_host);
     if (s->step_dev) (void)hipFree(s->step_dev);
+    if (s->step_align_dev) (void)hipFree(s->step_align_dev);
     for (auto& e : s->fstep_exec)
         if (e) (void)hipGraphExecDestroy(e);
     for (auto& r : s->prof.recs) {
@@ -1043,7 +1044,7 @@ static void mall_prefetch_prepare(wlk_session* s) {
 }
 
 static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n_tok, bool first, int sot_index,
-                           bool step_block = false) {
+                           bool step_block = false, const AlignArgs* side_align = nullptr, int side_blocks = 0, int side_zf = 0) {
     wlk_model* m = s->m;
     const wlk_dims& D = m->D;
     const int ctx_len = D.n_text_ctx;
@@ -1189,8 +1190,12 @@ static void enqueue_decode(wlk_session* s, const LaunchCtx& c, int n_rows, int n
     // final LayerNorm + vocabulary projection only for the rows the policy reads
     GemmArgs lg;
     lg.lda = d; lg.W = m->w_tok_emb; lg.C = s->logits_last; lg.ldc = V; lg.M = n_rows; lg.N = V; lg.K = d;
+    if (side_align && !fused) throw std::logic_error("decode: side workgroups need the fused step");
     if (fused) {   // n_tok == 1: the last row of beam b is row b
         lg.A = s->dx; lg.ln_gamma = m->w_ln_w; lg.ln_beta = m->w_ln_b;
+        // graph-replayed steps: the alignment window is complete behind the last layer's cross-attention, so its z-score
+        // rides in this launch (gemv_f32_kernel's side workgroups) instead of in front of the step's last two
+        lg.side_align = side_align; lg.side_blocks = side_blocks; lg.side_zf = side_zf;
         launch_gemv(c, lg, "dec_lnf_logits");
     } else if (first && n_rows == 1 && gemv_applicable(2, d) && getenv("WLK_NO_PREFILL_MERGE") == nullptr) {
         // beam-1 prefill: the last row and the sot row (no-speech probability) normalised by one launch (a negative
@@ -1679,19 +1684,31 @@ extern "C++" int wlk_step_select(wlk_session* s, int64_t token, const int32_t* a
         if (!exec) {
             hipGraph_t graph = nullptr;
             mall_prefetch_prepare(s);
+            const int zf_blocks = (a.T + 63) / 64;
+            if (!s->step_align_dev) {      // the read-out's arguments as the side workgroups see them: everything that changes
+                AlignArgs ad = a;          // from step to step comes through `rows` (the step's device block)
+                ad.rows = &s->step_dev->row;
+                s->step_align_dev = reinterpret_cast<AlignArgs*>(dev_alloc<char>(sizeof(AlignArgs)));
+                WLK_HIP(hipMemcpyAsync(s->step_align_dev, &ad, sizeof(AlignArgs), hipMemcpyHostToDevice, s->stream));
+            }
             WLK_HIP(hipStreamSynchronize(s->stream));
             WLK_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
             try {
-                s->pf_marks = true;
-                enqueue_decode(s, c, 1, 1, false, 0, true);
-                s->pf_marks = false;
                 a.rows = &s->step_dev->row;
+                a.part = s->z + (size_t)s->beam * std::max(m->n_align, 1) * D.n_audio_ctx;
+                // the vocabulary projection's weights are a (V / 4 / 4 > 2048 workgroups) stream long enough to hide the z-score
+                const bool early_z = select_early_z_enabled() && D.n_vocab >= 16384;
+                s->pf_marks = true;
+                if (early_z) enqueue_decode(s, c, 1, 1, false, 0, true, s->step_align_dev, zf_blocks * a.n_align * a.n_beam, zf_blocks);
+                else enqueue_decode(s, c, 1, 1, false, 0, true);
+                s->pf_marks = false;
                 StepHostOut ho;
                 ho.result = s->result_host_dev;
                 ho.n_adj = &s->step_dev->n_adj;
                 ho.seq = &s->step_dev->seq;
                 if (!launch_select_fused(c, s->logits_last, D.n_vocab, 1, 2, s->top_vals, s->top_ids, s->topk_scratch,
-                                         s->step_dev->adj_row, s->step_dev->adj_ids, s->step_dev->adj_deltas, 0, a, ho))
+                                         s->step_dev->adj_row, s->step_dev->adj_ids, s->step_dev->adj_deltas, 0, a, ho, nullptr, 0,
+                                         nullptr, early_z))
                     throw std::runtime_error("fused step: read-out not available");
             } catch (...) {
                 s->pf_marks = false;

@@ -161,6 +161,7 @@ enum GemmFlags : int {
     kGemmRelu = 8,      // max(x, 0) after bias            (Sortformer sub-sampling / transformer FFN)
     kGemmSwish = 16,    // x * sigmoid(x) after bias       (Conformer feed-forward)
 };
+struct AlignArgs;
 struct GemmArgs {
     // ---- what a kernel needs before its first operand load: one contiguous block at the start of the kernel-argument
     // segment, fetched by ONE s_load burst at kernel entry (WLK_PIN_GEMM_ARGS) instead of a stage per first use -------
@@ -208,6 +209,11 @@ struct GemmArgs {
     const int* mg_beam_of_row = nullptr;
     int mg_heads = 0, mg_T = 0, mg_ring_rows = 0, mg_n_beam = 1, mg_side_blocks = 0;
     PtrTable z;
+    // weight-streaming GEMV of a graph-replayed step (the vocabulary projection): the FIRST `side_blocks` workgroups of the
+    // launch run the AlignAtt z-score (align_body.h) of *side_align - a device-resident AlignArgs whose `rows` name the
+    // step's device block - beside the weight stream: (T + 63) / 64 = side_zf frame blocks per alignment head and beam
+    const AlignArgs* side_align = nullptr;
+    int side_blocks = 0, side_zf = 0;
     bool force_kwave = false;            // diagnostics: take the k-wave kernel (under-filled grids) whatever the shape
     int force_kernel = 0;                // diagnostics / A-B: 0 = by shape, 2 = k-wave, 3 = the 64x64 kernel, 4 = the k-split kernel
     bool gemm_plain_loop = false;        // A/B switch: LDS fragment reads right before use instead of a group ahead
@@ -548,6 +554,7 @@ struct AlignArgs {
     float* attn_last;    // [n_beam][T] head-mean of the median-filtered newest row
     int* frames;         // [n_beam]
     const StepRow* rows = nullptr;   // launch_alignatt_rows
+    float* part = nullptr;           // early z-score form: [n_beam][64] (value, frame) pairs, one per 256-frame block
 };
 void launch_alignatt(const LaunchCtx& ctx, const AlignArgs& a);
 // top-k (with adjustments) and AlignAtt read-out of the same rows in two launches instead of four; returns false when
@@ -555,7 +562,10 @@ void launch_alignatt(const LaunchCtx& ctx, const AlignArgs& a);
 bool launch_select_fused(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, int k, float* top_vals, int* top_ids,
                          void* scratch, const int* adj_row, const int* adj_ids, const float* adj_deltas, int n_adj,
                          const AlignArgs& a, const StepHostOut& host = StepHostOut{}, const float* ns_logits = nullptr,
-                         int ns_token = 0, float* ns_probs = nullptr);
+                         int ns_token = 0, float* ns_probs = nullptr, bool early_z = false);
+// early_z: the z rows were written by the side workgroups of the vocabulary projection's launch (GemmArgs::side_align, the
+// same AlignArgs resident on the device) - the slice pass carries the arg-max, the last launch is the 64-thread fold
+bool select_early_z_enabled();
 bool select_fused_applicable(int n_rows, int k, const AlignArgs& a);
 // batched steps: one read-out per row with the row's own window / counters (a.ring, prefill_rows, n_single, newest_row
 // and content_len are taken from rows[r]; a.n_beam is the number of rows, each row is its own beam 0)

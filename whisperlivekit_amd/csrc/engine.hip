@@ -113,13 +113,15 @@ struct wlk_engine {
     void run();
     void step_single(EngineJob* j, std::vector<EngineJob*>& finished);
     void step_batched(std::vector<EngineJob*>& group, std::vector<EngineJob*>& finished);
-    void enqueue_decoder(int R, bool from_block = false);   // embed .. logits of R rows (captured into a hipGraph per row count)
+    void enqueue_decoder(int R, bool from_block = false, const AlignArgs* side_align = nullptr, int side_blocks = 0,
+                         int side_zf = 0);   // embed .. logits of R rows (captured into a hipGraph per row count)
+    AlignArgs* align_dev = nullptr;   // [9] the fused replay's read-out arguments per row count, resident (early z-score: select.hip)
     bool step_batched_one_replay(std::vector<EngineJob*>& group, std::vector<EngineJob*>& finished);
     void enqueue_select(int R, int n_adj);  // logit adjustments + log-softmax top-2 + AlignAtt read-out per row
 };
 
 // ---- one batched step ----------------------------------------------------------------------------------------
-void wlk_engine::enqueue_decoder(int R, bool from_block) {
+void wlk_engine::enqueue_decoder(int R, bool from_block, const AlignArgs* side_align, int side_blocks, int side_zf) {
     const wlk_dims& D = m->D;
     const int d = D.n_text_state, T = D.n_audio_ctx, H = D.n_text_head, V = D.n_vocab, ctx_len = D.n_text_ctx;
     const LaunchCtx c{stream, nullptr};
@@ -179,6 +181,7 @@ void wlk_engine::enqueue_decoder(int R, bool from_block) {
     GemmArgs lg;
     lg.A = x; lg.lda = d; lg.W = m->w_tok_emb; lg.C = logits; lg.ldc = V; lg.M = R; lg.N = V; lg.K = d;
     lg.ln_gamma = m->w_ln_w; lg.ln_beta = m->w_ln_b;
+    lg.side_align = side_align; lg.side_blocks = side_blocks; lg.side_zf = side_zf;   // fused replay: the rows' z-scores ride here
     launch_gemv(c, lg, "dec_lnf_logits");
 }
 
@@ -216,6 +219,7 @@ bool wlk_engine::step_batched_one_replay(std::vector<EngineJob*>& group, std::ve
     a.single_base = ctx_len;
     a.z = z; a.attn_last = attn_last; a.frames = reinterpret_cast<int*>(res_dev) + 4 * max_rows;
     a.rows = blk_dev->rows;
+    a.part = z + (size_t)max_rows * std::max(m->n_align, 1) * T;
     if (!select_fused_applicable(R, 2, a)) return false;
     EngineBlock& b = *blk_host;
     std::vector<int32_t> ids;
@@ -259,10 +263,19 @@ bool wlk_engine::step_batched_one_replay(std::vector<EngineJob*>& group, std::ve
     if (!exec) {
         const LaunchCtx c{stream, nullptr};
         hipGraph_t graph = nullptr;
+        // the rows' z-scores beside the vocabulary projection, medians beside the top-k slices, one folding wave per row at the
+        // end (select.hip, early_z) - as a single session's graph step does.  Opt-in here (WLK_EARLY_Z_ENGINE=1): with eight
+        // streams on the GPU the step's latency chain is not what bounds the throughput and up to 960 side workgroups compete
+        // with the encode lane - 347.2 against 349.0 audio-s/s in three alternating pairs (profiles/r06m_early_z.txt)
+        const char* ez = getenv("WLK_EARLY_Z_ENGINE");
+        const bool early_z = ez && ez[0] == '1' && select_early_z_enabled() && V >= 16384;
+        const int zf_blocks = (T + 63) / 64;
+        if (early_z) WLK_HIP(hipMemcpyAsync(align_dev + R, &a, sizeof(AlignArgs), hipMemcpyHostToDevice, stream));
         WLK_HIP(hipStreamSynchronize(stream));
         WLK_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         try {
-            enqueue_decoder(R, true);
+            if (early_z) enqueue_decoder(R, true, align_dev + R, zf_blocks * a.n_align * R, zf_blocks);
+            else enqueue_decoder(R, true);
             StepHostOut ho;
             ho.result = res_host_dev;
             ho.n_adj = &blk_dev->n_adj;
@@ -270,7 +283,7 @@ bool wlk_engine::step_batched_one_replay(std::vector<EngineJob*>& group, std::ve
             float* top_vals = res_dev;
             int* top_ids = reinterpret_cast<int*>(res_dev) + 2 * max_rows;
             if (!launch_select_fused(c, logits, V, R, 2, top_vals, top_ids, topk_scratch, blk_dev->adj_row, blk_dev->adj_ids,
-                                     blk_dev->adj_deltas, 0, a, ho))
+                                     blk_dev->adj_deltas, 0, a, ho, nullptr, 0, nullptr, early_z))
                 throw std::runtime_error("batched step: read-out not available");
         } catch (...) {
             (void)hipStreamEndCapture(stream, &graph);
@@ -640,7 +653,8 @@ static wlk_engine* engine_create(wlk_model* m) {
     e->mlp = dev_alloc<float>(R * 4 * d);
     e->logits = dev_alloc<float>(R * V);
     e->xsplit = dev_alloc<float>(cross_split_scratch_floats(8, D.n_text_head, (int)T));
-    e->z = dev_alloc<float>(R * std::max(m->n_align, 1) * T);
+    e->z = dev_alloc<float>(R * std::max(m->n_align, 1) * T + R * 128);   // + the read-out's per-block (value, frame) pairs
+    e->align_dev = reinterpret_cast<AlignArgs*>(dev_alloc<char>(9 * sizeof(AlignArgs)));
     e->attn_last = dev_alloc<float>(R * T);
     e->res_dev = dev_alloc<float>(R * 5);
     WLK_HIP(hipMalloc(&e->topk_scratch, topk_scratch_bytes((int)R)));
@@ -693,6 +707,7 @@ void wlk_engine_destroy_for_model(wlk_model* m) {
     for (float* p : fl)
         if (p) (void)hipFree(p);
     if (e->topk_scratch) (void)hipFree(e->topk_scratch);
+    if (e->align_dev) (void)hipFree(e->align_dev);
     if (e->adj_dev) (void)hipFree(e->adj_dev);
     if (e->pinned) (void)hipHostFree(e->pinned);
     if (e->blk_host) (void)hipHostFree(e->blk_host);

@@ -25,6 +25,7 @@
 
 #include "common.h"
 #include "wave_ops.h"
+#include "align_body.h"
 
 namespace wlk {
 
@@ -1431,6 +1432,16 @@ template <int MR, int RPW>
 __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
     WLK_PIN_GEMM_ARGS(g);
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [MR][K]
+    // side workgroups (GemmArgs::side_align): the z-score of the step's alignment window - it depends on the last
+    // cross-attention, not on the logits - runs on the first workgroups of the launch, beside the weight stream
+    const int side = g.side_blocks;
+    if ((int)blockIdx.x < side) {
+        const AlignArgs a = *g.side_align;
+        const int fblock = (int)blockIdx.x % g.side_zf, rest = (int)blockIdx.x / g.side_zf;
+        align_zscore_body(a, fblock, rest % a.n_align, rest / a.n_align);
+        return;
+    }
+    const int blk = (int)blockIdx.x - side, n_blk = (int)gridDim.x - side;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -1438,7 +1449,7 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
     // the first weight chunk of this wave's first output group does not depend on the activations:
     // issue it BEFORE the x staging round trip so the two memory latencies overlap instead of adding up
     const int n_groups = (g.N + RPW - 1) / RPW;
-    const int grp0 = blockIdx.x * 4 + wave;
+    const int grp0 = blk * 4 + wave;
     float4 wpre[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
@@ -1506,7 +1517,7 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    for (int grp = grp0; grp < n_groups; grp += gridDim.x * 4) {
+    for (int grp = grp0; grp < n_groups; grp += n_blk * 4) {
         const int n_base = grp * RPW;
         float acc[RPW][MR];
 #pragma unroll
@@ -1971,6 +1982,8 @@ void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     // the whole K of a row in flight per wave: up to 2048 for every variant, up to 5120 (the MLP's second projection of
     // the large models, 20 float4 per lane) for the plain one-feature-per-wave variant
     const bool plain1 = rpw == 1 && !g.ln_gamma && !g.mg_pm;
+    if (g.side_blocks > 0 && (!g.side_align || g.side_zf <= 0 || rpw != 4))
+        throw std::invalid_argument("gemv: side workgroups ride only in the vocabulary projection's launch");
     if (g.M == 1 && (g.K <= 2048 || (plain1 && g.K <= 5120)) && rpw <= 2 && gemv1_enabled() && !g.kv_rows) {
         const int ub = (g.K / 4 + 63) / 64;
         blocks += g.mg_pm ? g.mg_side_blocks : 0;
@@ -2047,6 +2060,7 @@ void launch_gemv(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
         WLK_HIP(hipGetLastError());
         return;
     }
+    blocks += g.side_blocks;     // the AlignAtt z-score of a graph step rides in front of the weight stream
 #define WLK_GEMV(MRv, RPWv) \
     hipLaunchKernelGGL((gemv_f32_kernel<MRv, RPWv>), dim3(blocks), dim3(256), lds, ctx.stream, g)
 #define WLK_GEMV_R(MRv)                      \

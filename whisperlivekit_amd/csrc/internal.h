@@ -263,6 +263,7 @@ struct wlk_session {
     wlk::StepBlock *step_host = nullptr, *step_host_dev = nullptr, *step_dev = nullptr;
     wlk::StepResult *result_host = nullptr, *result_host_dev = nullptr;
     hipGraphExec_t fstep_exec[2] = {nullptr, nullptr};
+    wlk::AlignArgs* step_align_dev = nullptr;            // the step's read-out arguments, resident: the vocabulary GEMV's side workgroups read them (early z-score)
     unsigned step_seq = 0;
     uint64_t step_ns = 0, step_launch_ns = 0, step_count = 0;   // wlk_session_step_stats (WLK_STEP_TIMING=1: also printed when the session is destroyed)
 

@@ -13,6 +13,7 @@
 
 #include "common.h"
 #include "wave_ops.h"
+#include "align_body.h"
 
 namespace wlk {
 
@@ -243,7 +244,8 @@ __device__ __forceinline__ void publish_flag(unsigned* flag, unsigned seq) {
 
 __device__ __forceinline__ void topk_stage2_body(const SelPartial* __restrict__ parts, int k,
                                                  float* __restrict__ top_vals, int* __restrict__ top_ids, int row,
-                                                 const StepHostOut host = StepHostOut{}, unsigned seq = 0) {
+                                                 const StepHostOut host = StepHostOut{}, unsigned seq = 0,
+                                                 const bool publish = true) {
     const int lane = threadIdx.x;   // one lane per slice (the first wave of the workgroup)
     const SelPartial p = parts[(long)row * kSelBlocks + lane];
     float mx = wave_max(p.mx);
@@ -272,7 +274,7 @@ __device__ __forceinline__ void topk_stage2_body(const SelPartial* __restrict__ 
             }
         }
     }
-    if (host.result && lane == 0) publish_flag(&host.result[row].flag_topk, seq);
+    if (publish && host.result && lane == 0) publish_flag(&host.result[row].flag_topk, seq);
 }
 
 __global__ __launch_bounds__(64) void topk_stage2_kernel(const SelPartial* __restrict__ parts, int k,
@@ -351,67 +353,6 @@ void launch_token_prob(const LaunchCtx& ctx, const float* logits, int n_vocab, i
 // Step 1 (this kernel): per frame column, mean and population std over the window rows in fp64
 // (torch.std_mean(unbiased=False) accumulates in double on CPU), then the z-score of the newest row.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void align_zscore_body(AlignArgs a, int fblock, int al, int b) {
-    // 64 frame columns x 4 row groups per workgroup: the window rows (up to 448 + 15) are walked by
-    // four threads per column in parallel and folded through LDS - the loop is latency-bound, so
-    // parallel rows matter more than anything else here
-    __shared__ double red[4][64];
-    const int fx = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int f = fblock * 64 + fx;
-    const bool ok = f < a.T;
-    if (a.rows) {                // batched steps: row b is a session of its own (one beam)
-        const StepRow sr = a.rows[b];
-        a.prefill_rows = sr.prefill_rows;
-        a.n_single = sr.n_single;
-        a.newest_row = sr.newest_row;
-    }
-    const gcf_ptr base = to_global(a.rows ? a.rows[b].ring + ((long)al * a.ring_rows) * a.T + (ok ? f : 0)
-                                          : a.ring + ((long)(al * a.n_beam + b) * a.ring_rows) * a.T + (ok ? f : 0));
-    const int n = a.prefill_rows + a.n_single;
-    auto row_of = [&](int i) { return i < a.prefill_rows ? i : a.single_base + (i - a.prefill_rows); };
-    // Round 4: the thread's first kZKeep window rows (windows of up to 4 kZKeep = 96 rows: every step but those of very
-    // long prompts) are requested together and kept for the second pass - one memory round trip instead of
-    // 2 x ceil(rows / 16) dependent ones; the sums run over the same values in the same order.
-    constexpr int kZKeep = 24;
-    float w[kZKeep];
-#pragma unroll
-    for (int t = 0; t < kZKeep; ++t) {
-        const int i = rg + 4 * t;
-        w[t] = base[(long)row_of(i < n ? i : 0) * a.T];
-    }
-    const float newest = base[(long)a.newest_row * a.T];
-    __builtin_amdgcn_sched_barrier(0);   // all of them in flight before the first is folded (hipcc interleaves otherwise)
-    double sum = 0.0;
-#pragma unroll
-    for (int t = 0; t < kZKeep; ++t)
-        if (rg + 4 * t < n) sum += (double)w[t];
-#pragma unroll 4
-    for (int i = rg + 4 * kZKeep; i < n; i += 4) sum += (double)base[(long)row_of(i) * a.T];
-    red[rg][fx] = sum;
-    __syncthreads();
-    const double mean = (red[0][fx] + red[1][fx] + red[2][fx] + red[3][fx]) / n;
-    __syncthreads();
-    double sq = 0.0;
-#pragma unroll
-    for (int t = 0; t < kZKeep; ++t) {
-        if (rg + 4 * t < n) {
-            const double d = (double)w[t] - mean;
-            sq += d * d;
-        }
-    }
-#pragma unroll 4
-    for (int i = rg + 4 * kZKeep; i < n; i += 4) {
-        const double t = (double)base[(long)row_of(i) * a.T] - mean;
-        sq += t * t;
-    }
-    red[rg][fx] = sq;
-    __syncthreads();
-    if (rg == 0 && ok) {
-        const float stdv = (float)sqrt((red[0][fx] + red[1][fx] + red[2][fx] + red[3][fx]) / n);
-        a.z[((long)b * a.n_align + al) * a.T + f] = (newest - (float)mean) / (stdv + 1e-8f);
-    }
-}
-
 __global__ __launch_bounds__(256) void align_zscore_kernel(AlignArgs a) {
     align_zscore_body(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
@@ -574,6 +515,101 @@ __global__ __launch_bounds__(1024) void select_stage2_kernel(TopkArgs t, AlignAr
     }
 }
 
+// Graph-replayed single-session steps (round 6, `early_z`).  The z-score has already run beside the vocabulary projection
+// (gemv_f32_kernel's side workgroups).  What the trace of the first form of this showed: the medians are VALU work - 1 500
+// frames x 5 heads x 21 compare-exchanges - and ONE workgroup (one compute unit) needs 9-11 us for them however it is
+// scheduled.  So the medians / head mean run as (T + 255) / 256 workgroups of the top-k SLICE pass's launch, one frame per
+// thread, each leaving the (value, lowest frame) arg-max of its 256 frames; the step's last launch is one wave that folds the
+// 64 slices of the top-k and the frame blocks of the read-out, stores both into the host's result block and raises both
+// flags behind one system-scope fence.  Same per-frame expressions as align_argmax_lds_body, and an arg-max with ties to the
+// lowest frame does not depend on how it is grouped: the step's numbers are those of the two launches above.
+constexpr int kAlignPartFrames = 256;
+__device__ __forceinline__ void align_median_part_body(AlignArgs a, int b, int blk, int n_blk) {
+    __shared__ float bestv[4];
+    __shared__ int besti[4];
+    const int tid = threadIdx.x;
+    if (a.rows) a.content_len = a.rows[b].content_len;
+    const float* zb = a.z + (long)b * a.n_align * a.T;
+    const int f = blk * kAlignPartFrames + tid;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    if (f < a.T) {
+        float acc = 0.f;
+        for (int al = 0; al < a.n_align; ++al) {
+            const float* z = zb + (long)al * a.T;
+            float v[7];
+#pragma unroll
+            for (int o = -3; o <= 3; ++o) {
+                int idx = f + o;
+                if (idx < 0) idx = -idx;
+                if (idx >= a.T) idx = 2 * (a.T - 1) - idx;
+                v[o + 3] = z[idx];
+            }
+            acc += a.T > 3 ? median7(v[0], v[1], v[2], v[3], v[4], v[5], v[6]) : z[f];
+        }
+        const float m = acc / (float)a.n_align;
+        a.attn_last[(long)b * a.T + f] = m;
+        if (f < a.content_len && (m > bv || (m == bv && f < bi))) { bv = m; bi = f; }
+    }
+    wave_argmax(bv, bi);
+    if ((tid & 63) == 0) { bestv[tid >> 6] = bv; besti[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (bestv[w] > bestv[0] || (bestv[w] == bestv[0] && besti[w] < besti[0])) { bestv[0] = bestv[w]; besti[0] = besti[w]; }
+        float* slot = a.part + ((long)b * 64 + blk) * 2;
+        slot[0] = bestv[0];
+        slot[1] = __int_as_float(besti[0]);
+    }
+}
+
+__global__ __launch_bounds__(256) void select_stage1_early_kernel(TopkArgs t, AlignArgs a, int n_blk) {
+    WLK_PIN_SELECT_ARGS(t, a);
+    const int n_topk = kSelBlocks * t.n_rows;
+    if ((int)blockIdx.x < n_topk) {
+        const int n_adj = t.host.n_adj ? *t.host.n_adj : t.n_adj;
+        topk_stage1_body(t.logits, t.n_vocab, t.k, t.parts, t.adj_row, t.adj_ids, t.adj_deltas, n_adj,
+                         blockIdx.x % kSelBlocks, blockIdx.x / kSelBlocks);
+    } else {
+        const int i = blockIdx.x - n_topk;
+        align_median_part_body(a, i / n_blk, i % n_blk, n_blk);
+    }
+}
+
+// one wave per row: lane = top-k slice, and lane = frame block of the read-out (n_blk <= 64)
+__global__ __launch_bounds__(64) void select_stage2_early_kernel(TopkArgs t, AlignArgs a, int n_blk) {
+    asm volatile("" ::"s"(t.parts), "s"(t.k), "s"(t.top_vals), "s"(t.top_ids), "s"(t.host.result), "s"(t.host.seq), "s"(a.part),
+                 "s"(a.frames));
+    __builtin_amdgcn_sched_barrier(0);
+    const int row = blockIdx.x, lane = threadIdx.x;
+    unsigned seq = 0;
+    if (t.host.result) seq = *t.host.seq;
+    const float* slot = a.part + ((long)row * 64 + (lane < n_blk ? lane : 0)) * 2;
+    float bv = slot[0];
+    int bi = __float_as_int(slot[1]);
+    if (lane >= n_blk) { bv = -INFINITY; bi = 0x7fffffff; }
+    topk_stage2_body(t.parts, t.k, t.top_vals, t.top_ids, row, t.host, seq, false);
+    // a block whose frames all lie behind content_len (or are NaN) left (-inf, 0x7fffffff): it loses every comparison, as
+    // its threads' candidates do in the one-workgroup form
+    wave_argmax(bv, bi);
+    if (lane == 0) {
+        const int frame = bi == 0x7fffffff ? 0 : bi;
+        a.frames[row] = frame;
+        if (t.host.result) {
+            t.host.result[row].frame = frame;
+            __threadfence_system();
+            __hip_atomic_store(&t.host.result[row].flag_topk, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&t.host.result[row].flag_align, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+bool select_early_z_enabled() {
+    // read per call (a session asks once, when it captures its step graph): tests flip WLK_EARLY_Z inside one process
+    const char* e = getenv("WLK_EARLY_Z");
+    return !(e && e[0] == '0');
+}
+
 bool select_fused_applicable(int n_rows, int k, const AlignArgs& a) {
     static const bool enabled = [] {
         const char* e = getenv("WLK_SELECT_FUSED");
@@ -585,7 +621,8 @@ bool select_fused_applicable(int n_rows, int k, const AlignArgs& a) {
 
 bool launch_select_fused(const LaunchCtx& ctx, float* logits, int n_vocab, int n_rows, int k, float* top_vals, int* top_ids,
                          void* scratch, const int* adj_row, const int* adj_ids, const float* adj_deltas, int n_adj,
-                         const AlignArgs& a, const StepHostOut& host, const float* ns_logits, int ns_token, float* ns_probs) {
+                         const AlignArgs& a, const StepHostOut& host, const float* ns_logits, int ns_token, float* ns_probs,
+                         bool early_z) {
     const size_t lds = (size_t)a.n_align * a.T * sizeof(float);
     if (!select_fused_applicable(n_rows, k, a)) return false;
     static std::atomic<bool> attr_set[64];
@@ -599,6 +636,21 @@ bool launch_select_fused(const LaunchCtx& ctx, float* logits, int n_vocab, int n
     TopkArgs t{logits, n_vocab, k, n_rows, static_cast<SelPartial*>(scratch), adj_row, adj_ids, adj_deltas, n_adj, top_vals, top_ids,
                host, ns_logits, ns_token, ns_probs};
     const int zf = (a.T + 63) / 64;
+    if (early_z) {
+        const int n_blk = (a.T + kAlignPartFrames - 1) / kAlignPartFrames;
+        if (ns_logits || !a.part || n_blk > 64) throw std::invalid_argument("select: the early z-score form needs a.part, T <= 16384 and no no-speech block");
+        {
+            KernelScope ks(ctx, "sel_stage1", 0.0, 4.0 * 3.0 * n_rows * (double)n_vocab);
+            hipLaunchKernelGGL(select_stage1_early_kernel, dim3(kSelBlocks * n_rows + n_blk * a.n_beam), dim3(256), 0, ctx.stream, t, a, n_blk);
+            WLK_HIP(hipGetLastError());
+        }
+        {
+            KernelScope ks(ctx, "sel_stage2");
+            hipLaunchKernelGGL(select_stage2_early_kernel, dim3(n_rows), dim3(64), 0, ctx.stream, t, a, n_blk);
+            WLK_HIP(hipGetLastError());
+        }
+        return true;
+    }
     {
         KernelScope ks(ctx, "sel_stage1", 0.0, 4.0 * 3.0 * n_rows * (double)n_vocab);
         hipLaunchKernelGGL(select_stage1_kernel, dim3(kSelBlocks * n_rows + zf * a.n_align * a.n_beam), dim3(256), 0,
