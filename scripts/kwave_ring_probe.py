@@ -1,4 +1,4 @@
-"""k-wave GEMM tiles (16 x 16: force 6, 32 x 32: force 7) at the row counts of the decoder prefill (~60-80 prompt rows) and of one
+"""k-wave GEMM tiles (16 x 16: force 6, 32 x 32: force 7, 32 x 32 with one LDS slab buffer: force 8) at the row counts of the decoder prefill (~60-80 prompt rows) and of one
 Sortformer session (<= 401 frames): microseconds per launch, back to back.  Run once per library (WLK_HIP_LIB) to compare builds."""
 import ctypes as C
 import sys
@@ -20,5 +20,5 @@ def t(m, n, k, flags, force, reps=40):
 for name, n, k, flags in SHAPES:
     row = []
     for m in (61, 82, 200, 291, 401):
-        row.append(f"M {m}: {t(m, n, k, flags, 7):5.1f} / {t(m, n, k, flags, 6):5.1f}")
-    print(f"{name:10s} N {n:4d} K {k:4d} (32x32 / 16x16 us): " + " | ".join(row), flush=True)
+        row.append(f"M {m}: {t(m, n, k, flags, 7):5.1f} / {t(m, n, k, flags, 8):5.1f} / {t(m, n, k, flags, 6):5.1f}")
+    print(f"{name:10s} N {n:4d} K {k:4d} (32x32 / 32x32 one LDS buffer / 16x16 us): " + " | ".join(row), flush=True)

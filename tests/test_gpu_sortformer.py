@@ -134,7 +134,7 @@ def test_kp_family_rows_do_not_depend_on_what_is_stacked_under_them(N, K, flags)
         assert np.array_equal(run(rows).view(np.uint32), big[:rows].view(np.uint32)), (rows, N, K)
     if K % 128 == 0:          # below 512 rows the family has two tile shapes (16 x 16: force 6, 32 x 32: force 7): same bits
         for rows in (291, 37):
-            for force in (6, 7):
+            for force in (6, 7, 8):      # 8: the 32 x 32 tiles with one LDS slab buffer (four workgroups per CU)
                 assert np.array_equal(run(rows, force).view(np.uint32), big[:rows].view(np.uint32)), (rows, N, K, force)
 
 

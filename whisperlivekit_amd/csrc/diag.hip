@@ -98,9 +98,9 @@ int wlk_diag_linear(const float* a, int64_t lda, int64_t a_floats, const float* 
         g.scale_cols = scale_cols;
         LaunchCtx ctx;
         g.force_kwave = force_gemv == 2;
-        g.force_kernel = (force_gemv >= 2 && force_gemv <= 4) || force_gemv == 6 || force_gemv == 7 ? force_gemv : 0;
+        g.force_kernel = (force_gemv >= 2 && force_gemv <= 4) || (force_gemv >= 6 && force_gemv <= 8) ? force_gemv : 0;
         if (force_gemv == 1) launch_gemv(ctx, g, "diag_gemv");
-        else if (force_gemv >= 5 && force_gemv <= 7) launch_gemm_kp(ctx, g, "diag_gemm_kp");      // 6 / 7: 16 x 16 / 32 x 32 tiles below 512 rows
+        else if (force_gemv >= 5 && force_gemv <= 8) launch_gemm_kp(ctx, g, "diag_gemm_kp");      // 6 / 7: 16 x 16 / 32 x 32 tiles below 512 rows
         else launch_gemm(ctx, g, "diag_gemm");
         WLK_HIP(hipDeviceSynchronize());
         WLK_HIP(hipMemcpy(c, Cc.p, (size_t)m * n * sizeof(float), hipMemcpyDeviceToHost));
@@ -123,7 +123,7 @@ int wlk_diag_linear_time(int m, int n, int k, int flags, int force, int reps, fl
         g.A = A.p; g.lda = k; g.W = W.p; g.bias = B.p; g.C = Cc.p; g.ldc = n; g.R = (flags & kGemmResidual) ? R.p : nullptr;
         g.ldr = n; g.M = m; g.N = n; g.K = k; g.flags = flags; g.scale = 0.5f; g.scale_cols = n / 2;
         g.force_kwave = force == 2;
-        g.force_kernel = (force >= 2 && force <= 4) || force == 6 || force == 7 || force >= 500 ? force : 0;      // >= 500: kp family with the tile (force - 500) / 10 x % 10
+        g.force_kernel = (force >= 2 && force <= 4) || (force >= 6 && force <= 8) || force >= 500 ? force : 0;      // >= 500: kp family with the tile (force - 500) / 10 x % 10
         long long* dbg = nullptr;
         const bool want_clock = getenv("WLK_GEMM_CLOCKS") != nullptr;
         if (want_clock) {
@@ -136,7 +136,7 @@ int wlk_diag_linear_time(int m, int n, int k, int flags, int force, int reps, fl
         LaunchCtx ctx{st, nullptr};
         auto go = [&]() {
             if (force == 1) launch_gemv(ctx, g, "diag");
-            else if ((force >= 5 && force <= 7) || force >= 500) launch_gemm_kp(ctx, g, "diag");
+            else if ((force >= 5 && force <= 8) || force >= 500) launch_gemm_kp(ctx, g, "diag");
             else launch_gemm(ctx, g, "diag");
         };
         go();

@@ -241,12 +241,15 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32)) void gemm_nt_f32_kernel
 // wave-order fold, same epilogue expression.  Every output element is then bit for bit what gemm_nt_f32_kpipe_kernel
 // computes for it with ANY tile: a row keeps its arithmetic when other rows are stacked under it and the launch moves
 // from 32 x 32 tiles to one-tile-per-CU tiles (launch_gemm_kp; the Sortformer's stacked sessions).  K % 128 == 0.
-template <bool KP>
+// NBUF = 1 (round 6 probe): ONE slab buffer in LDS instead of two - 36.9 KB per workgroup, four workgroups per compute unit
+// instead of two (a 291 x 2048 projection's 640 tiles are then resident at once instead of in two rounds), at the price of a
+// second barrier per slab.  Same operands into the same MFMAs in the same order.
+template <bool KP, int NBUF = 2>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kwave_kernel(GemmArgs g) {
     WLK_PIN_GEMM_ARGS(g);
     constexpr int KW = 4, SLAB = BK * KW, SUB = 32 * LDS_LD;
-    __shared__ __attribute__((aligned(16))) float As[2][KW * SUB];
-    __shared__ __attribute__((aligned(16))) float Ws[2][KW * SUB];
+    __shared__ __attribute__((aligned(16))) float As[NBUF][KW * SUB];
+    __shared__ __attribute__((aligned(16))) float Ws[NBUF][KW * SUB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = (g.N + 31) / 32;
     const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
@@ -316,11 +319,13 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kwave_kernel(GemmArgs g) {
         fetch(s0, ks + 2);
         __builtin_amdgcn_sched_barrier(0);
         mma(0);
-        stash(s1, 1);
+        if constexpr (NBUF == 1) __syncthreads();
+        stash(s1, NBUF - 1);
         __syncthreads();
         fetch(s1, ks + 3);
         __builtin_amdgcn_sched_barrier(0);
-        mma(1);
+        mma(NBUF - 1);
+        if constexpr (NBUF == 1) __syncthreads();
         stash(s0, 0);
         __syncthreads();
     }
@@ -1367,7 +1372,7 @@ static KSplitTile kp_tile(int M, int N, int K) {
 // force_kernel 6 / 7 (diagnostics): 16 x 16 / 32 x 32 whatever the shape.  WLK_KP16=0 / 1 overrides the rule.
 static bool kp_takes_16(int M, int N, int K, int force) {
     if (force == 6) return true;
-    if (force == 7) return false;
+    if (force == 7 || force == 8) return false;
     static const int env = [] { const char* e = getenv("WLK_KP16"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     if (env >= 0) return env == 1;
     const long tiles16 = (long)((N + 15) / 16) * ((M + 15) / 16);
@@ -1416,7 +1421,13 @@ void launch_gemm_kp(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
         hipLaunchKernelGGL((gemm_nt_f32_kwave16_kernel<0, true>), dim3((unsigned)tiles16), dim3(256), 0, ctx.stream, g);
     } else {
         const long tiles32 = (long)((g.N + 31) / 32) * ((g.M + 31) / 32);
-        hipLaunchKernelGGL(gemm_nt_f32_kwave_kernel<true>, dim3((unsigned)tiles32), dim3(256), 0, ctx.stream, g);
+        // more than two tiles per compute unit: the one-buffer form (36.9 KB of LDS, three to four workgroups per CU) keeps them all
+        // resident where the two-buffer form runs a second round - 291 x 2048 x 512: 19.0 -> 15.2 us, 401 rows 22.2 -> 19.2, q|k|v at
+        // 401 rows 16.8 -> 14.0; below that the extra barrier per slab costs 0-3 % (profiles/r06q_kwave_nbuf1_probe.txt).  Same bits.
+        // force_kernel 7 / 8 (diagnostics): two buffers / one buffer whatever the grid.
+        const bool one_buf = g.force_kernel == 8 || (g.force_kernel != 7 && tiles32 > 512);
+        if (one_buf) hipLaunchKernelGGL((gemm_nt_f32_kwave_kernel<true, 1>), dim3((unsigned)tiles32), dim3(256), 0, ctx.stream, g);
+        else hipLaunchKernelGGL(gemm_nt_f32_kwave_kernel<true>, dim3((unsigned)tiles32), dim3(256), 0, ctx.stream, g);
     }
     WLK_HIP(hipGetLastError());
 }
