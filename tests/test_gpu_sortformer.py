@@ -102,7 +102,7 @@ def _vp(a):
 def test_kp_family_rows_do_not_depend_on_what_is_stacked_under_them(N, K, flags):
     """Round 6: every projection of the Sortformer goes through launch_gemm_kp - 32 x 32 k-wave tiles below 512 rows,
     one-tile-per-CU k-pipe tiles from there on, ONE per-element arithmetic (wave w sums k = 32 t + 8 w .. + 7 of every slab,
-    partials folded in wave order; K = 192: one wave walks K in order) - so the rows of one session come out bit for bit the
+    partials folded in wave order; K = 192 the same with a half-empty last slab, on k-wave tiles at every row count) - so the rows of one session come out bit for bit the
     same alone (M = 291, 401, 37) and stacked with other sessions' rows (M = 2 392: a k-pipe tile).  Also against float64."""
     lib = _lib.load()
     rng = np.random.default_rng(N + K)
@@ -134,7 +134,7 @@ def test_kp_family_rows_do_not_depend_on_what_is_stacked_under_them(N, K, flags)
         assert np.array_equal(run(rows).view(np.uint32), big[:rows].view(np.uint32)), (rows, N, K)
     if K % 128 == 0:          # below 512 rows the family has two tile shapes (16 x 16: force 6, 32 x 32: force 7): same bits
         for rows in (291, 37):
-            for force in (6, 7, 8):      # 8: the 32 x 32 tiles with one LDS slab buffer (four workgroups per CU)
+            for force in (6, 7, 8):      # 8: the 32 x 32 tiles with one LDS slab buffer (three to four workgroups per CU)
                 assert np.array_equal(run(rows, force).view(np.uint32), big[:rows].view(np.uint32)), (rows, N, K, force)
 
 

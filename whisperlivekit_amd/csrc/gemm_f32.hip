@@ -1333,8 +1333,10 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
 // through here, and a session's activities are bit for bit those of its step alone (tests/test_gpu_sortformer.py).
 //   K % 128 == 0, K >= 256:  M >= 512 -> gemm_nt_f32_kpipe_kernel with the tile ksplit_tile picks (any N, any K of that form);
 //                            else     -> gemm_nt_f32_kwave_kernel<true>;
-//   other K (the Transformer half's K = 192): the plain tiled kernel - one wave per 32 x 32 tile walks K in order, the
-//                            same for its 64 x 64 and 32 x 64 workgroup shapes.
+//   K = 128 .. 255, K % 32 == 0 (the Transformer half's K = 192): k-wave tiles at EVERY row count (16 x 16 / 32 x 32 below 512
+//                            rows, 32 x 32 from there on) - the second slab is half zeros, the arithmetic the family's;
+//   other K:                 the plain tiled kernel - one wave per 32 x 32 tile walks K in order, the same for its 64 x 64 and
+//                            32 x 64 workgroup shapes.
 // the k-pipe tile of a kp-family launch (any tile gives the same bits; this is speed only)
 // Measured on MI355X for the Sortformer's shapes at the row counts stacked steps produce (scripts/kp_tile_probe.py,
 // profiles/r06_kp_tile_probe.txt): ksplit_tile's "rounds of 256 workgroups" model is right for M = 1500 and up to 25 % off
@@ -1403,7 +1405,13 @@ void launch_gemm_kp(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
         WLK_HIP(hipGetLastError());
         return;
     }
-    if (g.K % 128 != 0 || g.K < 256) {
+    // K = 192 (the Sortformer's Transformer width; any multiple of 32 from 128 to 255): the k-wave tiles too, at EVERY row count -
+    // the last 128-deep slab is half zeros, a row's arithmetic (wave w: k = 32 t + 8 w .. + 7, partials folded in wave order) does
+    // not depend on M.  Until round 6 these shapes took the 64 x 64 family, where ONE wave walks K (7.9 us per launch for 64 MFLOP);
+    // WLK_KP_SHORT_K=0 keeps that.
+    static const bool short_k = [] { const char* e = getenv("WLK_KP_SHORT_K"); return !(e && e[0] == '0'); }();
+    const bool short_k_kwave = short_k && g.K % 32 == 0 && g.K >= 128 && g.K < 256;
+    if (!short_k_kwave && (g.K % 128 != 0 || g.K < 256)) {
         GemmArgs p = g;
         p.force_kernel = 3;
         launch_gemm(ctx, p, tag);
@@ -1412,11 +1420,11 @@ void launch_gemm_kp(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
     if ((((long)g.M - 1) * g.lda + g.K) * 4 >= (1L << 31) || (long)g.N * g.K * 4 >= (1L << 31))
         throw std::invalid_argument("gemm: operand larger than 2 GiB");
     KernelScope ks(ctx, tag, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
-    if (gemm_kp_takes_kpipe(g.M, g.N, g.K)) {
+    if (!short_k_kwave && gemm_kp_takes_kpipe(g.M, g.N, g.K)) {
         KSplitTile kt = kp_tile(g.M, g.N, g.K);
         if (g.force_kernel >= 500) kt = KSplitTile{(g.force_kernel - 500) / 10, (g.force_kernel - 500) % 10, 104};   // tile probe
         if (!dispatch_kpipe(ctx, g, kt.tm, kt.tn, kt.ks)) throw std::logic_error("gemm: k-pipe tile without an instantiation");
-    } else if (kp_takes_16(g.M, g.N, g.K, g.force_kernel)) {
+    } else if ((!short_k_kwave || g.M < 512) && kp_takes_16(g.M, g.N, g.K, g.force_kernel)) {
         const long tiles16 = (long)((g.N + 15) / 16) * ((g.M + 15) / 16);
         hipLaunchKernelGGL((gemm_nt_f32_kwave16_kernel<0, true>), dim3((unsigned)tiles16), dim3(256), 0, ctx.stream, g);
     } else {
