@@ -185,6 +185,10 @@ struct GemmArgs {
     // GEMV path only (decode steps): fused pre-LayerNorm of the A rows (eps 1e-5) ...
     const float* ln_gamma = nullptr;
     const float* ln_beta = nullptr;
+    // 16 x 16 k-wave kernel with the LayerNorm inside (round 6): the column-tile-0 workgroups also store the normalised rows
+    // here ([M][ld_ln_out]) - for networks that use LN(x) twice (the Sortformer's post-LN Transformer: projection input AND residual)
+    float* ln_out = nullptr;
+    long ld_ln_out = 0;
     // ... and fused KV-cache append: output columns [kv_d, 2kv_d) / [2kv_d, 3kv_d) of row m are ALSO
     // written to kcache/vcache[(m*kv_ctx + *kv_pos) * kv_d + col] (one fed token per row)
     float* kcache = nullptr;

@@ -452,7 +452,9 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kwave16_kernel(GemmArgs g) {
         }
     };
     [[maybe_unused]] float ln_mean[2] = {0.f, 0.f}, ln_rstd[2] = {1.f, 1.f};
-    auto stash = [&](const Slab& st, int buf) {
+    // LN: the workgroups of column tile 0 also keep the normalised rows (GemmArgs::ln_out) - `ks` is the slab being stashed
+    [[maybe_unused]] const bool keep_ln = LN && g.ln_out != nullptr && tile_n == 0;
+    auto stash = [&](const Slab& st, int buf, [[maybe_unused]] int ks = 0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             float4 a4 = st.a[i];
@@ -461,6 +463,8 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kwave16_kernel(GemmArgs g) {
                 a4.y = (a4.y - ln_mean[i]) * ln_rstd[i] * st.ga.y + st.be.y;
                 a4.z = (a4.z - ln_mean[i]) * ln_rstd[i] * st.ga.z + st.be.z;
                 a4.w = (a4.w - ln_mean[i]) * ln_rstd[i] * st.ga.w + st.be.w;
+                const int row = m0 + (tid >> 5) + 8 * i, kk = ks * SLAB + kcol;
+                if (keep_ln && row < g.M && kk < g.K) *reinterpret_cast<float4*>(g.ln_out + (long)row * g.ld_ln_out + kk) = a4;
             }
             *reinterpret_cast<float4*>(&As[buf][lds_at[i]]) = a4;
         }
@@ -541,18 +545,18 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kwave16_kernel(GemmArgs g) {
             ln_rstd[i] = ln_stat[2 * row + 1];
         }
     }
-    stash(s0, 0);
+    stash(s0, 0, 0);
     __syncthreads();
     for (int ks = 0; ks < ns2; ks += 2) {
         fetch(s0, ks + 2);
         __builtin_amdgcn_sched_barrier(0);
         mma(0);
-        stash(s1, 1);
+        stash(s1, 1, ks + 1);
         __syncthreads();
         fetch(s1, ks + 3);
         __builtin_amdgcn_sched_barrier(0);
         mma(1);
-        stash(s0, 0);
+        stash(s0, 0, ks + 2);
         __syncthreads();
     }
     // fold the four k-partials in wave order
@@ -1386,8 +1390,18 @@ static bool kp_takes_16(int M, int N, int K, int force) {
 // replace - the third time this trade was measured, after the encoder's large tiles in round 1 and the prefill in round 4).
 bool gemm_kp_fuses_layernorm(int M, int N, int K) {
     static const bool on = [] { const char* e = getenv("WLK_SF_LN_FUSE"); return e && e[0] == '1'; }();
+    // K = 192 (the Transformer half, round 6; opt-in WLK_SF_TF_LN_FUSE=1): sixteen rows of 192 are only 12 KB per workgroup and the
+    // column-tile-0 workgroups keep the normalised rows for the block's residual (GemmArgs::ln_out) - 35 launches less per chunk,
+    // bit-identical, and STILL a loss: 3.61 against 3.57 ms per chunk (profiles/r06t_tf_ln_fuse.txt).  A LayerNorm launch's 4.4 us
+    // are its own chain (row load -> two dependent reductions -> store), which moves into every consumer workgroup's critical
+    // path when folded; the kernel boundary it saves is the smaller part.  Needs the k-wave tiles for K = 192 (WLK_KP_SHORT_K).
+    static const bool on192 = [] {
+        const char* e = getenv("WLK_SF_TF_LN_FUSE");
+        const char* k = getenv("WLK_KP_SHORT_K");
+        return e && e[0] == '1' && !(k && k[0] == '0');
+    }();
     (void)N;
-    return on && K == 512 && M > 0 && M < 512;
+    return M > 0 && M < 512 && ((on && K == 512) || (on192 && K == 192));
 }
 bool gemm_kp_takes_kpipe(int M, int N, int K) { return K % 128 == 0 && K >= 256 && M >= 512 && ksplit_tile(M, N, K, true).tm != 0; }
 void launch_gemm_kp(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
@@ -1401,7 +1415,8 @@ void launch_gemm_kp(const LaunchCtx& ctx, const GemmArgs& g, const char* tag) {
         if (!gemm_kp_fuses_layernorm(g.M, g.N, g.K)) throw std::invalid_argument("gemm (kp family): this shape does not take the LayerNorm");
         KernelScope ks(ctx, tag, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
         const long tiles16 = (long)((g.N + 15) / 16) * ((g.M + 15) / 16);
-        hipLaunchKernelGGL((gemm_nt_f32_kwave16_kernel<8, true>), dim3((unsigned)tiles16), dim3(256), 0, ctx.stream, g);
+        if (g.K == 192) hipLaunchKernelGGL((gemm_nt_f32_kwave16_kernel<3, true>), dim3((unsigned)tiles16), dim3(256), 0, ctx.stream, g);
+        else hipLaunchKernelGGL((gemm_nt_f32_kwave16_kernel<8, true>), dim3((unsigned)tiles16), dim3(256), 0, ctx.stream, g);
         WLK_HIP(hipGetLastError());
         return;
     }
