@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "wave_ops.h"
 
 namespace wlk {
 
@@ -274,33 +275,57 @@ __global__ __launch_bounds__(256) void sf_attention_mfma_kernel(SfAttnArgs a) {
     const float* qbase = a.q + (long)base * a.ldq + h * dh;
     const float* kbase = a.k + (long)base * a.ldk + h * dh;
     const float* vbase = a.v + (long)base * a.ldv + h * dh;
-    for (int e = threadIdx.x; e < 16 * DHP; e += 256) {
-        const int r = e / DHP, d = e - r * DHP;
-        float q = 0.f, u = 0.f, v = 0.f;
-        if (d < dh) {
-            q = qbase[(long)min(i0 + r, T - 1) * a.ldq + d];
-            if (a.bias_u) u = a.bias_u[h * dh + d];
-            if (a.bias_v) v = a.bias_v[h * dh + d];
+    // Round 6, second form.  The first form's ISA: every load sat in its own exec-mask branch (`dlive[c] ? load : 0`, `if
+    // (a.bias_u)`), hipcc joins such branches with s_waitcnt vmcnt(0), and each tile loop ran load -> wait -> 16 dependent MFMAs
+    // with nothing in flight: fifteen exposed round trips per wave at 291 frames, ~15 of the launch's 20 us.  Now every load of
+    // the kernel is unconditional (addresses clamped into the row / the head; what a dead chunk loads is multiplied by the query
+    // fragments' zeros there, dead value rows are never stored), and each operand stream runs kSfRing tiles ahead in a rotating
+    // register ring whose refills the compiler can count.  Same fragments into the same MFMAs in the same order: bit-identical.
+    constexpr int kSfRing = 3;
+    static_assert((16 * DHP) % 256 == 0, "whole passes of the staging loop");
+    {
+        constexpr int NQ = 16 * DHP / 256;
+        const float* up = a.bias_u ? a.bias_u + h * dh : qbase;     // an absent bias reads the queries (always readable), then counts as 0
+        const float* vp = a.bias_v ? a.bias_v + h * dh : qbase;
+        float q[NQ], u[NQ], v[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int e = threadIdx.x + 256 * i, r = e / DHP, d = min(e - r * DHP, dh - 1);
+            q[i] = qbase[(long)min(i0 + r, T - 1) * a.ldq + d];
+            u[i] = up[d];
+            v[i] = vp[d];
         }
-        qu[r * QLD + d] = q + u;
-        qv[r * QLD + d] = q + v;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) { pin_loaded(q[i]); pin_loaded(u[i]); pin_loaded(v[i]); }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int e = threadIdx.x + 256 * i, r = e / DHP, d = e - r * DHP;
+            const bool live = d < dh;
+            const float qq = live ? q[i] : 0.f, uu = live && a.bias_u ? u[i] : 0.f, vv = live && a.bias_v ? v[i] : 0.f;
+            qu[r * QLD + d] = qq + uu;
+            qv[r * QLD + d] = qq + vv;
+        }
     }
-    __syncthreads();
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    // B fragments of this lane's query: d = 16 c + 4 g + {0..3}
-    float4 bu[C], bv[C];
+    // chunk c of a lane's fragment row lies inside the head iff 16 c + 4 g < dh; a dead chunk re-reads chunk 0 (valid memory)
+    const int coff[4] = {0, 16 + 4 * g < dh ? 16 : 0, 32 + 4 * g < dh ? 32 : 0, 48 + 4 * g < dh ? 48 : 0};
+    const int g4 = 4 * g < dh ? 4 * g : 0;
+    auto load_rows = [&](const float* rows, long ld, int row, int hi, float4 (&x)[C]) {       // row index clamped into [0, hi]
+        const float* p = rows + (long)min(max(row, 0), hi) * ld + g4;
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        bu[c] = *reinterpret_cast<const float4*>(qu + n * QLD + 16 * c + 4 * g);
-        bv[c] = *reinterpret_cast<const float4*>(qv + n * QLD + 16 * c + 4 * g);
-    }
-    const bool dlive[4] = {4 * g < dh, 16 + 4 * g < dh, 32 + 4 * g < dh, 48 + 4 * g < dh};   // whole float4 inside the head
-    // one 16-row tile of `rows` (row index clamped into [0, hi]) times the query fragments -> acc
-    auto tile_dot = [&](const float* rows, long ld, int row, int hi, const float4 (&b)[C]) {
-        const float* p = rows + (long)min(max(row, 0), hi) * ld + 4 * g;
-        float4 x[C];
+        for (int c = 0; c < C; ++c) x[c] = *reinterpret_cast<const float4*>(p + coff[c]);
+    };
+    const int vcol[4] = {min(n, dh - 1), min(16 + n, dh - 1), min(32 + n, dh - 1), min(48 + n, dh - 1)};
+    auto load_v = [&](int kt, float (&vv)[4][C]) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) x[c] = dlive[c] ? *reinterpret_cast<const float4*>(p + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = 0; e < 4; ++e) {
+            const float* vr = vbase + (long)min(kt * 16 + 4 * g + e, T - 1) * a.ldv;
+#pragma unroll
+            for (int c = 0; c < C; ++c) vv[e][c] = vr[vcol[c]];
+        }
+    };
+    // one 16-row tile of fragments times the query fragments (the MFMA order of the first form: c, then x y z w)
+    auto dot_rows = [&](const float4 (&x)[C], const float4 (&b)[C]) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -311,18 +336,47 @@ __global__ __launch_bounds__(256) void sf_attention_mfma_kernel(SfAttnArgs a) {
         }
         return acc;
     };
-    if (a.pos) {
-        const int rbase = a.pos_row0 - i0 - 15;
-        const float* pbase = a.pos + h * dh;
-        for (int rt = wave; rt < n_rt; rt += 4) {
-            // A row m = lane & 15 of the tile; rows past the table are clamped (their products are never read)
-            const f32x4 acc = tile_dot(pbase, a.ldp, rbase + rt * 16 + n, 2 * a.pos_row0, bv);
-            *reinterpret_cast<float4*>(G + n * GP + rt * 16 + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    const int my_kt = wave < n_kt ? (n_kt - wave + 3) / 4 : 0;          // this wave's key tiles kt = wave + 4 i
+    const int my_rt = a.pos && wave < n_rt ? (n_rt - wave + 3) / 4 : 0;  // ... and relative-position tiles
+    const int rbase = a.pos_row0 - i0 - 15;
+    const float* pbase = a.pos ? a.pos + h * dh : kbase;                 // (no table: the ring below is primed with key rows and unused)
+    const long ldp = a.pos ? a.ldp : a.ldk;
+    const int phi = a.pos ? 2 * a.pos_row0 : T - 1;
+    float4 px[kSfRing][C], kx[kSfRing][C];
+#pragma unroll
+    for (int d = 0; d < kSfRing; ++d) load_rows(pbase, ldp, rbase + (wave + 4 * d) * 16 + n, phi, px[d]);
+#pragma unroll
+    for (int d = 0; d < kSfRing; ++d) load_rows(kbase, a.ldk, (wave + 4 * d) * 16 + n, T - 1, kx[d]);
+    __syncthreads();                            // the staged queries
+    // B fragments of this lane's query: d = 16 c + 4 g + {0..3} (zeros past the head: what a dead chunk loaded counts for nothing)
+    float4 bu[C], bv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        bu[c] = *reinterpret_cast<const float4*>(qu + n * QLD + 16 * c + 4 * g);
+        bv[c] = *reinterpret_cast<const float4*>(qv + n * QLD + 16 * c + 4 * g);
+    }
+    // (ring slots are indexed statically - a rotating ring's register moves would read, i.e. wait for, the loads in flight;
+    // the last group of a stream multiplies up to kSfRing - 1 clamped tiles nobody stores)
+    for (int bi = 0; bi < my_rt; bi += kSfRing) {
+#pragma unroll
+        for (int d = 0; d < kSfRing; ++d) {
+            const int i = bi + d, rt = wave + 4 * i;
+            const f32x4 acc = dot_rows(px[d], bv);
+            if (i < my_rt) *reinterpret_cast<float4*>(G + n * GP + rt * 16 + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            load_rows(pbase, ldp, rbase + (rt + 4 * kSfRing) * 16 + n, phi, px[d]);     // past the end: a clamped row nobody uses
         }
     }
-    for (int kt = wave; kt < n_kt; kt += 4) {
-        const f32x4 acc = tile_dot(kbase, a.ldk, kt * 16 + n, T - 1, bu);
-        *reinterpret_cast<float4*>(S + n * SP + kt * 16 + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    float vx[kSfRing][4][C];
+#pragma unroll
+    for (int d = 0; d < kSfRing; ++d) load_v(wave + 4 * d, vx[d]);
+    for (int bi = 0; bi < my_kt; bi += kSfRing) {
+#pragma unroll
+        for (int d = 0; d < kSfRing; ++d) {
+            const int i = bi + d, kt = wave + 4 * i;
+            const f32x4 acc = dot_rows(kx[d], bu);
+            if (i < my_kt) *reinterpret_cast<float4*>(S + n * SP + kt * 16 + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            load_rows(kbase, a.ldk, (kt + 4 * kSfRing) * 16 + n, T - 1, kx[d]);
+        }
     }
     __syncthreads();
     // softmax of the four query rows of this wave
@@ -354,20 +408,22 @@ __global__ __launch_bounds__(256) void sf_attention_mfma_kernel(SfAttnArgs a) {
     f32x4 o[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = wave; kt < n_kt; kt += 4) {
-        const float4 p4 = *reinterpret_cast<const float4*>(S + n * SP + kt * 16 + 4 * g);
-        const float pe[4] = {p4.x, p4.y, p4.z, p4.w};
-        float vv[4][C];
+    for (int bi = 0; bi < my_kt; bi += kSfRing) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float* vr = vbase + (long)min(kt * 16 + 4 * g + e, T - 1) * a.ldv;
+        for (int d = 0; d < kSfRing; ++d) {
+            const int i = bi + d, kt = wave + 4 * i;
+            // (a tile past the wave's last one multiplies probabilities of 0: its S entries are not read - the index is clamped
+            // to the wave's own first tile and the products are masked to zero)
+            const int ktc = i < my_kt ? kt : wave;
+            float4 p4 = *reinterpret_cast<const float4*>(S + n * SP + ktc * 16 + 4 * g);
+            if (i >= my_kt) p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float pe[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
-            for (int c = 0; c < C; ++c) vv[e][c] = 16 * c + n < dh ? vr[16 * c + n] : 0.f;
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < C; ++c) o[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vx[d][e][c], pe[e], o[c], 0, 0, 0);
+            load_v(kt + 4 * kSfRing, vx[d]);
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int c = 0; c < C; ++c) o[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[e][c], pe[e], o[c], 0, 0, 0);
     }
     float* red = G;                              // [3][C][4][64]: the scores' G is dead by now
     if (wave > 0) {
